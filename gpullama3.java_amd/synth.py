@@ -1,0 +1,281 @@
+"""Synthetic random-weight models in the reference's wire format.
+
+There is no network and no .gguf on disk, so pp/tg are measured on random-weight models of the
+named architectures.  Values: f32 N(0, 0.02^2) for matrices, 1 + N(0, 0.02^2) for norm weights;
+quantised with ggml's reference Q8_0 / Q4_0 rules into exactly the block layout the reference
+reads (J/tensor/GGMLType.java:5-21; Q8_0FloatTensor.java:55-63; Q4_0FloatTensor.java:57-71).
+Tensor names follow J/model/loader/LlamaModelLoader.java:83-98 and Qwen3ModelLoader.java:96-118;
+metadata keys follow LlamaModelLoader.java:47-63 / Qwen3ModelLoader.java:48-74.
+
+Two generators: NumPy (bit-stable Philox stream, used for the committed golden fixtures) and
+torch (any device — the GPU box generates the 1B/8B models in HBM in seconds).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict
+
+import numpy as np
+
+from . import gguf
+from .gguf import GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0
+
+ARCH_LLAMA, ARCH_QWEN3 = 0, 1
+
+
+@dataclass
+class ModelConfig:
+    name: str
+    arch: int
+    dim: int
+    hidden: int
+    n_layers: int
+    n_heads: int
+    n_kv_heads: int
+    head_size: int
+    vocab: int
+    ctx: int
+    rms_eps: float
+    rope_theta: float
+    tied: bool          # wcls shares token_embd (AbstractModelLoader.java:194)
+
+    @property
+    def q_dim(self):
+        return self.n_heads * self.head_size
+
+    @property
+    def kv_dim(self):
+        return self.n_kv_heads * self.head_size
+
+
+CONFIGS = {
+    # BASELINE.json configs[1] / configs[2] / configs[4] and two tiny fixture shapes
+    "llama-3.2-1b": ModelConfig("Llama-3.2-1B-random", ARCH_LLAMA, 2048, 8192, 16, 32, 8, 64, 128256, 648, 1e-5, 500000.0, True),
+    "llama-3-8b": ModelConfig("Llama-3-8B-random", ARCH_LLAMA, 4096, 14336, 32, 32, 8, 128, 128256, 648, 1e-5, 500000.0, False),
+    "qwen3-4b": ModelConfig("Qwen3-4B-random", ARCH_QWEN3, 2560, 9728, 36, 32, 8, 128, 151936, 648, 1e-6, 1000000.0, True),
+    "tiny-llama": ModelConfig("tiny-llama-random", ARCH_LLAMA, 256, 512, 2, 8, 2, 32, 512, 64, 1e-5, 500000.0, False),
+    "tiny-llama-tied": ModelConfig("tiny-llama-tied-random", ARCH_LLAMA, 256, 768, 3, 8, 4, 32, 640, 48, 1e-5, 10000.0, True),
+    "tiny-qwen3": ModelConfig("tiny-qwen3-random", ARCH_QWEN3, 256, 512, 2, 8, 2, 64, 512, 64, 1e-6, 1000000.0, True),
+    # wide enough to exercise full 64-block chunks + ragged tails in the HIP matvec (K = 2560, 4096-wide q)
+    "mid-qwen3": ModelConfig("mid-qwen3-random", ARCH_QWEN3, 2560, 1536, 2, 32, 8, 128, 2048, 40, 1e-6, 1000000.0, True),
+    "mid-llama": ModelConfig("mid-llama-random", ARCH_LLAMA, 2048, 4096, 2, 32, 8, 64, 4096, 160, 1e-5, 500000.0, False),
+}
+
+
+# ------------------------------------------------------------------ quantisers (NumPy)
+def _round_away(x):
+    return np.trunc(x + np.copysign(np.float32(0.5), x))
+
+
+def quantize_q8_0(w: np.ndarray) -> np.ndarray:
+    """ggml quantize_row_q8_0_ref: d = amax/127 (stored f16), q = roundf(x / d)."""
+    w = np.ascontiguousarray(w, dtype=np.float32).reshape(-1, 32)
+    amax = np.max(np.abs(w), axis=1)
+    d = (amax / np.float32(127.0)).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        inv = np.where(d != 0, np.float32(1.0) / d, np.float32(0)).astype(np.float32)
+    q = _round_away(w * inv[:, None]).astype(np.int8)
+    out = np.empty((w.shape[0], 34), np.uint8)
+    out[:, :2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    out[:, 2:] = q.view(np.uint8)
+    return out.reshape(-1)
+
+
+def quantize_q4_0(w: np.ndarray) -> np.ndarray:
+    """ggml quantize_row_q4_0_ref: d = (signed max-magnitude)/-8, q = min(15, (int)(x/d + 8.5));
+    elem j<16 in the low nibble of byte j, elem j+16 in the high nibble."""
+    w = np.ascontiguousarray(w, dtype=np.float32).reshape(-1, 32)
+    idx = np.argmax(np.abs(w), axis=1)
+    mx = w[np.arange(w.shape[0]), idx]
+    d = (mx / np.float32(-8.0)).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        inv = np.where(d != 0, np.float32(1.0) / d, np.float32(0)).astype(np.float32)
+    x = w * inv[:, None] + np.float32(8.5)
+    qi = np.minimum(15, x.astype(np.int32)).astype(np.uint8)
+    out = np.empty((w.shape[0], 18), np.uint8)
+    out[:, :2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    out[:, 2:] = qi[:, :16] | (qi[:, 16:] << 4)
+    return out.reshape(-1)
+
+
+def encode(w: np.ndarray, ggml_type: int) -> np.ndarray:
+    if ggml_type == GGML_F32:
+        return np.ascontiguousarray(w, "<f4").view(np.uint8).reshape(-1)
+    if ggml_type == GGML_F16:
+        return np.ascontiguousarray(w, np.float32).astype("<f2").view(np.uint8).reshape(-1)
+    if ggml_type == GGML_Q8_0:
+        return quantize_q8_0(w)
+    if ggml_type == GGML_Q4_0:
+        return quantize_q4_0(w)
+    raise ValueError(ggml_type)
+
+
+def rope_table(ctx: int, head_size: int, theta: float):
+    """Host-side RoPE table, as the Java host builds it (RoPE.precomputeFreqsCis, ropeScaling=false,
+    J/inference/operation/RoPE.java:6-37): freq in double -> f32, pos*freq in f32, cos/sin in double -> f32."""
+    i = np.arange(0, head_size, 2, dtype=np.float64)
+    freq = (1.0 / np.power(np.float64(theta), i / np.float64(head_size))).astype(np.float32)
+    val = (np.arange(ctx, dtype=np.float32)[:, None] * freq[None, :]).astype(np.float32)
+    v64 = val.astype(np.float64)
+    return (np.ascontiguousarray(np.cos(v64).astype(np.float32).reshape(-1)),
+            np.ascontiguousarray(np.sin(v64).astype(np.float32).reshape(-1)))
+
+
+# ------------------------------------------------------------------ tensor list
+def tensor_specs(cfg: ModelConfig, wtype: int):
+    """(name, rows, cols, ggml_type, kind) in file order; kind: 'mat' | 'norm'."""
+    specs = [("token_embd.weight", cfg.vocab, cfg.dim, wtype, "mat")]
+    for l in range(cfg.n_layers):
+        p = f"blk.{l}."
+        specs += [
+            (p + "attn_norm.weight", 1, cfg.dim, GGML_F32, "norm"),
+            (p + "attn_q.weight", cfg.q_dim, cfg.dim, wtype, "mat"),
+            (p + "attn_k.weight", cfg.kv_dim, cfg.dim, wtype, "mat"),
+            (p + "attn_v.weight", cfg.kv_dim, cfg.dim, wtype, "mat"),
+            (p + "attn_output.weight", cfg.dim, cfg.q_dim, wtype, "mat"),
+        ]
+        if cfg.arch == ARCH_QWEN3:
+            specs += [(p + "attn_q_norm.weight", 1, cfg.head_size, GGML_F32, "norm"),
+                      (p + "attn_k_norm.weight", 1, cfg.head_size, GGML_F32, "norm")]
+        specs += [
+            (p + "ffn_norm.weight", 1, cfg.dim, GGML_F32, "norm"),
+            (p + "ffn_gate.weight", cfg.hidden, cfg.dim, wtype, "mat"),
+            (p + "ffn_down.weight", cfg.dim, cfg.hidden, wtype, "mat"),
+            (p + "ffn_up.weight", cfg.hidden, cfg.dim, wtype, "mat"),
+        ]
+    specs.append(("output_norm.weight", 1, cfg.dim, GGML_F32, "norm"))
+    if not cfg.tied:
+        specs.append(("output.weight", cfg.vocab, cfg.dim, wtype, "mat"))
+    return specs
+
+
+class SynthModel:
+    """cfg + tensors (name -> (raw uint8 ndarray, ggml_type, rows, cols)) + rope tables."""
+
+    def __init__(self, cfg: ModelConfig, wtype: int, tensors: dict):
+        self.cfg, self.wtype, self.tensors = cfg, wtype, tensors
+        self.rope = rope_table(cfg.ctx, cfg.head_size, cfg.rope_theta)
+
+    def oracle_tensors(self):
+        return {k: (v[0], v[1]) for k, v in self.tensors.items()}
+
+    def oracle_cfg(self):
+        c = self.cfg
+        return dict(arch=c.arch, dim=c.dim, hidden=c.hidden, n_layers=c.n_layers, n_heads=c.n_heads,
+                    n_kv_heads=c.n_kv_heads, head_size=c.head_size, vocab=c.vocab, ctx=c.ctx, rms_eps=c.rms_eps)
+
+    def weight_bytes(self):
+        return sum(v[0].nbytes for v in self.tensors.values())
+
+    # ---- GGUF round trip (metadata keys as the reference loaders read them)
+    def metadata(self):
+        c = self.cfg
+        a = "llama" if c.arch == ARCH_LLAMA else "qwen3"
+        ftype = {GGML_F32: 0, GGML_F16: 1, GGML_Q4_0: 2, GGML_Q8_0: 7}[self.wtype]
+        md = {
+            "general.architecture": a, "general.name": c.name, "general.file_type": ftype,
+            f"{a}.embedding_length": c.dim, f"{a}.feed_forward_length": c.hidden, f"{a}.block_count": c.n_layers,
+            f"{a}.attention.head_count": c.n_heads, f"{a}.attention.head_count_kv": c.n_kv_heads,
+            f"{a}.context_length": c.ctx, f"{a}.attention.layer_norm_rms_epsilon": float(c.rms_eps),
+            f"{a}.rope.freq_base": float(c.rope_theta), f"{a}.vocab_size": c.vocab,
+        }
+        if c.arch == ARCH_QWEN3:
+            md[f"{a}.attention.key_length"] = c.head_size
+            md[f"{a}.attention.value_length"] = c.head_size
+        return md
+
+    def write_gguf(self, path: str):
+        ts = []
+        for name, (raw, ty, rows, cols) in self.tensors.items():
+            dims = [cols] if rows == 1 and ty == GGML_F32 else [cols, rows]
+            ts.append((name, dims, ty, raw))
+        gguf.write_gguf(path, self.metadata(), ts)
+
+    @staticmethod
+    def from_gguf(path: str, ctx: int | None = None) -> "SynthModel":
+        g = gguf.GGUFFile(path)
+        md = g.metadata
+        a = md["general.architecture"]
+        arch = ARCH_LLAMA if a == "llama" else ARCH_QWEN3
+        dim, nh = md[f"{a}.embedding_length"], md[f"{a}.attention.head_count"]
+        hs = md.get(f"{a}.attention.key_length", dim // nh)
+        cfg = ModelConfig(md["general.name"], arch, dim, md[f"{a}.feed_forward_length"], md[f"{a}.block_count"], nh,
+                          md.get(f"{a}.attention.head_count_kv", nh), hs,
+                          md.get(f"{a}.vocab_size", g.tensors["token_embd.weight"][0][1]),
+                          ctx or md[f"{a}.context_length"], md[f"{a}.attention.layer_norm_rms_epsilon"],
+                          md[f"{a}.rope.freq_base"], "output.weight" not in g.tensors)
+        tensors = {}
+        for name, (dims, ty, raw) in g.tensors.items():
+            rows = dims[1] if len(dims) > 1 else 1
+            tensors[name] = (raw, ty, rows, dims[0])
+        m = SynthModel(cfg, g.tensors["token_embd.weight"][1], tensors)
+        m._gguf = g
+        return m
+
+
+def make_numpy(cfg: ModelConfig, wtype: int = GGML_Q8_0, seed: int = 42, sigma: float = 0.02) -> SynthModel:
+    """Bit-stable generator (NumPy Philox, streamed per tensor in file order)."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    tensors = {}
+    for name, rows, cols, ty, kind in tensor_specs(cfg, wtype):
+        w = rng.standard_normal((rows, cols), dtype=np.float32) * np.float32(sigma)
+        if kind == "norm":
+            w = w + np.float32(1.0)
+        tensors[name] = (encode(w, ty), ty, rows, cols)
+    return SynthModel(cfg, wtype, tensors)
+
+
+# ------------------------------------------------------------------ torch generator (1B / 8B scale)
+def _t_quantize_q8_0(w):
+    import torch
+    w = w.reshape(-1, 32)
+    amax = w.abs().amax(dim=1)
+    d = amax / 127.0
+    inv = torch.where(d != 0, 1.0 / d, torch.zeros_like(d))
+    x = w * inv[:, None]
+    q = torch.trunc(x + torch.copysign(torch.full_like(x, 0.5), x)).to(torch.int8)
+    out = torch.empty((w.shape[0], 34), dtype=torch.uint8, device=w.device)
+    out[:, :2] = d.to(torch.float16).view(torch.uint8).reshape(-1, 2)
+    out[:, 2:] = q.view(torch.uint8)
+    return out.reshape(-1)
+
+
+def _t_quantize_q4_0(w):
+    import torch
+    w = w.reshape(-1, 32)
+    idx = w.abs().argmax(dim=1, keepdim=True)
+    mx = w.gather(1, idx).squeeze(1)
+    d = mx / -8.0
+    inv = torch.where(d != 0, 1.0 / d, torch.zeros_like(d))
+    qi = torch.clamp((w * inv[:, None] + 8.5).to(torch.int32), max=15).to(torch.uint8)
+    out = torch.empty((w.shape[0], 18), dtype=torch.uint8, device=w.device)
+    out[:, :2] = d.to(torch.float16).view(torch.uint8).reshape(-1, 2)
+    out[:, 2:] = qi[:, :16] | (qi[:, 16:] << 4)
+    return out.reshape(-1)
+
+
+def make_torch(cfg: ModelConfig, wtype: int = GGML_Q8_0, seed: int = 42, sigma: float = 0.02, device="cpu",
+               rows_per_chunk: int = 16384) -> SynthModel:
+    """Same recipe with torch RNG on ``device``; raw bytes are returned as host NumPy arrays because
+    the C-ABI takes caller-owned host pointers (the Java host's mmap'd GGUF)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    tensors = {}
+    for name, rows, cols, ty, kind in tensor_specs(cfg, wtype):
+        parts = []
+        for r0 in range(0, rows, rows_per_chunk):
+            r = min(rows_per_chunk, rows - r0)
+            w = torch.randn((r, cols), generator=g, device=device, dtype=torch.float32) * sigma
+            if kind == "norm":
+                w = w + 1.0
+            if ty == GGML_F32:
+                b = w.contiguous().view(torch.uint8).reshape(-1)
+            elif ty == GGML_F16:
+                b = w.to(torch.float16).contiguous().view(torch.uint8).reshape(-1)
+            elif ty == GGML_Q8_0:
+                b = _t_quantize_q8_0(w)
+            else:
+                b = _t_quantize_q4_0(w)
+            parts.append(b.cpu().numpy())
+        tensors[name] = (np.concatenate(parts) if len(parts) > 1 else parts[0], ty, rows, cols)
+    return SynthModel(cfg, wtype, tensors)

@@ -1,0 +1,400 @@
+/*
+ * gl3_oracle.c — CPU restatement of GPULlama3.java's pure-Java forward pass.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle and the timed CPU
+ * baseline ("port") for the HIP path.  Nothing in the product path
+ * (gpullama3.java_amd/, include/, libgpullama_hip.so) links, imports or calls
+ * it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * PARITY UNPINNED: the reference ships no golden vectors, known-answer tests
+ * or fixtures for the forward pass and cannot be compiled
+ * here (no JDK).  This restatement is pinned instead by (1) hand-derived KATs
+ * (tests/test_oracle_kat.py) and (2) bit-for-bit agreement with an
+ * independent NumPy restatement (oracle/oracle_np.py).
+ *
+ * All citations are relative to /root/reference/src/main/java/org/beehive/gpullama3/
+ * (abbreviated J/).  Java numeric rules honoured here:
+ *   - float ops round to binary32 at every step, no FMA contraction
+ *     (compile with -ffp-contract=off, never -ffast-math);
+ *   - Math.sqrt/exp/pow/cos/sin are evaluated in double and then cast;
+ *   - Float.float16ToFloat / floatToFloat16 are IEEE (RNE, subnormals kept);
+ *   - (int) of a float truncates toward zero.
+ * Threading mirrors Parallel.parallelFor (J/auxiliary/Parallel.java:9-11):
+ * matmul rows and attention heads are fanned out, no cross-thread reductions,
+ * so results are independent of the thread count.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ggml type ids used by the wire format — J/tensor/GGMLType.java:5-21 */
+enum { ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q8_0 = 8 };
+
+/* tensor ids: same numbering as include/gpullama3_hip.h (gl3_tensor_id) */
+enum {
+    ORC_T_TOKEN_EMBD = 0, ORC_T_OUTPUT_NORM = 1, ORC_T_OUTPUT = 2,
+    ORC_T_ATTN_NORM = 3, ORC_T_WQ = 4, ORC_T_WK = 5, ORC_T_WV = 6, ORC_T_WO = 7,
+    ORC_T_FFN_NORM = 8, ORC_T_W1 = 9, ORC_T_W2 = 10, ORC_T_W3 = 11,
+    ORC_T_ATTN_Q_NORM = 12, ORC_T_ATTN_K_NORM = 13, ORC_T_COUNT = 14
+};
+
+typedef struct {
+    int32_t arch;       /* 0 = llama (InferenceCore.forwardJava), 1 = qwen3 (forwardJavaQwen3) */
+    int32_t dim, hidden, n_layers, n_heads, n_kv_heads, head_size, vocab, ctx;
+    float   rms_eps;
+} orc_config;
+
+typedef struct { const void* p; int type; } orc_tensor;
+
+typedef struct {
+    orc_config c;
+    orc_tensor global[3];
+    orc_tensor* layer[ORC_T_COUNT];       /* per-layer tensors, [id][layer] */
+    const float *rope_cr, *rope_ci;       /* freq_cis_real / freq_cis_imag, [ctx * head_size/2] */
+    /* State — J/inference/state/LlamaState.java:28-81 */
+    float *x, *xb, *xb2, *q, *k, *v, *hb, *hb2, *att, *logits;
+    float *key_cache, *value_cache;       /* [L][ctx][kvDim] */
+    int8_t* aq; float* ascale;            /* hoisted activation quantisation scratch */
+    int q_dim, kv_dim;
+} orc_ctx;
+
+/* ---- Float.float16ToFloat / Float.floatToFloat16 (IEEE binary16, RNE) ---- */
+ORC_API float orc_f16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else { /* subnormal: value = man * 2^-24 */
+            float f = (float)man * 5.9604644775390625e-08f;
+            memcpy(&bits, &f, 4); bits |= sign;
+        }
+    } else if (exp == 31) bits = sign | 0x7F800000u | (man << 13);
+    else bits = sign | ((exp + 112u) << 23) | (man << 13);
+    float out; memcpy(&out, &bits, 4); return out;
+}
+
+ORC_API uint16_t orc_f32_to_f16(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ax = x & 0x7FFFFFFFu;
+    if (ax >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((ax > 0x7F800000u) ? (0x200u | ((ax >> 13) & 0x3FFu)) : 0));
+    if (ax >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);        /* rounds to inf (>= 65520) */
+    if (ax < 0x33000001u) return (uint16_t)sign;                     /* <= 2^-25 rounds to 0 (tie to even) */
+    int e = (int)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7FFFFFu) | 0x800000u;
+    int shift = (e < -14) ? (13 + (-14 - e)) : 13;                  /* subnormal halves shift further */
+    uint32_t half_m = m >> shift;
+    uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (half_m & 1u))) half_m++;
+    uint32_t he = (e < -14) ? 0u : (uint32_t)(e + 15);
+    /* half_m carries the implicit bit for normals: adding it to (he-1)<<10 also handles mantissa carry */
+    uint32_t out = (e < -14) ? half_m : (((he - 1u) << 10) + half_m);
+    return (uint16_t)(sign | out);
+}
+
+static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+/* ---- element access: FloatTensor.getFloat per ggml type ------------------
+ * Q8_0FloatTensor.getFloat  J/tensor/standard/Q8_0FloatTensor.java:55-63
+ * Q4_0FloatTensor.getFloat  J/tensor/standard/Q4_0FloatTensor.java:57-71
+ * FP16FloatTensor.getFloat  J/tensor/standard/FP16FloatTensor.java:48-51      */
+static inline float t_get(const orc_tensor* t, size_t i) {
+    const uint8_t* p = (const uint8_t*)t->p;
+    switch (t->type) {
+    case ORC_F32: { float f; memcpy(&f, p + 4 * i, 4); return f; }
+    case ORC_F16: return orc_f16_to_f32(rd16(p + 2 * i));
+    case ORC_Q8_0: {
+        const uint8_t* b = p + (i / 32) * 34;
+        return (float)(int8_t)b[2 + (i % 32)] * orc_f16_to_f32(rd16(b));
+    }
+    case ORC_Q4_0: {
+        const uint8_t* b = p + (i / 32) * 18;
+        size_t m = i % 32; int qv;
+        if (m < 16) qv = b[2 + m] & 0x0F; else qv = (b[2 + m - 16] >> 4) & 0x0F;
+        return (float)(int8_t)(qv - 8) * orc_f16_to_f32(rd16(b));
+    }
+    }
+    return 0.f;
+}
+
+/* ---- Q8_0 activation quantisation, hoisted out of dotQ8Activation --------
+ * J/tensor/standard/Q8_0FloatTensor.java:90-123.  The Java code re-quantises
+ * the activation block inside every row's dot; the values depend only on the
+ * activation, so computing them once per matmul is the same arithmetic.      */
+static void quantize_act(const float* x, int n, int8_t* aq, float* ascale) {
+    for (int b = 0; b < n / 32; b++) {
+        float amax = 0.f;
+        for (int i = 0; i < 32; i++) { float av = fabsf(x[b * 32 + i]); if (av > amax) amax = av; }
+        float qs = amax / 127.f;
+        ascale[b] = orc_f16_to_f32(orc_f32_to_f16(qs));
+        float ainv = qs != 0.f ? 1.f / qs : 0.f;
+        for (int i = 0; i < 32; i++) {
+            float s = x[b * 32 + i] * ainv;
+            aq[b * 32 + i] = (int8_t)(int)(s + copysignf(0.5f, s));
+        }
+    }
+}
+
+static inline float dot_q8(const uint8_t* wrow, const int8_t* aq, const float* ascale, int n) {
+    float result = 0.f;
+    for (int b = 0; b < n / 32; b++) {
+        const uint8_t* blk = wrow + b * 34;
+        float wscale = orc_f16_to_f32(rd16(blk));
+        const int8_t* wq = (const int8_t*)(blk + 2);
+        int isum = 0;
+        for (int i = 0; i < 32; i++) isum += (int)aq[b * 32 + i] * (int)wq[i];
+        result += (float)isum * (wscale * ascale[b]);
+    }
+    return result;
+}
+
+/* FloatTensor.scalarDot  J/tensor/standard/FloatTensor.java:86-92 */
+static inline float dot_scalar(const orc_tensor* w, size_t off, const float* x, int n) {
+    float result = 0.f;
+    for (int j = 0; j < n; j++) result += t_get(w, off + j) * x[j];
+    return result;
+}
+
+/* FloatTensor.matmul  J/tensor/standard/FloatTensor.java:98-100 (rows in parallel) */
+static void matmul(orc_ctx* o, const orc_tensor* w, const float* x, float* out, int d0, int d1) {
+    if (w->type == ORC_Q8_0) {
+        quantize_act(x, d1, o->aq, o->ascale);
+        const uint8_t* base = (const uint8_t*)w->p;
+        size_t rb = (size_t)(d1 / 32) * 34;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < d0; i++) out[i] = dot_q8(base + (size_t)i * rb, o->aq, o->ascale, d1);
+    } else {
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < d0; i++) out[i] = dot_scalar(w, (size_t)i * d1, x, d1);
+    }
+}
+
+/* InferenceCore.rmsnorm  J/inference/InferenceCore.java:39-48 */
+static void rmsnorm(float* out, const float* x, const orc_tensor* w, int offset, int size, float eps) {
+    float ss = 0.f;
+    for (int i = 0; i < size; i++) { float xi = x[offset + i]; ss = ss + xi * xi; }
+    ss /= (float)size;
+    ss += eps;
+    ss = (float)(1.0 / sqrt((double)ss));
+    for (int i = 0; i < size; i++) out[offset + i] = t_get(w, i) * (ss * x[offset + i]);
+}
+
+/* FloatTensor.softmaxInPlace  J/tensor/standard/FloatTensor.java:211-219 */
+static void softmax(float* a, int n) {
+    float maxv = -INFINITY;
+    for (int i = 0; i < n; i++) maxv = fmaxf(maxv, a[i]);
+    for (int i = 0; i < n; i++) a[i] = (float)exp((double)(a[i] - maxv));
+    float sum = 0.f;
+    for (int i = 0; i < n; i++) sum += a[i];
+    for (int i = 0; i < n; i++) a[i] = a[i] / sum;
+}
+
+/* Attention over the KV cache — J/inference/InferenceCore.java:98-137 (Llama)
+ * and :631-663 (Qwen3); identical arithmetic, head_size taken from config.   */
+static void attention(orc_ctx* o, int l, int pos) {
+    const orc_config* c = &o->c;
+    int hs = c->head_size, kvd = o->kv_dim, kvmul = c->n_heads / c->n_kv_heads;
+    float sqrt_hs = (float)sqrt((double)hs);
+    const float* kc = o->key_cache + (size_t)l * c->ctx * kvd;
+    const float* vc = o->value_cache + (size_t)l * c->ctx * kvd;
+#pragma omp parallel for schedule(static)
+    for (int h = 0; h < c->n_heads; h++) {
+        const float* q = o->q + h * hs;
+        float* att = o->att + (size_t)h * c->ctx;
+        for (int t = 0; t <= pos; t++) {
+            const float* kk = kc + (size_t)t * kvd + (h / kvmul) * hs;
+            float score = 0.f;
+            for (int j = 0; j < hs; j++) score += q[j] * kk[j];
+            att[t] = score / sqrt_hs;
+        }
+        softmax(att, pos + 1);
+        float* xb = o->xb + h * hs;
+        for (int j = 0; j < hs; j++) xb[j] = 0.f;
+        for (int t = 0; t <= pos; t++) {
+            const float* vv = vc + (size_t)t * kvd + (h / kvmul) * hs;
+            float a = att[t];
+            for (int j = 0; j < hs; j++) xb[j] = a * vv[j] + xb[j];   /* saxpyInPlace :221-227 */
+        }
+    }
+}
+
+/* One transformer step.  arch 0: InferenceCore.forwardJava :50-172;
+ * arch 1: forwardJavaQwen3 :565-697.  want_logits=0 reproduces the prefill
+ * variants (InferenceCoreWithPrefillDecode.forwardJavaPrefill :47-132 and the
+ * per-token arithmetic of batchForwardJavaPrefill,
+ * InferenceCoreBatchPrefillDecode.java:62-168 — same dot, same sequential
+ * attention, so the KV cache written is bit-identical).  layer_x, if not NULL,
+ * receives x after every layer ([L][dim], the parity tap).                    */
+static void forward(orc_ctx* o, int token, int pos, int want_logits, float* layer_x) {
+    const orc_config* c = &o->c;
+    int dim = c->dim, hs = c->head_size, kvd = o->kv_dim, qd = o->q_dim;
+    /* weights.token_embedding_table.copyTo(token * dim, state.x, 0, dim) */
+    for (int i = 0; i < dim; i++) o->x[i] = t_get(&o->global[ORC_T_TOKEN_EMBD], (size_t)token * dim + i);
+
+    for (int l = 0; l < c->n_layers; l++) {
+        rmsnorm(o->xb, o->x, &o->layer[ORC_T_ATTN_NORM][l], 0, dim, c->rms_eps);
+        matmul(o, &o->layer[ORC_T_WQ][l], o->xb, o->q, qd, dim);
+        matmul(o, &o->layer[ORC_T_WK][l], o->xb, o->k, kvd, dim);
+        matmul(o, &o->layer[ORC_T_WV][l], o->xb, o->v, kvd, dim);
+
+        if (c->arch == 0) {
+            /* adjacent-pair RoPE, q for i<dim and k for i<kvDim — InferenceCore.java:75-87 */
+            for (int i = 0; i < dim; i += 2) {
+                int head_dim = i % hs;
+                float fcr = o->rope_cr[(size_t)pos * (hs / 2) + head_dim / 2];
+                float fci = o->rope_ci[(size_t)pos * (hs / 2) + head_dim / 2];
+                int rotn = i < kvd ? 2 : 1;
+                for (int v = 0; v < rotn; v++) {
+                    float* vec = v == 0 ? o->q : o->k;
+                    float v0 = vec[i], v1 = vec[i + 1];
+                    vec[i] = v0 * fcr - v1 * fci;
+                    vec[i + 1] = v0 * fci + v1 * fcr;
+                }
+            }
+        } else {
+            /* per-head Q/K RMSNorm then NeoX RoPE — InferenceCore.java:594-619 */
+            for (int i = 0; i < c->n_heads; i++) rmsnorm(o->q, o->q, &o->layer[ORC_T_ATTN_Q_NORM][l], i * hs, hs, c->rms_eps);
+            for (int i = 0; i < c->n_kv_heads; i++) rmsnorm(o->k, o->k, &o->layer[ORC_T_ATTN_K_NORM][l], i * hs, hs, c->rms_eps);
+            int half = hs / 2;
+            for (int h = 0; h < c->n_heads; h++) {
+                int rotn = h < c->n_kv_heads ? 2 : 1, poff = h * hs;
+                for (int ic = 0; ic < half; ic++) {
+                    float fcr = o->rope_cr[(size_t)pos * half + ic];
+                    float fci = o->rope_ci[(size_t)pos * half + ic];
+                    for (int vi = 0; vi < rotn; vi++) {
+                        float* vec = vi == 0 ? o->q : o->k;
+                        float v0 = vec[poff + ic], v1 = vec[poff + ic + half];
+                        vec[poff + ic] = v0 * fcr - v1 * fci;
+                        vec[poff + ic + half] = v0 * fci + v1 * fcr;
+                    }
+                }
+            }
+        }
+        /* KV write — InferenceCore.java:92-93 */
+        memcpy(o->key_cache + ((size_t)l * c->ctx + pos) * kvd, o->k, sizeof(float) * kvd);
+        memcpy(o->value_cache + ((size_t)l * c->ctx + pos) * kvd, o->v, sizeof(float) * kvd);
+
+        attention(o, l, pos);
+
+        matmul(o, &o->layer[ORC_T_WO][l], o->xb, o->xb2, dim, qd);
+        for (int i = 0; i < dim; i++) o->x[i] = o->x[i] + o->xb2[i];
+
+        rmsnorm(o->xb, o->x, &o->layer[ORC_T_FFN_NORM][l], 0, dim, c->rms_eps);
+        matmul(o, &o->layer[ORC_T_W1][l], o->xb, o->hb, c->hidden, dim);
+        matmul(o, &o->layer[ORC_T_W3][l], o->xb, o->hb2, c->hidden, dim);
+        /* SwiGLU — InferenceCore.java:155-158: exp in double */
+        for (int i = 0; i < c->hidden; i++) {
+            float v = o->hb[i];
+            v = v / (float)(1.0 + exp(-(double)v));
+            o->hb[i] = v * o->hb2[i];
+        }
+        matmul(o, &o->layer[ORC_T_W2][l], o->hb, o->xb, dim, c->hidden);
+        for (int i = 0; i < dim; i++) o->x[i] = o->x[i] + o->xb[i];
+        if (layer_x) memcpy(layer_x + (size_t)l * dim, o->x, sizeof(float) * dim);
+    }
+    if (!want_logits) return;
+    rmsnorm(o->x, o->x, &o->global[ORC_T_OUTPUT_NORM], 0, dim, c->rms_eps);
+    matmul(o, &o->global[ORC_T_OUTPUT], o->x, o->logits, c->vocab, dim);
+}
+
+/* ------------------------------- C API ----------------------------------- */
+ORC_API orc_ctx* orc_create(const orc_config* cfg) {
+    orc_ctx* o = (orc_ctx*)calloc(1, sizeof(orc_ctx));
+    o->c = *cfg;
+    const orc_config* c = &o->c;
+    o->q_dim = c->n_heads * c->head_size;
+    o->kv_dim = c->n_kv_heads * c->head_size;
+    for (int i = 0; i < ORC_T_COUNT; i++) o->layer[i] = (orc_tensor*)calloc(c->n_layers, sizeof(orc_tensor));
+    int big = c->dim > o->q_dim ? c->dim : o->q_dim;
+    int maxk = big > c->hidden ? big : c->hidden;
+    o->x = calloc(c->dim, 4); o->xb = calloc(big, 4); o->xb2 = calloc(c->dim, 4);
+    o->q = calloc(o->q_dim, 4); o->k = calloc(o->kv_dim, 4); o->v = calloc(o->kv_dim, 4);
+    o->hb = calloc(c->hidden, 4); o->hb2 = calloc(c->hidden, 4);
+    o->att = calloc((size_t)c->n_heads * c->ctx, 4); o->logits = calloc(c->vocab, 4);
+    o->key_cache = calloc((size_t)c->n_layers * c->ctx * o->kv_dim, 4);
+    o->value_cache = calloc((size_t)c->n_layers * c->ctx * o->kv_dim, 4);
+    o->aq = malloc(maxk); o->ascale = malloc(sizeof(float) * (maxk / 32 + 1));
+    return o;
+}
+
+ORC_API void orc_destroy(orc_ctx* o) {
+    if (!o) return;
+    for (int i = 0; i < ORC_T_COUNT; i++) free(o->layer[i]);
+    free(o->x); free(o->xb); free(o->xb2); free(o->q); free(o->k); free(o->v); free(o->hb); free(o->hb2);
+    free(o->att); free(o->logits); free(o->key_cache); free(o->value_cache); free(o->aq); free(o->ascale);
+    free(o);
+}
+
+/* host pointer stays owned by the caller (the mmap'd GGUF tensor-data section) */
+ORC_API int orc_set_tensor(orc_ctx* o, int id, int layer, const void* p, int ggml_type) {
+    if (id < 0 || id >= ORC_T_COUNT) return -1;
+    if (id <= ORC_T_OUTPUT) { o->global[id].p = p; o->global[id].type = ggml_type; return 0; }
+    if (layer < 0 || layer >= o->c.n_layers) return -1;
+    o->layer[id][layer].p = p; o->layer[id][layer].type = ggml_type; return 0;
+}
+
+ORC_API void orc_set_rope(orc_ctx* o, const float* cr, const float* ci) { o->rope_cr = cr; o->rope_ci = ci; }
+
+ORC_API void orc_forward(orc_ctx* o, int token, int pos, float* logits_out, float* layer_x) {
+    forward(o, token, pos, 1, layer_x);
+    if (logits_out) memcpy(logits_out, o->logits, sizeof(float) * o->c.vocab);
+}
+
+ORC_API void orc_prefill(orc_ctx* o, const int32_t* tokens, int n, int start_pos) {
+    for (int b = 0; b < n; b++) forward(o, tokens[b], start_pos + b, 0, NULL);
+}
+
+ORC_API void orc_get_x(orc_ctx* o, float* out) { memcpy(out, o->x, sizeof(float) * o->c.dim); }
+
+ORC_API void orc_get_kv(orc_ctx* o, int layer, int pos, float* k_out, float* v_out) {
+    size_t off = ((size_t)layer * o->c.ctx + pos) * o->kv_dim;
+    memcpy(k_out, o->key_cache + off, sizeof(float) * o->kv_dim);
+    memcpy(v_out, o->value_cache + off, sizeof(float) * o->kv_dim);
+}
+
+/* Sampler.TENSOR_ARGMAX → FloatTensor.argmax  J/tensor/standard/FloatTensor.java:138-151:
+ * first index of the maximum (strict >), NaN never selected.                   */
+ORC_API int orc_argmax(const float* v, int n) {
+    int mi = 0; float mv = v[0];
+    for (int i = 0; i < n; i++) if (v[i] > mv) { mv = v[i]; mi = i; }
+    return mi;
+}
+
+/* RoPE.precomputeFreqsCis (ropeScaling=false branch)  J/inference/operation/RoPE.java:6-37 */
+ORC_API void orc_rope_table(int ctx, int head_size, double theta, float* cr, float* ci) {
+    size_t n = 0;
+    for (int pos = 0; pos < ctx; ++pos)
+        for (int i = 0; i < head_size; i += 2) {
+            float freq = (float)(1.0 / pow(theta, i / (double)head_size));
+            float val = pos * freq;
+            cr[n] = (float)cos((double)val);
+            ci[n] = (float)sin((double)val);
+            n++;
+        }
+}
+
+/* stand-alone pieces exported for known-answer tests */
+ORC_API void orc_quantize_act(const float* x, int n, int8_t* aq, float* ascale) { quantize_act(x, n, aq, ascale); }
+ORC_API float orc_dot_q8(const uint8_t* wrow, const float* x, int n) {
+    int8_t* aq = malloc(n); float* as = malloc(sizeof(float) * (n / 32 + 1));
+    quantize_act(x, n, aq, as);
+    float r = dot_q8(wrow, aq, as, n); free(aq); free(as); return r;
+}
+ORC_API float orc_get_float(const void* p, int type, long i) { orc_tensor t = {p, type}; return t_get(&t, (size_t)i); }
+ORC_API void orc_rmsnorm(float* out, const float* x, const float* w, int size, float eps) {
+    orc_tensor t = {w, ORC_F32}; rmsnorm(out, x, &t, 0, size, eps);
+}
+ORC_API void orc_softmax(float* a, int n) { softmax(a, n); }
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

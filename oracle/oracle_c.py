@@ -1,0 +1,134 @@
+"""ctypes wrapper over oracle/libgl3_oracle.so (the C restatement; see gl3_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never by gpullama3.java_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "libgl3_oracle.so")
+
+T_IDS = {"token_embd.weight": 0, "output_norm.weight": 1, "output.weight": 2, "attn_norm.weight": 3,
+         "attn_q.weight": 4, "attn_k.weight": 5, "attn_v.weight": 6, "attn_output.weight": 7,
+         "ffn_norm.weight": 8, "ffn_gate.weight": 9, "ffn_down.weight": 10, "ffn_up.weight": 11,
+         "attn_q_norm.weight": 12, "attn_k_norm.weight": 13}
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("arch", "dim", "hidden", "n_layers", "n_heads", "n_kv_heads",
+                                          "head_size", "vocab", "ctx")] + [("rms_eps", C.c_float)]
+
+
+def build(force: bool = False):
+    src = os.path.join(_DIR, "gl3_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _DIR, "-B"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(OrcConfig)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_tensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_set_rope.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_get_x.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_argmax.argtypes = [C.c_void_p, C.c_int]
+        L.orc_rope_table.argtypes = [C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_f16_to_f32.restype = C.c_float
+        L.orc_f16_to_f32.argtypes = [C.c_uint16]
+        L.orc_f32_to_f16.restype = C.c_uint16
+        L.orc_f32_to_f16.argtypes = [C.c_float]
+        L.orc_quantize_act.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_dot_q8.restype = C.c_float
+        L.orc_dot_q8.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_get_float.restype = C.c_float
+        L.orc_get_float.argtypes = [C.c_void_p, C.c_int, C.c_long]
+        L.orc_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+        L.orc_softmax.argtypes = [C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class COracle:
+    """Same call surface as the HIP plan: forward(token, pos) -> logits, prefill(tokens, start)."""
+
+    def __init__(self, model):
+        """model: gpullama3.java_amd synth.SynthModel-like (cfg, tensors name->(raw, type, ...), rope)."""
+        L = lib()
+        c = model.cfg
+        self.cfg = c
+        oc = OrcConfig(c.arch, c.dim, c.hidden, c.n_layers, c.n_heads, c.n_kv_heads, c.head_size, c.vocab, c.ctx, c.rms_eps)
+        self._h = L.orc_create(C.byref(oc))
+        self._keep = [model]
+        for name, t in model.tensors.items():
+            raw, ty = t[0], t[1]
+            if name.startswith("blk."):
+                _, l, rest = name.split(".", 2)
+                L.orc_set_tensor(self._h, T_IDS[rest], int(l), _p(raw), ty)
+            else:
+                L.orc_set_tensor(self._h, T_IDS[name], 0, _p(raw), ty)
+        if "output.weight" not in model.tensors:      # tied: wcls = token_embd
+            raw, ty = model.tensors["token_embd.weight"][:2]
+            L.orc_set_tensor(self._h, T_IDS["output.weight"], 0, _p(raw), ty)
+        self._cr, self._ci = model.rope
+        L.orc_set_rope(self._h, _p(self._cr), _p(self._ci))
+
+    def forward(self, token: int, pos: int, layer_x: bool = False):
+        c = self.cfg
+        logits = np.empty(c.vocab, np.float32)
+        lx = np.empty((c.n_layers, c.dim), np.float32) if layer_x else None
+        lib().orc_forward(self._h, token, pos, _p(logits), _p(lx) if layer_x else None)
+        return (logits, lx) if layer_x else logits
+
+    def prefill(self, tokens, start_pos: int):
+        t = np.ascontiguousarray(tokens, np.int32)
+        lib().orc_prefill(self._h, _p(t), len(t), start_pos)
+
+    def x(self):
+        out = np.empty(self.cfg.dim, np.float32)
+        lib().orc_get_x(self._h, _p(out))
+        return out
+
+    def kv(self, layer: int, pos: int):
+        kvd = self.cfg.n_kv_heads * self.cfg.head_size
+        k, v = np.empty(kvd, np.float32), np.empty(kvd, np.float32)
+        lib().orc_get_kv(self._h, layer, pos, _p(k), _p(v))
+        return k, v
+
+    def close(self):
+        if self._h:
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def argmax(v: np.ndarray) -> int:
+    v = np.ascontiguousarray(v, np.float32)
+    return lib().orc_argmax(_p(v), v.size)

@@ -1,0 +1,203 @@
+"""NumPy restatement of GPULlama3.java's pure-Java forward pass (second, independent oracle).
+
+TEST INFRASTRUCTURE ONLY — never imported by the product path (gpullama3.java_amd/).
+PARITY UNPINNED: the reference holds no golden vectors for this path; this file
+and oracle/gl3_oracle.c are written independently from the Java source and must agree bit for
+bit (tests/test_oracle_cross.py), plus the hand-derived KATs in tests/test_oracle_kat.py.
+
+Citations are relative to /root/reference/src/main/java/org/beehive/gpullama3/ (J/).
+
+Numeric rules: every float op rounds to binary32 (NumPy float32 ufuncs), no FMA; sequential
+sums use ``np.add.accumulate`` (strict left-to-right in float32 — unlike ``np.sum`` it never
+pairwise-reassociates); Math.exp/sqrt/pow/cos/sin are evaluated in float64 and cast.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0 = 0, 1, 2, 8
+# block size / type size — J/tensor/GGMLType.java:5-21
+BLOCK = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_Q4_0: (32, 18), GGML_Q8_0: (32, 34)}
+
+
+def seq_sum(a: np.ndarray, axis: int = -1) -> np.ndarray:
+    """Strict left-to-right float32 sum along ``axis`` starting from 0f (0+a0 == a0 exactly)."""
+    a = np.asarray(a, dtype=F32)
+    return np.take(np.add.accumulate(a, axis=axis, dtype=F32), -1, axis=axis)
+
+
+def dequant(raw: np.ndarray, ggml_type: int, n: int) -> np.ndarray:
+    """FloatTensor.getFloat for every element — Q8_0FloatTensor.java:55-63, Q4_0FloatTensor.java:57-71,
+    FP16FloatTensor.java:48-51."""
+    raw = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw.view(np.uint8).reshape(-1)
+    if ggml_type == GGML_F32:
+        return raw[: 4 * n].view(F32).copy()
+    if ggml_type == GGML_F16:
+        return raw[: 2 * n].view(np.float16).astype(F32)
+    if ggml_type == GGML_Q8_0:
+        blk = raw[: n // 32 * 34].reshape(-1, 34)
+        d = blk[:, :2].copy().view(np.float16).astype(F32)          # [nb,1]
+        q = blk[:, 2:].view(np.int8).astype(F32)                     # [nb,32]
+        return (q * d).reshape(-1)
+    if ggml_type == GGML_Q4_0:
+        blk = raw[: n // 32 * 18].reshape(-1, 18)
+        d = blk[:, :2].copy().view(np.float16).astype(F32)
+        lo = (blk[:, 2:] & 0x0F).astype(np.int8) - 8
+        hi = (blk[:, 2:] >> 4).astype(np.int8) - 8
+        q = np.concatenate([lo, hi], axis=1).astype(F32)
+        return (q * d).reshape(-1)
+    raise ValueError(ggml_type)
+
+
+def quantize_act(x: np.ndarray):
+    """Activation side of dotQ8Activation — J/tensor/standard/Q8_0FloatTensor.java:90-123."""
+    xb = np.asarray(x, dtype=F32).reshape(-1, 32)
+    amax = np.max(np.abs(xb), axis=1).astype(F32)
+    qs = amax / F32(127.0)
+    ascale = qs.astype(np.float16).astype(F32)
+    with np.errstate(divide="ignore"):
+        ainv = np.where(qs != 0, F32(1.0) / qs, F32(0.0)).astype(F32)
+    s = xb * ainv[:, None]
+    aq = np.trunc(s + np.copysign(F32(0.5), s)).astype(np.int32)
+    return aq, ascale
+
+
+def matmul(w_raw, ggml_type: int, x: np.ndarray, d0: int, d1: int) -> np.ndarray:
+    """FloatTensor.matmul (J/tensor/standard/FloatTensor.java:98-100) with the per-type dot."""
+    x = np.asarray(x, dtype=F32)
+    raw = w_raw.view(np.uint8).reshape(-1)
+    if ggml_type == GGML_Q8_0:
+        nb = d1 // 32
+        blk = raw[: d0 * nb * 34].reshape(d0, nb, 34)
+        wscale = blk[:, :, :2].copy().view(np.float16).astype(F32).reshape(d0, nb)
+        wq = blk[:, :, 2:].view(np.int8).astype(np.int32)           # [d0,nb,32]
+        aq, ascale = quantize_act(x)
+        isum = np.einsum("rbi,bi->rb", wq, aq).astype(np.int32)      # exact int32
+        prod = isum.astype(F32) * (wscale * ascale[None, :])          # isum * (wScale * aScale)
+        return seq_sum(prod, axis=1)                                   # result += ..., b ascending
+    # scalar mode: result += getFloat(j) * x[j]  — FloatTensor.java:86-92
+    w = dequant(raw, ggml_type, d0 * d1).reshape(d0, d1)
+    return seq_sum(w * x[None, :], axis=1)
+
+
+def rmsnorm(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
+    """InferenceCore.rmsnorm — J/inference/InferenceCore.java:39-48."""
+    x = np.asarray(x, dtype=F32)
+    ss = seq_sum(x * x)
+    ss = F32(ss / F32(x.size))
+    ss = F32(ss + F32(eps))
+    ss = F32(1.0 / np.sqrt(np.float64(ss)))
+    return (np.asarray(w, dtype=F32) * (ss * x)).astype(F32)
+
+
+def softmax(a: np.ndarray) -> np.ndarray:
+    """FloatTensor.softmaxInPlace — J/tensor/standard/FloatTensor.java:211-219."""
+    a = np.asarray(a, dtype=F32)
+    m = np.max(a)
+    e = np.exp((a - m).astype(np.float64)).astype(F32)
+    return (e / seq_sum(e)).astype(F32)
+
+
+def rope_table(ctx: int, head_size: int, theta: float):
+    """RoPE.precomputeFreqsCis, ropeScaling=false — J/inference/operation/RoPE.java:6-37."""
+    i = np.arange(0, head_size, 2, dtype=np.float64)
+    freq = (1.0 / np.power(np.float64(theta), i / np.float64(head_size))).astype(F32)
+    val = (np.arange(ctx, dtype=F32)[:, None] * freq[None, :]).astype(F32)
+    return np.cos(val.astype(np.float64)).astype(F32).reshape(-1), np.sin(val.astype(np.float64)).astype(F32).reshape(-1)
+
+
+class NpOracle:
+    """Holds config, raw GGUF-layout tensors and the State arrays (LlamaState.java:28-81)."""
+
+    def __init__(self, cfg: dict, tensors: dict, rope):
+        self.c = cfg
+        self.t = tensors          # name -> (raw uint8 ndarray, ggml_type)
+        self.cr, self.ci = rope
+        c = cfg
+        self.q_dim = c["n_heads"] * c["head_size"]
+        self.kv_dim = c["n_kv_heads"] * c["head_size"]
+        self.kc = np.zeros((c["n_layers"], c["ctx"], self.kv_dim), F32)
+        self.vc = np.zeros((c["n_layers"], c["ctx"], self.kv_dim), F32)
+
+    def _mm(self, name, x, d0, d1):
+        raw, ty = self.t[name]
+        return matmul(raw, ty, x, d0, d1)
+
+    def _f32(self, name, n):
+        raw, ty = self.t[name]
+        return dequant(raw, ty, n)
+
+    def forward(self, token: int, pos: int, want_logits: bool = True, layer_x: list | None = None):
+        c = self.c
+        dim, hs, kvd, qd, hid = c["dim"], c["head_size"], self.kv_dim, self.q_dim, c["hidden"]
+        H, KVH = c["n_heads"], c["n_kv_heads"]
+        kvmul = H // KVH
+        eps = c["rms_eps"]
+        emb_raw, emb_ty = self.t["token_embd.weight"]
+        bs, ts = BLOCK[emb_ty]
+        row = emb_raw.view(np.uint8).reshape(-1)[token * dim // bs * ts: (token + 1) * dim // bs * ts]
+        x = dequant(row, emb_ty, dim)
+        half = hs // 2
+        fcr = self.cr[pos * half:(pos + 1) * half]
+        fci = self.ci[pos * half:(pos + 1) * half]
+        for l in range(c["n_layers"]):
+            p = f"blk.{l}."
+            xb = rmsnorm(x, self._f32(p + "attn_norm.weight", dim), eps)
+            q = self._mm(p + "attn_q.weight", xb, qd, dim)
+            k = self._mm(p + "attn_k.weight", xb, kvd, dim)
+            v = self._mm(p + "attn_v.weight", xb, kvd, dim)
+            if c["arch"] == 0:   # InferenceCore.java:75-87, adjacent pairs
+                def rot(vec):
+                    vv = vec.reshape(-1, half, 2)
+                    v0, v1 = vv[:, :, 0], vv[:, :, 1]
+                    out = np.empty_like(vv)
+                    out[:, :, 0] = v0 * fcr - v1 * fci
+                    out[:, :, 1] = v0 * fci + v1 * fcr
+                    return out.reshape(-1)
+            else:                # InferenceCore.java:594-619, per-head norm + NeoX pairs
+                qn = self._f32(p + "attn_q_norm.weight", hs)
+                kn = self._f32(p + "attn_k_norm.weight", hs)
+                q = np.concatenate([rmsnorm(q[h * hs:(h + 1) * hs], qn, eps) for h in range(H)])
+                k = np.concatenate([rmsnorm(k[h * hs:(h + 1) * hs], kn, eps) for h in range(KVH)])
+
+                def rot(vec):
+                    vv = vec.reshape(-1, 2, half)
+                    v0, v1 = vv[:, 0, :], vv[:, 1, :]
+                    out = np.empty_like(vv)
+                    out[:, 0, :] = v0 * fcr - v1 * fci
+                    out[:, 1, :] = v0 * fci + v1 * fcr
+                    return out.reshape(-1)
+            q, k = rot(q.astype(F32)), rot(k.astype(F32))
+            self.kc[l, pos] = k
+            self.vc[l, pos] = v
+            sqrt_hs = F32(np.sqrt(np.float64(hs)))
+            xb = np.zeros(qd, F32)
+            for h in range(H):   # InferenceCore.java:98-137
+                qh = q[h * hs:(h + 1) * hs]
+                kk = self.kc[l, :pos + 1, (h // kvmul) * hs:(h // kvmul + 1) * hs]
+                score = seq_sum(kk * qh[None, :], axis=1) / sqrt_hs
+                a = softmax(score)
+                vv = self.vc[l, :pos + 1, (h // kvmul) * hs:(h // kvmul + 1) * hs]
+                xb[h * hs:(h + 1) * hs] = seq_sum(a[:, None] * vv, axis=0)
+            x = x + self._mm(p + "attn_output.weight", xb, dim, qd)
+            xb = rmsnorm(x, self._f32(p + "ffn_norm.weight", dim), eps)
+            hb = self._mm(p + "ffn_gate.weight", xb, hid, dim)
+            hb2 = self._mm(p + "ffn_up.weight", xb, hid, dim)
+            sig = (1.0 + np.exp(-hb.astype(np.float64))).astype(F32)   # (float)(1.0 + Math.exp(-value))
+            hb = (hb / sig) * hb2
+            x = x + self._mm(p + "ffn_down.weight", hb.astype(F32), dim, hid)
+            if layer_x is not None:
+                layer_x.append(x.copy())
+        self.x = x
+        if not want_logits:
+            return None
+        x = rmsnorm(x, self._f32("output_norm.weight", dim), eps)
+        name = "output.weight" if "output.weight" in self.t else "token_embd.weight"
+        return self._mm(name, x, c["vocab"], dim)
+
+
+def argmax(v: np.ndarray) -> int:
+    """FloatTensor.argmax — first index of the maximum (FloatTensor.java:138-151)."""
+    return int(np.argmax(v))

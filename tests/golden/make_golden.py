@@ -1,0 +1,51 @@
+"""Generates tests/golden/*.npz with the NumPy oracle (oracle/oracle_np.py).
+
+PARITY UNPINNED: the reference has no golden vectors for the forward pass and
+cannot run here, so these fixtures are produced by this repo's own restatement; they guard the
+oracle against drift and give the HIP path fixed expected outputs.  Weights are NOT stored: they
+are regenerated from the NumPy Philox seed (bit-stable), the fixture holds token ids, logits of
+every step, x after every layer of the last step, and the greedy continuation.
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+from oracle import oracle_np  # noqa: E402
+
+CASES = [  # (fixture, config, ggml type, seed, prompt tokens, greedy steps)
+    ("tiny_llama_q8_0", "tiny-llama", 8, 7, 6, 24),
+    ("tiny_llama_f16", "tiny-llama", 1, 7, 4, 8),
+    ("tiny_llama_tied_q4_0", "tiny-llama-tied", 2, 11, 4, 8),
+    ("tiny_qwen3_q8_0", "tiny-qwen3", 8, 5, 6, 24),
+]
+
+
+def run_case(pkg, cfg_name, wtype, seed, n_prompt, n_greedy):
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg_name], wtype=wtype, seed=seed)
+    o = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope)
+    prompt = pkg.javarand.bench_tokens(m.cfg.vocab, n_prompt)
+    logits, lx = [], []
+    tok_stream = list(prompt)
+    for pos in range(n_prompt + n_greedy - 1):
+        lx = []
+        lg = o.forward(tok_stream[pos], pos, layer_x=lx)
+        logits.append(lg)
+        if pos >= n_prompt - 1:
+            tok_stream.append(oracle_np.argmax(lg))
+    return dict(prompt=np.array(prompt, np.int32), tokens=np.array(tok_stream, np.int32),
+                logits=np.stack(logits).astype(np.float32), last_layer_x=np.stack(lx).astype(np.float32),
+                k_last=o.kc[:, n_prompt + n_greedy - 2].copy(), v_last=o.vc[:, n_prompt + n_greedy - 2].copy())
+
+
+if __name__ == "__main__":
+    pkg = ge.load_package()
+    for fx, cfg_name, wt, seed, npmt, ng in CASES:
+        out = run_case(pkg, cfg_name, wt, seed, npmt, ng)
+        np.savez_compressed(os.path.join(os.path.dirname(__file__), fx + ".npz"), **out)
+        print(fx, out["tokens"].tolist())

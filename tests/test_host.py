@@ -1,0 +1,61 @@
+"""Host-side logic that needs no GPU: java.util.Random stream, GGUF round trip, quantisers."""
+import numpy as np
+
+
+def test_java_random_stream(pkg):
+    jr = pkg.javarand
+    assert jr.JavaRandom(42).next_int() == -1170105035           # well-known new Random(42).nextInt()
+    # LlamaBench token stream (J/bench/LlamaBench.java:188-193), KATs from SURVEY.md §8d
+    assert jr.bench_tokens(128256, 8) == [16538, 38523, 90864, 87572, 14706, 105637, 41921, 91574]
+    assert jr.bench_tokens(151936, 8) == [73242, 98171, 117232, 88212, 73202, 59685, 40129, 133046]
+    assert jr.bench_tokens(512, 8) == [372, 27, 349, 24, 158, 482, 141, 362]   # power-of-two branch
+    assert all(0 <= t < 1000 for t in jr.bench_tokens(1000, 500))
+
+
+def test_quantizers_follow_ggml_reference(pkg):
+    s = pkg.synth
+    w = np.zeros(64, np.float32)
+    w[:4] = [1.27, -0.635, 0.005, 0.0149]
+    raw = s.quantize_q8_0(w)
+    assert raw.size == 68
+    d = raw[:2].copy().view(np.float16)[0]
+    assert d == np.float16(np.float32(1.27) / np.float32(127))
+    assert list(raw[2:6].view(np.int8)) == [127, -64, 1, 1]      # -63.5 -> -64 (half away), 0.5 -> 1, 1.49 -> 1
+    assert np.all(raw[34:] == 0)                                  # all-zero block: d = 0, q = 0
+    w = np.zeros(32, np.float32)
+    w[0], w[1], w[17] = -8.0, 7.0, 3.0
+    raw = s.quantize_q4_0(w)
+    assert raw[:2].copy().view(np.float16)[0] == 1.0              # d = max/-8 with max = -8
+    assert raw[2] & 0xF == 0 and raw[3] & 0xF == 15 and raw[3] >> 4 == 11 and raw[2] >> 4 == 8
+
+
+def test_gguf_round_trip(pkg, tmp_path):
+    s = pkg.synth
+    for name, wt in [("tiny-llama", s.GGML_Q8_0), ("tiny-qwen3", s.GGML_Q4_0), ("tiny-llama-tied", s.GGML_F16)]:
+        m = s.make_numpy(s.CONFIGS[name], wtype=wt, seed=3)
+        path = str(tmp_path / (name + ".gguf"))
+        m.write_gguf(path)
+        m2 = s.SynthModel.from_gguf(path)
+        c1, c2 = m.cfg, m2.cfg
+        for f in ("arch", "dim", "hidden", "n_layers", "n_heads", "n_kv_heads", "head_size", "vocab", "ctx", "tied"):
+            assert getattr(c1, f) == getattr(c2, f), f
+        assert abs(c1.rms_eps - c2.rms_eps) < 1e-12 and c1.rope_theta == c2.rope_theta
+        assert set(m.tensors) == set(m2.tensors)
+        for k, (raw, ty, rows, cols) in m.tensors.items():
+            raw2, ty2, rows2, cols2 = m2.tensors[k]
+            assert (ty, rows, cols) == (ty2, rows2, cols2) and np.array_equal(raw, raw2)
+        assert m2._gguf.tensor_data_offset % 32 == 0
+
+
+def test_torch_generator_matches_block_layout(pkg):
+    s = pkg.synth
+    cfg = s.CONFIGS["tiny-llama"]
+    for wt in (s.GGML_Q8_0, s.GGML_Q4_0, s.GGML_F16):
+        m = s.make_torch(cfg, wtype=wt, seed=1)
+        for k, (raw, ty, rows, cols) in m.tensors.items():
+            assert raw.dtype == np.uint8 and raw.size == pkg.gguf.byte_size(ty, rows * cols)
+    # the torch and NumPy quantisers implement the same rule
+    import torch
+    w = torch.randn(64, 64, generator=torch.Generator().manual_seed(0)) * 0.02
+    assert np.array_equal(s._t_quantize_q8_0(w).numpy(), s.quantize_q8_0(w.numpy()))
+    assert np.array_equal(s._t_quantize_q4_0(w).numpy(), s.quantize_q4_0(w.numpy()))

@@ -1,0 +1,69 @@
+"""The C oracle (timed CPU baseline) against the committed golden fixtures (made by the independent
+NumPy restatement) — bit for bit — plus structural properties of the reference path."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = [("tiny_llama_q8_0", "tiny-llama", 8, 7), ("tiny_llama_f16", "tiny-llama", 1, 7),
+         ("tiny_llama_tied_q4_0", "tiny-llama-tied", 2, 11), ("tiny_qwen3_q8_0", "tiny-qwen3", 8, 5)]
+
+
+@pytest.mark.parametrize("fx,cfg,wt,seed", CASES)
+def test_c_oracle_matches_golden_bitwise(pkg, orc, fx, cfg, wt, seed):
+    g = np.load(os.path.join(GOLD, fx + ".npz"))
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wt, seed=seed)
+    o = orc.COracle(m)
+    toks = g["tokens"]
+    n_prompt = len(g["prompt"])
+    assert toks[:n_prompt].tolist() == pkg.javarand.bench_tokens(m.cfg.vocab, n_prompt)
+    for pos in range(g["logits"].shape[0]):
+        lg, lx = o.forward(int(toks[pos]), pos, layer_x=True)
+        assert np.array_equal(lg.view(np.uint32), g["logits"][pos].view(np.uint32)), pos
+        if pos >= n_prompt - 1:
+            assert orc.argmax(lg) == toks[pos + 1]            # greedy ids
+    assert np.array_equal(lx, g["last_layer_x"])
+    for l in range(m.cfg.n_layers):
+        k, v = o.kv(l, g["logits"].shape[0] - 1)
+        assert np.array_equal(k, g["k_last"][l]) and np.array_equal(v, g["v_last"][l])
+
+
+def test_numpy_and_c_agree_on_fresh_seed(pkg, orc):
+    for cfg, wt in [("tiny-llama-tied", 8), ("tiny-qwen3", 1)]:
+        m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wt, seed=1234)
+        co = orc.COracle(m)
+        no = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope)
+        for pos, t in enumerate(pkg.javarand.bench_tokens(m.cfg.vocab, 4, seed=9)):
+            assert np.array_equal(co.forward(t, pos), no.forward(t, pos))
+
+
+def test_prefill_writes_the_same_kv_as_sequential_decode(pkg, orc):
+    # InferenceCoreBatchPrefillDecode.batchForwardJavaPrefill :62-168 == forwardJava minus logits
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], seed=7)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 9)
+    a, b = orc.COracle(m), orc.COracle(m)
+    for pos, t in enumerate(toks[:8]):
+        a.forward(t, pos)
+    b.prefill(toks[:5], 0)
+    b.prefill(toks[5:8], 5)
+    for l in range(m.cfg.n_layers):
+        for pos in range(8):
+            ka, va = a.kv(l, pos)
+            kb, vb = b.kv(l, pos)
+            assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    assert np.array_equal(a.forward(toks[8], 8), b.forward(toks[8], 8))
+
+
+def test_thread_count_independent(pkg, orc):
+    import subprocess, sys, json
+    code = ("import sys,json,numpy as np;sys.path.insert(0,%r);import __graft_entry__ as ge;p=ge.load_package();"
+            "from oracle import oracle_c as oc;m=p.synth.make_numpy(p.synth.CONFIGS['tiny-llama'],seed=7);o=oc.COracle(m);"
+            "o.forward(5,0);print(json.dumps(o.forward(9,1).view(np.uint32)[:64].tolist()))") % os.path.dirname(GOLD[:-6])
+    outs = []
+    for n in ("1", "3"):
+        env = dict(os.environ, OMP_NUM_THREADS=n)
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().splitlines()[-1])
+    assert outs[0] == outs[1]

