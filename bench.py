@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""llama-bench-style pp512 / tg128 for the HIP forward pass (LlamaBench protocol, J/bench/LlamaBench.java:172-273).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): random-weight
+Llama-3-8B-shaped Q8_0 model (dim 4096, hidden 14336, 32 layers, 32/8 heads, vocab 128256), token ids from
+java.util.Random(42) as LlamaBench does, context = 512 + 128 + 8.
+
+A *step* is one llama-bench repetition of tg128: 128 single-token decode steps at positions 0..127 over a
+growing KV cache, each returning the full logits to host memory (the reference's timed region includes the
+logits D2H, LlamaBench.java:234-254).  `value` = tokens / wall over exactly K steps (weights already in HBM).
+pp512 (batched prefill, -b 512, no logits) is timed the same way and reported beside it.
+
+N > 1 runs ONE model tensor-parallel over N GPUs (row/col split + one RCCL all-reduce per block), one process
+per GPU: total work is fixed, so "scaling": "strong".
+
+Extra objects: `roofline` — the dominant kernel (fused gate/up Q8_0 matvec) from an instrumented pass with HIP
+events around every launch; `cpu_baseline` — the C oracle (oracle/gl3_oracle.c, kind "port") on the host cores,
+bounded sample, rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X spec sheet (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured achievable)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)        # llama-bench -r 5
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="llama-3-8b")
+    ap.add_argument("--n-gen", type=int, default=128)
+    ap.add_argument("--n-prompt", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=512, help="prefill chunk (llama-bench -b)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pp", action="store_true")
+    ap.add_argument("--seed", type=int, default=42)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from importlib import import_module
+    plan_mod = import_module(ge.PKG_NAME + ".plan")
+    hip = import_module(ge.PKG_NAME + ".hip")
+    synth = pkg.synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    cfg = synth.CONFIGS[args.model]
+    cfg = synth.ModelConfig(**{**cfg.__dict__, "ctx": args.n_prompt + args.n_gen + 8})   # LlamaBench: max(depth+tokens)+8
+    t0 = time.time()
+    keep_host = (world == 1 and not args.no_cpu_baseline)
+    uid = None
+    if world > 1:
+        obj = [plan_mod.make_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0)
+        uid = obj[0]
+    if keep_host:
+        model = synth.make_torch(cfg, seed=args.seed, device=dev)
+    else:
+        model = synth.StreamModel(cfg, synth.GGML_Q8_0, synth.iter_torch(cfg, seed=args.seed, device=dev))
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(model, prefill_batch_size=args.batch, device=local_rank,
+                                                           tp_rank=rank, tp_size=world, unique_id=uid)
+    torch.cuda.empty_cache()
+    setup_s = time.time() - t0
+    toks = pkg.javarand.bench_tokens(cfg.vocab, args.n_prompt + args.n_gen)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def tg_rep():
+        for i in range(args.n_gen):
+            plan.forward_decode(toks[i], i, copy=False)
+
+    def pp_rep():
+        plan.prefill(toks[:args.n_prompt], 0)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        samples = []
+        barrier()
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            fn()
+            samples.append(time.perf_counter() - t1)
+        barrier()
+        total = time.perf_counter() - t_start
+        if dist is not None:
+            t = torch.tensor([total], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            total = float(t.item())
+        return total, samples
+
+    tg_total, tg_samples = timed(tg_rep, args.steps, args.warmup)
+    tg_tok_s = args.steps * args.n_gen / tg_total
+    pp = None
+    if not args.no_pp:
+        try:
+            pp_total, pp_samples = timed(pp_rep, args.steps, args.warmup)
+            pp = dict(tok_s=args.steps * args.n_prompt / pp_total, batch=args.batch,
+                      samples_tok_s=[args.n_prompt / s for s in pp_samples])
+        except hip.Gl3Error as e:
+            pp = dict(error=str(e))
+
+    # ---- roofline of the dominant kernel: instrumented (eager, HIP events per launch) decode steps mid-sequence
+    acc = None
+    n_prof = 8
+    for i in range(n_prof):
+        k = plan.profile_decode(toks[64 + i], 64 + i)
+        if acc is None:
+            acc = k
+        else:
+            for name in k:
+                for f in ("ms", "launches", "bytes"):
+                    acc[name][f] += k[name][f]
+    kern = {}
+    for name, v in acc.items():
+        if v["launches"]:
+            us = v["ms"] / v["launches"] * 1e3
+            kern[name] = dict(avg_us=round(us, 3), launches_per_token=v["launches"] // n_prof,
+                              bytes_per_launch=v["bytes"] // v["launches"],
+                              gbs=round(v["bytes"] / v["launches"] / (us * 1e-6) / 1e9, 1) if us > 0 else None)
+    dom = kern["matvec_gateup"]
+    roofline = dict(bound="hbm", kernel="matvec_q8_kernel<PRO_RMS,EPI_SWIGLU> (fused gate/up, Llama-3-8B: 2x14336x4096 Q8_0)",
+                    achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(dom["gbs"] / HBM_PEAK_GBS, 4),
+                    traffic=None, avg_us=dom["avg_us"], bytes_per_launch=dom["bytes_per_launch"])
+
+    # whole-token algorithmic bytes: weights + norms + KV read/write + logits
+    L, kvd = cfg.n_layers, cfg.kv_dim
+    mat_elems = L * (cfg.q_dim * cfg.dim + 2 * kvd * cfg.dim + cfg.dim * cfg.q_dim + 3 * cfg.hidden * cfg.dim) + cfg.vocab * cfg.dim
+    avg_pos = (args.n_gen - 1) / 2.0
+    token_bytes = mat_elems * 34 // 32 + (2 * L + 1) * cfg.dim * 4 + cfg.dim // 32 * 34 + 2 * L * kvd * 4 * (avg_pos + 1) \
+        + 2 * L * kvd * 4 + cfg.vocab * 4
+    token_gbs = token_bytes * tg_tok_s / 1e9
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle_c
+        o = oracle_c.COracle(model)
+        n_done, t1 = 0, time.perf_counter()
+        while True:
+            o.forward(toks[n_done], n_done)
+            n_done += 1
+            el = time.perf_counter() - t1
+            if el > args.cpu_seconds or n_done >= args.n_gen:
+                break
+        cpu = dict(value=round(n_done / el, 4), unit="tok/s", cores=oracle_c.lib().orc_num_threads(), kind="port",
+                   sample="tg%d at depth 0 (first %d decode steps of the same model/token stream, %.1f s)" % (n_done, n_done, el))
+        # parity spot check on the full-size model, printed to stderr (the asserts live in tests/)
+        ref = o.forward(toks[n_done], n_done)
+        plan.reset_kv()
+        for i in range(n_done):
+            plan.forward_decode(toks[i], i, copy=False)
+        got = plan.forward_decode(toks[n_done], n_done)
+        err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+        print("[bench] full-size parity vs CPU oracle at pos %d: rel err %.3e, argmax %d/%d" %
+              (n_done, err, int(np.argmax(got)), int(np.argmax(ref))), file=sys.stderr)
+        cpu["parity_rel_err_fullsize"] = err
+
+    if rank == 0:
+        mean = np.mean([args.n_gen / s for s in tg_samples])
+        sd = float(np.std([args.n_gen / s for s in tg_samples], ddof=1)) if len(tg_samples) > 1 else 0.0
+        out = {
+            "metric": "tg128 tok/s (llama-bench), Llama-3-8B Q8_0" if args.model == "llama-3-8b" else "tg%d tok/s, %s Q8_0" % (args.n_gen, args.model),
+            "value": round(tg_tok_s, 3), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(tg_total / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+            "config": {"workload": "%s Q8_0 random-weight GGUF-layout model, tg%d at depth 0 (one step = %d decode tokens, logits D2H "
+                                   "inside the timed region); pp%d -b %d reported beside it" %
+                                   (cfg.name, args.n_gen, args.n_gen, args.n_prompt, args.batch),
+                       "parallelism": "tp%d" % world if world > 1 else "single GPU", "ctx": cfg.ctx, "tokens": "java.util.Random(42)"},
+            "tg_tok_s_mean": round(float(mean), 3), "tg_tok_s_stddev": round(sd, 3),
+            "pp": pp,
+            "roofline": roofline,
+            "token_level": {"algorithmic_bytes_per_token": int(token_bytes), "achieved_gbs": round(token_gbs, 1),
+                            "frac_of_hbm_peak": round(token_gbs / HBM_PEAK_GBS / max(world, 1), 4),
+                            "roofline_tok_s": round(HBM_PEAK_GBS * 1e9 * world / token_bytes, 1)},
+            "kernels": kern,
+            "cpu_baseline": cpu,
+            "init": dict(plan.init_ms(), setup_s=round(setup_s, 2)),
+        }
+        print(json.dumps(out))
+    plan.freeTornadoExecutionPlan()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

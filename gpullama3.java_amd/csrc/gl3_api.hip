@@ -1,0 +1,569 @@
+// gl3_api.hip — C-ABI of libgpullama_hip.so (include/gpullama3_hip.h): plan lifetime, weight upload +
+// repack, the decode-step launch sequence (captured once into a hipGraph), parity taps and profiling.
+//
+// The launch sequence follows the task list of the reference's single-token plan
+// (J/tornadovm/layers/type/q8_0/LlamaQ8_0FFNLayers.java:111-230, LogitsQ8_0Layer.java:60-95) fused down to
+// six launches per layer:
+//   1 qkv matvec   = attn_rms_reduce + attn_rms_apply + qkv_projection        (RMSNorm + act-quant in prologue)
+//   2 attention    = rope_and_kv_cache + attention (split over the sequence)
+//   3 combine      = split-KV combine (as Qwen3's combineSplitKVAttention, ...Layered.java:1368)
+//   4 wo matvec    = attn_output_proj (+ residual)
+//   5 gate/up      = ffn_rms_reduce + rms_ffn_gate_up (SwiGLU epilogue)
+//   6 down matvec  = ffn_down_proj (+ residual)
+// and per token: embedding gather/dequant, final RMSNorm fused into the vocab projection, optional argmax.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "gl3_ctx.h"
+#include "gl3_decode_kernels.h"
+
+using namespace gl3;
+
+static std::string g_create_err;
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static bool env_flag(const char* name, bool dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v) != 0;
+}
+
+// ------------------------------------------------------------------------------------------------ matvec launch
+struct MatvecPlan { int wgs, rows_per_wave, g; };
+
+// Balanced static partition: prefer a workgroup count that is a multiple of the 256 CUs and divides the rows
+// evenly (per-CU HBM throughput is capped near 10 B/clk, so every CU must get the same share).
+static MatvecPlan plan_matvec(int rows, int max_g) {
+    MatvecPlan p{};
+    const int cands[] = {1024, 768, 512, 256};
+    for (int wgs : cands) {
+        if (rows % (wgs * WAVES) == 0) { p.wgs = wgs; p.rows_per_wave = rows / (wgs * WAVES); break; }
+    }
+    if (!p.wgs) {
+        p.rows_per_wave = (rows + 1024 * WAVES - 1) / (1024 * WAVES);
+        p.wgs = (rows + p.rows_per_wave * WAVES - 1) / (p.rows_per_wave * WAVES);
+    }
+    static const int force_g = getenv("GL3_G") ? atoi(getenv("GL3_G")) : 0;
+    p.g = 1;
+    for (int g = max_g; g >= 1; g >>= 1)
+        if (p.rows_per_wave % g == 0 || p.rows_per_wave > 2 * g) { p.g = g; break; }
+    if (force_g) p.g = force_g > max_g ? max_g : force_g;
+    return p;
+}
+
+template <int PRO, int EPI>
+static void launch_matvec_t(const MatvecArgs& a, const MatvecPlan& p, size_t smem, hipStream_t s, bool nt) {
+#define GL3_MV(G, NT) hipLaunchKernelGGL((matvec_q8_kernel<PRO, EPI, G, NT>), dim3(p.wgs), dim3(WG), smem, s, a)
+    if (nt) {
+        if (p.g >= 4 && EPI != EPI_SWIGLU) GL3_MV(4, true);
+        else if (p.g >= 2) GL3_MV(2, true);
+        else GL3_MV(1, true);
+    } else {
+        if (p.g >= 4 && EPI != EPI_SWIGLU) GL3_MV(4, false);
+        else if (p.g >= 2) GL3_MV(2, false);
+        else GL3_MV(1, false);
+    }
+#undef GL3_MV
+}
+
+static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const Q8Mat* w2, const float* x,
+                          const float* norm_w, float* out, const float* resid_in) {
+    static const bool nt = env_flag("GL3_NT", true);
+    MatvecArgs a{};
+    a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.k = w.k; a.nbp = w.nbp;
+    a.x = x; a.norm_w = norm_w; a.eps = ctx->d.rms_eps; a.out = out; a.resid_in = resid_in;
+    const MatvecPlan p = plan_matvec(w.rows, epi == EPI_SWIGLU ? 2 : 4);
+    a.rows_per_wave = p.rows_per_wave;
+    const int nct = (w.nbp + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
+    const size_t smem = (size_t)nct * 2048 + (size_t)nct * CHUNK_BLOCKS * 4 + 64;
+    if (pro == PRO_RMS && epi == EPI_STORE) launch_matvec_t<PRO_RMS, EPI_STORE>(a, p, smem, ctx->stream, nt);
+    else if (pro == PRO_QUANT && epi == EPI_RESID) launch_matvec_t<PRO_QUANT, EPI_RESID>(a, p, smem, ctx->stream, nt);
+    else if (pro == PRO_RMS && epi == EPI_SWIGLU) launch_matvec_t<PRO_RMS, EPI_SWIGLU>(a, p, smem, ctx->stream, nt);
+    else launch_matvec_t<PRO_QUANT, EPI_STORE>(a, p, smem, ctx->stream, nt);
+}
+
+// ------------------------------------------------------------------------------------------------ decode step
+struct Prof {
+    gl3_ctx* ctx; gl3_kernel_times* kt; size_t n = 0; std::vector<int> klass;
+    void begin(int k, uint64_t bytes) {
+        if (!kt) return;
+        if (ctx->ev.size() < 2 * (n + 1)) {
+            ctx->ev.resize(2 * (n + 1));
+            hipEventCreate(&ctx->ev[2 * n]); hipEventCreate(&ctx->ev[2 * n + 1]);
+        }
+        hipEventRecord(ctx->ev[2 * n], ctx->stream);
+        klass.push_back(k); kt->launches[k]++; kt->bytes[k] += bytes;
+    }
+    void end() { if (kt) { hipEventRecord(ctx->ev[2 * n + 1], ctx->stream); ++n; } }
+    void collect() {
+        if (!kt) return;
+        hipStreamSynchronize(ctx->stream);
+        for (size_t i = 0; i < n; ++i) {
+            float ms = 0; hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]);
+            kt->ms[klass[i]] += ms;
+        }
+    }
+};
+
+static uint64_t mv_bytes(const Q8Mat& w) { return w.algo_bytes() + (uint64_t)w.k * 4 + (uint64_t)w.rows * 4; }
+
+static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* kt) {
+    const gl3_model_desc& d = ctx->d;
+    hipStream_t s = ctx->stream;
+    Prof pr{ctx, kt};
+    const bool tp = ctx->use_rccl;
+    const size_t kv_layer = (size_t)d.ctx * ctx->kv_dim_l;
+
+    pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
+    hipLaunchKernelGGL(embed_q8_kernel, dim3(1), dim3(WG), 0, s, ctx->emb.w, ctx->emb.nbp, d.dim, ctx->dyn, ctx->x);
+    pr.end();
+
+    for (int l = 0; l < d.n_layers; ++l) {
+        gl3_layer& L = ctx->layers[l];
+        pr.begin(GL3_K_MATVEC_QKV, mv_bytes(L.wqkv) + d.dim * 4);
+        launch_matvec(ctx, PRO_RMS, EPI_STORE, L.wqkv, nullptr, ctx->x, L.attn_norm, ctx->qkv, nullptr);
+        pr.end();
+
+        AttnArgs aa{};
+        aa.qkv = ctx->qkv; aa.kcache = ctx->kcache + l * kv_layer; aa.vcache = ctx->vcache + l * kv_layer;
+        aa.rope_cr = ctx->rope_cr; aa.rope_ci = ctx->rope_ci; aa.qnorm = L.qnorm; aa.knorm = L.knorm;
+        aa.dyn = ctx->dyn; aa.part = ctx->part; aa.n_heads = ctx->heads_l; aa.n_kv_heads = ctx->kv_heads_l;
+        aa.hs = d.head_size; aa.q_dim = ctx->q_dim_l; aa.kv_dim = ctx->kv_dim_l; aa.n_split = ctx->n_split;
+        aa.eps = d.rms_eps; aa.arch = d.arch;
+        pr.begin(GL3_K_ATTENTION, 0);
+        hipLaunchKernelGGL(attn_partial_kernel, dim3(ctx->heads_l * ctx->n_split), dim3(WG), 0, s, aa);
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(ctx->heads_l), dim3(WG), 0, s, ctx->part, ctx->xb, d.head_size,
+                           ctx->n_split);
+        pr.end();
+
+        // x += Wo . xb ; under tensor parallelism rank 0 carries the residual and the partials are all-reduced
+        pr.begin(GL3_K_MATVEC_WO, mv_bytes(L.wo));
+        launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, tp ? ctx->y : ctx->x,
+                      (!tp || d.tp_rank == 0) ? ctx->x : nullptr);
+        pr.end();
+        if (tp) {
+            pr.begin(GL3_K_COLLECTIVE, 0);
+            GL3_NCCL(ncclAllReduce(ctx->y, ctx->x, d.dim, ncclFloat, ncclSum, ctx->comm, s));
+            pr.end();
+        }
+
+        pr.begin(GL3_K_MATVEC_GATEUP, mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4);
+        launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb, nullptr);
+        pr.end();
+
+        pr.begin(GL3_K_MATVEC_DOWN, mv_bytes(L.w2));
+        launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, tp ? ctx->y : ctx->x,
+                      (!tp || d.tp_rank == 0) ? ctx->x : nullptr);
+        pr.end();
+        if (tp) {
+            pr.begin(GL3_K_COLLECTIVE, 0);
+            GL3_NCCL(ncclAllReduce(ctx->y, ctx->x, d.dim, ncclFloat, ncclSum, ctx->comm, s));
+            pr.end();
+        }
+        if (ctx->taps) hipMemcpyAsync(ctx->taps + (size_t)l * d.dim, ctx->x, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, s);
+    }
+    if (want_logits) {
+        pr.begin(GL3_K_MATVEC_LOGITS, mv_bytes(ctx->wcls) + d.dim * 4);
+        launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm,
+                      ctx->logits + (size_t)d.tp_rank * ctx->vocab_l, nullptr);
+        pr.end();
+        if (tp && d.tp_size > 1) {
+            pr.begin(GL3_K_COLLECTIVE, 0);
+            GL3_NCCL(ncclAllGather(ctx->logits + (size_t)d.tp_rank * ctx->vocab_l, ctx->logits, ctx->vocab_l, ncclFloat,
+                                   ctx->comm, s));
+            pr.end();
+        }
+    }
+    GL3_HIP(hipGetLastError());
+    pr.collect();
+    return GL3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ create / destroy
+template <typename T>
+static int32_t dmalloc(gl3_ctx* ctx, T** p, size_t n) {
+    GL3_HIP(hipMalloc((void**)p, n * sizeof(T)));
+    return GL3_OK;
+}
+
+static int32_t alloc_mat(gl3_ctx* ctx, Q8Mat& m, int rows, int k) {
+    m.rows = rows; m.k = k; m.nbp = ((k / 32) + 7) / 8 * 8;
+    GL3_HIP(hipMalloc((void**)&m.w, m.bytes()));
+    return GL3_OK;
+}
+
+extern "C" {
+
+const char* gl3_version(void) { return "gpullama3-hip 0.1 (gfx950)"; }
+
+const char* gl3_last_error(gl3_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
+    if (!desc || !out) { g_create_err = "null argument"; return GL3_E_ARG; }
+    if (desc->struct_size != sizeof(gl3_model_desc)) { g_create_err = "gl3_model_desc.struct_size mismatch"; return GL3_E_ARG; }
+    gl3_ctx* ctx = new gl3_ctx();
+    ctx->d = *desc;
+    const gl3_model_desc& d = ctx->d;
+    auto bail = [&](int32_t code, const std::string& msg) { g_create_err = msg.empty() ? ctx->err : msg; gl3_destroy(ctx); return code; };
+    const double t0 = now_ms();
+    if (d.arch != GL3_ARCH_LLAMA && d.arch != GL3_ARCH_QWEN3) return bail(GL3_E_UNSUPPORTED, "unsupported architecture");
+    if (d.weight_type != GL3_TYPE_Q8_0) return bail(GL3_E_UNSUPPORTED, "only Q8_0 weights are implemented in this build");
+    if (d.dim <= 0 || d.dim % 32 || d.hidden % 32 || d.n_layers <= 0 || d.n_heads <= 0 || d.n_kv_heads <= 0 ||
+        d.n_heads % d.n_kv_heads || d.vocab <= 0 || d.ctx <= 0)
+        return bail(GL3_E_ARG, "bad model dimensions");
+    if (d.head_size != 32 && d.head_size != 64 && d.head_size != 128 && d.head_size != 256)
+        return bail(GL3_E_UNSUPPORTED, "head_size must be 32/64/128/256");
+    const int tp = d.tp_size < 1 ? 1 : d.tp_size;
+    ctx->d.tp_size = tp;
+    if (d.tp_rank < 0 || d.tp_rank >= tp) return bail(GL3_E_ARG, "tp_rank out of range");
+    if (d.n_heads % tp || d.n_kv_heads % tp || d.hidden % (32 * tp) || d.vocab % tp)
+        return bail(GL3_E_UNSUPPORTED, "tp_size must divide n_heads, n_kv_heads, hidden/32 and vocab");
+    ctx->q_dim = d.n_heads * d.head_size; ctx->kv_dim = d.n_kv_heads * d.head_size;
+    ctx->heads_l = d.n_heads / tp; ctx->kv_heads_l = d.n_kv_heads / tp;
+    ctx->q_dim_l = ctx->heads_l * d.head_size; ctx->kv_dim_l = ctx->kv_heads_l * d.head_size;
+    ctx->hidden_l = d.hidden / tp; ctx->vocab_l = d.vocab / tp;
+    ctx->n_split = 8;
+    while ((d.ctx + ctx->n_split - 1) / ctx->n_split > ATT_MAX_T) ctx->n_split *= 2;
+    ctx->use_rccl = tp > 1 || (d.flags & GL3_FLAG_FORCE_RCCL);
+
+#define TRY(x) do { int32_t r_ = (x); if (r_ != GL3_OK) return bail(r_, ""); } while (0)
+#define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bail(e_ == hipErrorOutOfMemory ? GL3_E_OOM : GL3_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+    TRYHIP(hipSetDevice(d.device));
+    TRYHIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    TRY(alloc_mat(ctx, ctx->emb, d.vocab, d.dim));
+    ctx->layers.resize(d.n_layers);
+    for (auto& L : ctx->layers) {
+        TRY(alloc_mat(ctx, L.wqkv, ctx->q_dim_l + 2 * ctx->kv_dim_l, d.dim));
+        TRY(alloc_mat(ctx, L.wo, d.dim, ctx->q_dim_l));
+        TRY(alloc_mat(ctx, L.w1, ctx->hidden_l, d.dim));
+        TRY(alloc_mat(ctx, L.w3, ctx->hidden_l, d.dim));
+        TRY(alloc_mat(ctx, L.w2, d.dim, ctx->hidden_l));
+        TRY(dmalloc(ctx, &L.attn_norm, d.dim));
+        TRY(dmalloc(ctx, &L.ffn_norm, d.dim));
+        if (d.arch == GL3_ARCH_QWEN3) { TRY(dmalloc(ctx, &L.qnorm, d.head_size)); TRY(dmalloc(ctx, &L.knorm, d.head_size)); }
+    }
+    TRY(dmalloc(ctx, &ctx->out_norm, d.dim));
+    const size_t kvn = (size_t)d.n_layers * d.ctx * ctx->kv_dim_l;
+    TRY(dmalloc(ctx, &ctx->kcache, kvn));
+    TRY(dmalloc(ctx, &ctx->vcache, kvn));
+    TRYHIP(hipMemset(ctx->kcache, 0, kvn * 4));
+    TRYHIP(hipMemset(ctx->vcache, 0, kvn * 4));
+    TRY(dmalloc(ctx, &ctx->x, d.dim));
+    TRY(dmalloc(ctx, &ctx->y, d.dim));
+    TRY(dmalloc(ctx, &ctx->qkv, ctx->q_dim_l + 2 * ctx->kv_dim_l));
+    TRY(dmalloc(ctx, &ctx->xb, ctx->q_dim_l));
+    TRY(dmalloc(ctx, &ctx->hb, ctx->hidden_l));
+    TRY(dmalloc(ctx, &ctx->logits, d.vocab));
+    TRY(dmalloc(ctx, &ctx->part, (size_t)ctx->heads_l * ctx->n_split * (d.head_size + 2)));
+    TRY(dmalloc(ctx, &ctx->dyn, 4));
+    TRY(dmalloc(ctx, &ctx->argmax, 1));
+    if (d.flags & GL3_FLAG_LAYER_TAPS) TRY(dmalloc(ctx, &ctx->taps, (size_t)d.n_layers * d.dim));
+    TRYHIP(hipHostMalloc((void**)&ctx->h_dyn, 4 * sizeof(int)));
+    TRYHIP(hipHostMalloc((void**)&ctx->h_logits, (size_t)d.vocab * 4));
+    TRYHIP(hipHostMalloc((void**)&ctx->h_argmax, sizeof(int)));
+    if (d.max_batch > 1) TRY(gl3_prefill_alloc(ctx));
+    TRYHIP(hipDeviceSynchronize());
+#undef TRY
+#undef TRYHIP
+    ctx->plan_ms = now_ms() - t0;
+    *out = ctx;
+    return GL3_OK;
+}
+
+void gl3_destroy(gl3_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->d.device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx->graph) hipGraphDestroy(ctx->graph);
+    if (ctx->comm) ncclCommDestroy(ctx->comm);
+    gl3_prefill_free(ctx);
+    for (auto e : ctx->ev) hipEventDestroy(e);
+    auto f = [](void* p) { if (p) hipFree(p); };
+    f(ctx->emb.w);
+    if (ctx->wcls_owned) f(ctx->wcls.w);
+    for (auto& L : ctx->layers) {
+        f(L.wqkv.w); f(L.wo.w); f(L.w1.w); f(L.w3.w); f(L.w2.w);
+        f(L.attn_norm); f(L.ffn_norm); f(L.qnorm); f(L.knorm);
+    }
+    f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->x); f(ctx->y); f(ctx->qkv);
+    f(ctx->xb); f(ctx->hb); f(ctx->logits); f(ctx->part); f(ctx->dyn); f(ctx->argmax); f(ctx->taps); f(ctx->staging);
+    if (ctx->h_dyn) hipHostFree(ctx->h_dyn);
+    if (ctx->h_logits) hipHostFree(ctx->h_logits);
+    if (ctx->h_argmax) hipHostFree(ctx->h_argmax);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+// ------------------------------------------------------------------------------------------------ upload
+static int32_t stage(gl3_ctx* ctx, const void* host, size_t bytes) {
+    if (ctx->staging_bytes < bytes) {
+        if (ctx->staging) hipFree(ctx->staging);
+        ctx->staging = nullptr; ctx->staging_bytes = 0;
+        GL3_HIP(hipMalloc((void**)&ctx->staging, bytes));
+        ctx->staging_bytes = bytes;
+    }
+    GL3_HIP(hipMemcpy(ctx->staging, host, bytes, hipMemcpyHostToDevice));
+    return GL3_OK;
+}
+
+// src: full [rows_full x k_full] GGUF Q8_0 tensor on the host; keeps rows [r0, r0+m.rows) (placed at dst_row0 of m)
+// and 32-blocks [b0, b0 + m.k/32).
+static int32_t upload_q8(gl3_ctx* ctx, Q8Mat& m, int dst_row0, int sub_rows, const void* host, uint64_t bytes, int rows_full,
+                         int k_full, long r0, int b0) {
+    const int nb_full = k_full / 32, nb = m.k / 32;
+    if (bytes != (uint64_t)rows_full * nb_full * 34) GL3_FAIL(GL3_E_ARG, "tensor byte size does not match its shape");
+    const uint8_t* h = (const uint8_t*)host;
+    long src_r0 = r0;
+    if (nb == nb_full) {   // row slice: upload only the rows this rank keeps
+        h += (size_t)r0 * nb_full * 34;
+        int32_t r = stage(ctx, h, (size_t)sub_rows * nb_full * 34);
+        if (r != GL3_OK) return r;
+        src_r0 = 0;
+    } else {
+        int32_t r = stage(ctx, h, bytes);
+        if (r != GL3_OK) return r;
+    }
+    const long total = (long)sub_rows * m.nbp;
+    hipLaunchKernelGGL(repack_q8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->staging,
+                       m.w + (size_t)dst_row0 * m.nbp * 34, sub_rows, nb, m.nbp, src_r0, b0, nb_full);
+    GL3_HIP(hipStreamSynchronize(ctx->stream));
+    return GL3_OK;
+}
+
+static int32_t upload_f32(gl3_ctx* ctx, float* dst, int n, const void* host, uint64_t bytes, int type) {
+    if (type != GL3_TYPE_F32) GL3_FAIL(GL3_E_UNSUPPORTED, "norm weights must be F32");
+    if (!dst) GL3_FAIL(GL3_E_ARG, "tensor not part of this architecture");
+    if (bytes != (uint64_t)n * 4) GL3_FAIL(GL3_E_ARG, "norm tensor byte size mismatch");
+    GL3_HIP(hipMemcpy(dst, host, bytes, hipMemcpyHostToDevice));
+    return GL3_OK;
+}
+
+int32_t gl3_upload_tensor(gl3_ctx* ctx, int32_t id, int32_t layer, const void* host, uint64_t bytes, int32_t type) {
+    if (!ctx) return GL3_E_ARG;
+    if (!host || id < 0 || id >= GL3_T_COUNT) GL3_FAIL(GL3_E_ARG, "bad tensor id / null host pointer");
+    if (ctx->finalized) GL3_FAIL(GL3_E_STATE, "upload after finalize");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    const gl3_model_desc& d = ctx->d;
+    const double t0 = now_ms();
+    int32_t r = GL3_OK;
+    const int rank = d.tp_rank;
+    const bool is_mat = !(id == GL3_T_OUTPUT_NORM || id == GL3_T_ATTN_NORM || id == GL3_T_FFN_NORM || id == GL3_T_ATTN_Q_NORM ||
+                          id == GL3_T_ATTN_K_NORM);
+    if (is_mat && type != d.weight_type) GL3_FAIL(GL3_E_UNSUPPORTED, "matrix ggml type differs from gl3_model_desc.weight_type");
+    if (id > GL3_T_OUTPUT && (layer < 0 || layer >= d.n_layers)) GL3_FAIL(GL3_E_ARG, "layer out of range");
+    gl3_layer* L = id > GL3_T_OUTPUT ? &ctx->layers[layer] : nullptr;
+    switch (id) {
+    case GL3_T_TOKEN_EMBD: r = upload_q8(ctx, ctx->emb, 0, d.vocab, host, bytes, d.vocab, d.dim, 0, 0); break;
+    case GL3_T_OUTPUT:
+        if (!ctx->wcls_owned) { r = alloc_mat(ctx, ctx->wcls, ctx->vocab_l, d.dim); ctx->wcls_owned = (r == GL3_OK); }
+        if (r == GL3_OK) r = upload_q8(ctx, ctx->wcls, 0, ctx->vocab_l, host, bytes, d.vocab, d.dim, (long)rank * ctx->vocab_l, 0);
+        break;
+    case GL3_T_OUTPUT_NORM: r = upload_f32(ctx, ctx->out_norm, d.dim, host, bytes, type); break;
+    case GL3_T_ATTN_NORM: r = upload_f32(ctx, L->attn_norm, d.dim, host, bytes, type); break;
+    case GL3_T_FFN_NORM: r = upload_f32(ctx, L->ffn_norm, d.dim, host, bytes, type); break;
+    case GL3_T_ATTN_Q_NORM: r = upload_f32(ctx, L->qnorm, d.head_size, host, bytes, type); break;
+    case GL3_T_ATTN_K_NORM: r = upload_f32(ctx, L->knorm, d.head_size, host, bytes, type); break;
+    case GL3_T_WQ: r = upload_q8(ctx, L->wqkv, 0, ctx->q_dim_l, host, bytes, ctx->q_dim, d.dim, (long)rank * ctx->q_dim_l, 0); break;
+    case GL3_T_WK: r = upload_q8(ctx, L->wqkv, ctx->q_dim_l, ctx->kv_dim_l, host, bytes, ctx->kv_dim, d.dim, (long)rank * ctx->kv_dim_l, 0); break;
+    case GL3_T_WV: r = upload_q8(ctx, L->wqkv, ctx->q_dim_l + ctx->kv_dim_l, ctx->kv_dim_l, host, bytes, ctx->kv_dim, d.dim, (long)rank * ctx->kv_dim_l, 0); break;
+    case GL3_T_WO: r = upload_q8(ctx, L->wo, 0, d.dim, host, bytes, d.dim, ctx->q_dim, 0, rank * (ctx->q_dim_l / 32)); break;
+    case GL3_T_W1: r = upload_q8(ctx, L->w1, 0, ctx->hidden_l, host, bytes, d.hidden, d.dim, (long)rank * ctx->hidden_l, 0); break;
+    case GL3_T_W3: r = upload_q8(ctx, L->w3, 0, ctx->hidden_l, host, bytes, d.hidden, d.dim, (long)rank * ctx->hidden_l, 0); break;
+    case GL3_T_W2: r = upload_q8(ctx, L->w2, 0, d.dim, host, bytes, d.dim, d.hidden, 0, rank * (ctx->hidden_l / 32)); break;
+    default: GL3_FAIL(GL3_E_ARG, "unknown tensor id");
+    }
+    if (r != GL3_OK) return r;
+    if (L) L->have |= 1u << id; else ctx->have_global |= 1u << id;
+    ctx->copy_in_ms += now_ms() - t0;
+    return GL3_OK;
+}
+
+int32_t gl3_upload_rope(gl3_ctx* ctx, const float* cr, const float* ci, uint64_t n) {
+    if (!ctx) return GL3_E_ARG;
+    if (!cr || !ci) GL3_FAIL(GL3_E_ARG, "null rope table");
+    const uint64_t need = (uint64_t)ctx->d.ctx * (ctx->d.head_size / 2);
+    if (n < need) GL3_FAIL(GL3_E_ARG, "rope table shorter than ctx * head_size/2");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    if (ctx->rope_cr) { hipFree(ctx->rope_cr); hipFree(ctx->rope_ci); ctx->rope_cr = ctx->rope_ci = nullptr; }
+    GL3_HIP(hipMalloc((void**)&ctx->rope_cr, need * 4));
+    GL3_HIP(hipMalloc((void**)&ctx->rope_ci, need * 4));
+    GL3_HIP(hipMemcpy(ctx->rope_cr, cr, need * 4, hipMemcpyHostToDevice));
+    GL3_HIP(hipMemcpy(ctx->rope_ci, ci, need * 4, hipMemcpyHostToDevice));
+    ctx->rope_n = need;
+    return GL3_OK;
+}
+
+int32_t gl3_tp_unique_id(void* out, uint64_t bytes) {
+    if (!out || bytes < sizeof(ncclUniqueId)) return GL3_E_ARG;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return GL3_E_RCCL;
+    memset(out, 0, bytes);
+    memcpy(out, &id, sizeof(id));
+    return GL3_OK;
+}
+
+int32_t gl3_tp_init(gl3_ctx* ctx, const void* unique_id, uint64_t bytes) {
+    if (!ctx) return GL3_E_ARG;
+    if (!unique_id || bytes < sizeof(ncclUniqueId)) GL3_FAIL(GL3_E_ARG, "bad RCCL unique id");
+    if (ctx->finalized) GL3_FAIL(GL3_E_STATE, "tp_init after finalize");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    GL3_NCCL(ncclCommInitRank(&ctx->comm, ctx->d.tp_size, id, ctx->d.tp_rank));
+    return GL3_OK;
+}
+
+static int32_t capture(gl3_ctx* ctx, bool want_logits, hipGraph_t* g, hipGraphExec_t* ge) {
+    GL3_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int32_t r = enqueue_decode(ctx, want_logits, nullptr);
+    hipError_t e = hipStreamEndCapture(ctx->stream, g);
+    if (r != GL3_OK) return r;
+    GL3_HIP(e);
+    GL3_HIP(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+    return GL3_OK;
+}
+
+int32_t gl3_finalize(gl3_ctx* ctx) {
+    if (!ctx) return GL3_E_ARG;
+    if (ctx->finalized) return GL3_OK;
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    const gl3_model_desc& d = ctx->d;
+    const uint32_t need_g = (1u << GL3_T_TOKEN_EMBD) | (1u << GL3_T_OUTPUT_NORM);
+    if ((ctx->have_global & need_g) != need_g) GL3_FAIL(GL3_E_STATE, "token_embd / output_norm not uploaded");
+    uint32_t need_l = (1u << GL3_T_ATTN_NORM) | (1u << GL3_T_WQ) | (1u << GL3_T_WK) | (1u << GL3_T_WV) | (1u << GL3_T_WO) |
+                      (1u << GL3_T_FFN_NORM) | (1u << GL3_T_W1) | (1u << GL3_T_W2) | (1u << GL3_T_W3);
+    if (d.arch == GL3_ARCH_QWEN3) need_l |= (1u << GL3_T_ATTN_Q_NORM) | (1u << GL3_T_ATTN_K_NORM);
+    for (int l = 0; l < d.n_layers; ++l)
+        if ((ctx->layers[l].have & need_l) != need_l) GL3_FAIL(GL3_E_STATE, "layer " + std::to_string(l) + ": tensors missing");
+    if (!ctx->rope_cr) GL3_FAIL(GL3_E_STATE, "rope tables not uploaded");
+    if (ctx->use_rccl && !ctx->comm) GL3_FAIL(GL3_E_STATE, "tensor parallel plan without gl3_tp_init");
+    if (!(ctx->have_global & (1u << GL3_T_OUTPUT))) {   // tied: wcls = this rank's vocab rows of token_embd
+        ctx->wcls = ctx->emb;
+        ctx->wcls.rows = ctx->vocab_l;
+        ctx->wcls.w = ctx->emb.w + (size_t)d.tp_rank * ctx->vocab_l * ctx->emb.nbp * 34;
+        ctx->wcls_owned = false;
+    }
+    if (ctx->staging) { hipFree(ctx->staging); ctx->staging = nullptr; ctx->staging_bytes = 0; }
+    ctx->finalized = true;
+    if (!(d.flags & GL3_FLAG_NO_GRAPH) && !env_flag("GL3_NO_GRAPH", false)) {
+        const double t0 = now_ms();
+        int32_t r = capture(ctx, true, &ctx->graph, &ctx->graph_exec);
+        if (r != GL3_OK) {   // e.g. a collective that cannot be captured: run eagerly instead
+            ctx->graph_exec = nullptr;
+            (void)hipGetLastError();
+            fprintf(stderr, "[gl3] hipGraph capture failed (%s); falling back to eager launches\n", ctx->err.c_str());
+        }
+        ctx->plan_ms += now_ms() - t0;
+    }
+    GL3_HIP(hipStreamSynchronize(ctx->stream));
+    return GL3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+static int32_t set_dyn(gl3_ctx* ctx, int32_t token, int32_t pos) {
+    if (!ctx->finalized) GL3_FAIL(GL3_E_STATE, "forward before gl3_finalize");
+    if (token < 0 || token >= ctx->d.vocab) GL3_FAIL(GL3_E_ARG, "token id out of range");
+    if (pos < 0 || pos >= ctx->d.ctx) GL3_FAIL(GL3_E_ARG, "position outside the KV cache (context length)");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    ctx->h_dyn[0] = token; ctx->h_dyn[1] = pos;
+    GL3_HIP(hipMemcpyAsync(ctx->dyn, ctx->h_dyn, 2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    return GL3_OK;
+}
+
+int32_t gl3_forward_decode(gl3_ctx* ctx, int32_t token, int32_t pos, float* logits_out, int32_t* argmax_out) {
+    if (!ctx) return GL3_E_ARG;
+    int32_t r = set_dyn(ctx, token, pos);
+    if (r != GL3_OK) return r;
+    const bool want_logits = logits_out || argmax_out;
+    if (ctx->graph_exec && want_logits) GL3_HIP(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+    else if ((r = enqueue_decode(ctx, want_logits, nullptr)) != GL3_OK) return r;
+    if (argmax_out) {
+        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->logits, ctx->d.vocab, ctx->argmax);
+        GL3_HIP(hipMemcpyAsync(ctx->h_argmax, ctx->argmax, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (logits_out) GL3_HIP(hipMemcpyAsync(ctx->h_logits, ctx->logits, (size_t)ctx->d.vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GL3_HIP(hipStreamSynchronize(ctx->stream));
+    if (logits_out) memcpy(logits_out, ctx->h_logits, (size_t)ctx->d.vocab * 4);
+    if (argmax_out) *argmax_out = *ctx->h_argmax;
+    return GL3_OK;
+}
+
+int32_t gl3_forward_prefill(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t start_pos) {
+    if (!ctx) return GL3_E_ARG;
+    if (!tokens || n < 0) GL3_FAIL(GL3_E_ARG, "bad token array");
+    if (!ctx->finalized) GL3_FAIL(GL3_E_STATE, "forward before gl3_finalize");
+    if (start_pos < 0 || start_pos + n > ctx->d.ctx) GL3_FAIL(GL3_E_ARG, "prefill range outside the KV cache");
+    if (n == 0) return GL3_OK;
+    if (ctx->pf) {
+        if (n > ctx->d.max_batch) GL3_FAIL(GL3_E_ARG, "prefill chunk larger than max_batch");
+        return gl3_prefill_run(ctx, tokens, n, start_pos);
+    }
+    // max_batch <= 1: sequential single-token prefill without logits
+    // (TornadoVMMasterPlanPrefillDecode.tornadoVMForwardPrefill, J/tornadovm/TornadoVMMasterPlanPrefillDecode.java:116)
+    for (int i = 0; i < n; ++i) {
+        int32_t r = set_dyn(ctx, tokens[i], start_pos + i);
+        if (r != GL3_OK) return r;
+        if ((r = enqueue_decode(ctx, false, nullptr)) != GL3_OK) return r;
+        GL3_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return GL3_OK;
+}
+
+int32_t gl3_profile_decode(gl3_ctx* ctx, int32_t token, int32_t pos, gl3_kernel_times* out) {
+    if (!ctx || !out) return GL3_E_ARG;
+    memset(out, 0, sizeof(*out));
+    int32_t r = set_dyn(ctx, token, pos);
+    if (r != GL3_OK) return r;
+    return enqueue_decode(ctx, true, out);
+}
+
+int32_t gl3_get_x(gl3_ctx* ctx, float* out) {
+    if (!ctx || !out) return GL3_E_ARG;
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    GL3_HIP(hipMemcpy(out, ctx->x, sizeof(float) * ctx->d.dim, hipMemcpyDeviceToHost));
+    return GL3_OK;
+}
+
+int32_t gl3_get_layer_x(gl3_ctx* ctx, int32_t layer, float* out) {
+    if (!ctx || !out) return GL3_E_ARG;
+    if (!ctx->taps) GL3_FAIL(GL3_E_STATE, "plan was created without GL3_FLAG_LAYER_TAPS");
+    if (layer < 0 || layer >= ctx->d.n_layers) GL3_FAIL(GL3_E_ARG, "layer out of range");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    GL3_HIP(hipMemcpy(out, ctx->taps + (size_t)layer * ctx->d.dim, sizeof(float) * ctx->d.dim, hipMemcpyDeviceToHost));
+    return GL3_OK;
+}
+
+int32_t gl3_get_kv(gl3_ctx* ctx, int32_t layer, int32_t pos, float* k_out, float* v_out) {
+    if (!ctx || !k_out || !v_out) return GL3_E_ARG;
+    if (layer < 0 || layer >= ctx->d.n_layers || pos < 0 || pos >= ctx->d.ctx) GL3_FAIL(GL3_E_ARG, "layer/position out of range");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    const size_t off = ((size_t)layer * ctx->d.ctx + pos) * ctx->kv_dim_l;
+    GL3_HIP(hipMemcpy(k_out, ctx->kcache + off, sizeof(float) * ctx->kv_dim_l, hipMemcpyDeviceToHost));
+    GL3_HIP(hipMemcpy(v_out, ctx->vcache + off, sizeof(float) * ctx->kv_dim_l, hipMemcpyDeviceToHost));
+    return GL3_OK;
+}
+
+int32_t gl3_reset_kv(gl3_ctx* ctx) {
+    if (!ctx) return GL3_E_ARG;
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    const size_t kvn = (size_t)ctx->d.n_layers * ctx->d.ctx * ctx->kv_dim_l;
+    GL3_HIP(hipMemsetAsync(ctx->kcache, 0, kvn * 4, ctx->stream));
+    GL3_HIP(hipMemsetAsync(ctx->vcache, 0, kvn * 4, ctx->stream));
+    GL3_HIP(hipStreamSynchronize(ctx->stream));
+    return GL3_OK;
+}
+
+int32_t gl3_get_init_ms(gl3_ctx* ctx, double* plan_ms, double* copy_in_ms) {
+    if (!ctx) return GL3_E_ARG;
+    if (plan_ms) *plan_ms = ctx->plan_ms;
+    if (copy_in_ms) *copy_in_ms = ctx->copy_in_ms;
+    return GL3_OK;
+}
+
+}  // extern "C"

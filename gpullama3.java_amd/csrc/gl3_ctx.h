@@ -1,0 +1,92 @@
+// gl3_ctx.h — plan state shared by the translation units of libgpullama_hip.so.
+// Mirrors what the reference keeps in State (J/inference/state/State.java:28-100) + TornadoWeights
+// (J/inference/weights/tornado/TornadoWeights.java:20-48), but resident in HBM for the ctx lifetime.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/gpullama3_hip.h"
+
+struct Q8Mat {               // one repacked (Q8R) matrix, see gl3_decode_kernels.h
+    uint8_t* w = nullptr;
+    int rows = 0, k = 0, nbp = 0;
+    size_t bytes() const { return (size_t)rows * nbp * 34; }
+    size_t algo_bytes() const { return (size_t)rows * (k / 32) * 34; }   // GGUF bytes (no padding)
+};
+
+struct gl3_layer {
+    Q8Mat wqkv, wo, w1, w3, w2;
+    float *attn_norm = nullptr, *ffn_norm = nullptr, *qnorm = nullptr, *knorm = nullptr;
+    uint32_t have = 0;       // bit per tensor id
+};
+
+struct gl3_ctx {
+    gl3_model_desc d{};
+    // derived (local = this tensor-parallel rank's share)
+    int q_dim = 0, kv_dim = 0, heads_l = 0, kv_heads_l = 0, q_dim_l = 0, kv_dim_l = 0, hidden_l = 0, vocab_l = 0;
+    int n_split = 8;
+    hipStream_t stream = nullptr;
+    // weights
+    Q8Mat emb, wcls;
+    bool wcls_owned = false;
+    float* out_norm = nullptr;
+    uint32_t have_global = 0;
+    std::vector<gl3_layer> layers;
+    float *rope_cr = nullptr, *rope_ci = nullptr;
+    uint64_t rope_n = 0;
+    // state
+    float *kcache = nullptr, *vcache = nullptr;   // [L][ctx][kv_dim_l]
+    float *x = nullptr, *qkv = nullptr, *xb = nullptr, *hb = nullptr, *y = nullptr, *logits = nullptr, *part = nullptr;
+    float* taps = nullptr;                        // [L][dim] when GL3_FLAG_LAYER_TAPS
+    int *dyn = nullptr, *argmax = nullptr;        // dyn[0] = token, dyn[1] = position
+    int* h_dyn = nullptr;                         // pinned
+    float* h_logits = nullptr;                    // pinned f32[vocab]
+    int* h_argmax = nullptr;
+    // upload staging
+    uint8_t* staging = nullptr;
+    size_t staging_bytes = 0;
+    // batched prefill (gl3_prefill.hip)
+    struct gl3_prefill_state* pf = nullptr;
+    // execution
+    bool finalized = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;          // decode step incl. logits
+    ncclComm_t comm = nullptr;
+    bool use_rccl = false;
+    std::vector<hipEvent_t> ev;
+    // metrics
+    double plan_ms = 0, copy_in_ms = 0;
+    std::string err;
+};
+
+#define GL3_HIP(call)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+            return e_ == hipErrorOutOfMemory ? GL3_E_OOM : GL3_E_HIP;                                  \
+        }                                                                                              \
+    } while (0)
+
+#define GL3_NCCL(call)                                                                                 \
+    do {                                                                                               \
+        ncclResult_t r_ = (call);                                                                      \
+        if (r_ != ncclSuccess) {                                                                       \
+            ctx->err = std::string(#call) + ": " + ncclGetErrorString(r_);                             \
+            return GL3_E_RCCL;                                                                         \
+        }                                                                                              \
+    } while (0)
+
+#define GL3_FAIL(code, msg)                                                                            \
+    do {                                                                                               \
+        ctx->err = (msg);                                                                              \
+        return (code);                                                                                 \
+    } while (0)
+
+// gl3_prefill.hip
+int32_t gl3_prefill_alloc(gl3_ctx* ctx);
+void gl3_prefill_free(gl3_ctx* ctx);
+int32_t gl3_prefill_run(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t start_pos);

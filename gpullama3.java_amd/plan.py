@@ -1,0 +1,152 @@
+"""HipMasterPlan — host-side mirror of the reference's plan interface over the C-ABI.
+
+Mirrors ``interface TornadoVMMasterPlan`` (J/tornadovm/TornadoVMMasterPlan.java:30-85) and its
+BatchPrefillDecode subclass (J/tornadovm/TornadoVMMasterPlanBatchPrefillDecode.java:107-168) with
+the reference's method names, so callers read like the Java engines:
+
+    plan = HipMasterPlan.initializeTornadoVMPlan(model, prefill_batch_size=512)   # ctor + copy-in
+    plan.tornadoVMForwardBatchPrefill(tokens, start_pos)                          # no logits
+    logits = plan.tornadoVMForwardDecode(token, position)                         # f32[vocab]
+    plan.freeTornadoExecutionPlan()
+
+Differences that the C-ABI makes explicit: the token id is an argument (the
+reference passes the embedding row through State.embeddingX) and logits are returned, not left in
+State.wrapLogits.  Unsupported model x quant x mode combinations raise Gl3Error(GL3_E_UNSUPPORTED)
+where the reference throws UnsupportedOperationException (ForwardPlanFactory.java:84-86).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import hip
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HipMasterPlan:
+    def __init__(self, model, prefill_batch_size: int = 1, device: int = 0, tp_rank: int = 0, tp_size: int = 1,
+                 flags: int = 0, unique_id: bytes | None = None):
+        """model: synth.SynthModel-like — cfg, tensors {gguf name: (raw uint8, ggml_type, rows, cols)}, rope (cr, ci)."""
+        L = hip.lib()
+        c = model.cfg
+        self.cfg = c
+        self._ctx = C.c_void_p()
+        d = hip.ModelDesc(C.sizeof(hip.ModelDesc), c.arch, c.dim, c.hidden, c.n_layers, c.n_heads, c.n_kv_heads,
+                          c.head_size, c.vocab, c.ctx, c.rms_eps, model.wtype, prefill_batch_size, device, tp_rank,
+                          tp_size, flags)
+        hip.check(L.gl3_create(C.byref(d), C.byref(self._ctx)))
+        self.tp_size, self.tp_rank = tp_size, tp_rank
+        self.max_batch = prefill_batch_size
+        try:
+            if tp_size > 1 or flags & hip.FLAG_FORCE_RCCL:
+                assert unique_id is not None, "tensor parallel plan needs the RCCL unique id from rank 0"
+                buf = C.create_string_buffer(unique_id, len(unique_id))
+                hip.check(L.gl3_tp_init(self._ctx, buf, len(unique_id)), self._ctx)
+            for name, t in model.tensor_items():
+                raw, ty = t[0], t[1]
+                if name.startswith("blk."):
+                    _, l, rest = name.split(".", 2)
+                    tid, layer = hip.T_IDS[rest], int(l)
+                else:
+                    tid, layer = hip.T_IDS[name], 0
+                raw = np.ascontiguousarray(raw)
+                hip.check(L.gl3_upload_tensor(self._ctx, tid, layer, _p(raw), raw.nbytes, ty), self._ctx)
+            cr, ci = model.rope
+            hip.check(L.gl3_upload_rope(self._ctx, _p(cr), _p(ci), cr.size), self._ctx)
+            self.forceCopyInReadOnlyData()
+        except Exception:
+            self.freeTornadoExecutionPlan()
+            raise
+        self._logits = np.empty(c.vocab, np.float32)
+        self._arg = C.c_int32()
+
+    # ---- reference-named interface -------------------------------------------------------------
+    @classmethod
+    def initializeTornadoVMPlan(cls, model, prefill_batch_size: int = 1, **kw) -> "HipMasterPlan":
+        """TornadoVMMasterPlan.initializeTornadoVMPlan(state, model) :55-70 — the plan flavour is picked from
+        llama.prefillBatchSize: > 1 allocates the batched-prefill (MFMA) buffers."""
+        return cls(model, prefill_batch_size=prefill_batch_size, **kw)
+
+    def forceCopyInReadOnlyData(self):
+        hip.check(hip.lib().gl3_finalize(self._ctx), self._ctx)
+
+    def tornadoVMForwardDecode(self, token: int, position: int) -> np.ndarray:
+        """One decode step; returns the logits (host-visible on return, like state.wrapLogits)."""
+        return self.forward_decode(token, position)
+
+    def tornadoVMForwardPrefill(self, token: int, position: int):
+        """TornadoVMMasterPlanPrefillDecode.tornadoVMForwardPrefill(position): one token, logits skipped."""
+        t = np.array([token], np.int32)
+        hip.check(hip.lib().gl3_forward_prefill(self._ctx, _p(t), 1, position), self._ctx)
+
+    def tornadoVMForwardBatchPrefill(self, tokens, start_pos: int):
+        """TornadoVMMasterPlanBatchPrefillDecode.tornadoVMForwardBatchPrefill(): one chunk, logits skipped."""
+        t = np.ascontiguousarray(tokens, np.int32)
+        hip.check(hip.lib().gl3_forward_prefill(self._ctx, _p(t), t.size, start_pos), self._ctx)
+
+    def freeTornadoExecutionPlan(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            hip.lib().gl3_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    # ---- pythonic conveniences -----------------------------------------------------------------
+    def forward_decode(self, token: int, position: int, copy: bool = True):
+        hip.check(hip.lib().gl3_forward_decode(self._ctx, token, position, _p(self._logits), None), self._ctx)
+        return self._logits.copy() if copy else self._logits
+
+    def forward_decode_argmax(self, token: int, position: int) -> int:
+        """-Dllama.deviceSample: greedy token id sampled on the device (4 bytes D2H instead of vocab*4)."""
+        hip.check(hip.lib().gl3_forward_decode(self._ctx, token, position, None, C.byref(self._arg)), self._ctx)
+        return int(self._arg.value)
+
+    def prefill(self, tokens, start_pos: int = 0):
+        """LlamaBench.prefill (J/bench/LlamaBench.java:258-273): chunks of max_batch."""
+        tokens = list(tokens)
+        b = max(1, self.max_batch)
+        for off in range(0, len(tokens), b):
+            self.tornadoVMForwardBatchPrefill(tokens[off:off + b], start_pos + off)
+
+    def x(self):
+        out = np.empty(self.cfg.dim, np.float32)
+        hip.check(hip.lib().gl3_get_x(self._ctx, _p(out)), self._ctx)
+        return out
+
+    def layer_x(self, layer: int):
+        out = np.empty(self.cfg.dim, np.float32)
+        hip.check(hip.lib().gl3_get_layer_x(self._ctx, layer, _p(out)), self._ctx)
+        return out
+
+    def kv(self, layer: int, pos: int):
+        n = self.cfg.kv_dim // self.tp_size
+        k, v = np.empty(n, np.float32), np.empty(n, np.float32)
+        hip.check(hip.lib().gl3_get_kv(self._ctx, layer, pos, _p(k), _p(v)), self._ctx)
+        return k, v
+
+    def reset_kv(self):
+        hip.check(hip.lib().gl3_reset_kv(self._ctx), self._ctx)
+
+    def profile_decode(self, token: int, position: int) -> dict:
+        kt = hip.KernelTimes()
+        hip.check(hip.lib().gl3_profile_decode(self._ctx, token, position, C.byref(kt)), self._ctx)
+        return {n: dict(ms=kt.ms[i], launches=kt.launches[i], bytes=kt.bytes[i]) for i, n in enumerate(hip.K_NAMES)}
+
+    def init_ms(self):
+        a, b = C.c_double(), C.c_double()
+        hip.check(hip.lib().gl3_get_init_ms(self._ctx, C.byref(a), C.byref(b)), self._ctx)
+        return dict(plan_creation_ms=a.value, weights_copy_in_ms=b.value)
+
+    def __del__(self):
+        try:
+            self.freeTornadoExecutionPlan()
+        except Exception:
+            pass
+
+
+def make_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    hip.check(hip.lib().gl3_tp_unique_id(buf, 128))
+    return buf.raw

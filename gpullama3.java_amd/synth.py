@@ -155,6 +155,9 @@ class SynthModel:
         self.cfg, self.wtype, self.tensors = cfg, wtype, tensors
         self.rope = rope_table(cfg.ctx, cfg.head_size, cfg.rope_theta)
 
+    def tensor_items(self):
+        return self.tensors.items()
+
     def oracle_tensors(self):
         return {k: (v[0], v[1]) for k, v in self.tensors.items()}
 
@@ -253,14 +256,14 @@ def _t_quantize_q4_0(w):
     return out.reshape(-1)
 
 
-def make_torch(cfg: ModelConfig, wtype: int = GGML_Q8_0, seed: int = 42, sigma: float = 0.02, device="cpu",
-               rows_per_chunk: int = 16384) -> SynthModel:
-    """Same recipe with torch RNG on ``device``; raw bytes are returned as host NumPy arrays because
-    the C-ABI takes caller-owned host pointers (the Java host's mmap'd GGUF)."""
+def iter_torch(cfg: ModelConfig, wtype: int = GGML_Q8_0, seed: int = 42, sigma: float = 0.02, device="cpu",
+               rows_per_chunk: int = 16384):
+    """Streams (name, raw host bytes, ggml_type, rows, cols) in file order, generated with torch RNG on
+    ``device``.  Raw bytes are host NumPy arrays because the C-ABI takes caller-owned host pointers (the
+    Java host's mmap'd GGUF); a streaming consumer never holds more than one tensor."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    tensors = {}
     for name, rows, cols, ty, kind in tensor_specs(cfg, wtype):
         parts = []
         for r0 in range(0, rows, rows_per_chunk):
@@ -277,5 +280,23 @@ def make_torch(cfg: ModelConfig, wtype: int = GGML_Q8_0, seed: int = 42, sigma: 
             else:
                 b = _t_quantize_q4_0(w)
             parts.append(b.cpu().numpy())
-        tensors[name] = (np.concatenate(parts) if len(parts) > 1 else parts[0], ty, rows, cols)
+        yield name, (np.concatenate(parts) if len(parts) > 1 else parts[0]), ty, rows, cols
+
+
+def make_torch(cfg: ModelConfig, wtype: int = GGML_Q8_0, seed: int = 42, sigma: float = 0.02, device="cpu") -> SynthModel:
+    """Same recipe as make_numpy with torch RNG on ``device`` (the GPU box builds the 8B model in seconds)."""
+    tensors = {name: (raw, ty, rows, cols) for name, raw, ty, rows, cols in iter_torch(cfg, wtype, seed, sigma, device)}
     return SynthModel(cfg, wtype, tensors)
+
+
+class StreamModel:
+    """cfg + rope + a one-shot tensor stream: lets a tensor-parallel rank upload an 8B model without ever
+    holding it in host memory (HipMasterPlan consumes ``tensor_items()``)."""
+
+    def __init__(self, cfg: ModelConfig, wtype: int, it):
+        self.cfg, self.wtype, self._it = cfg, wtype, it
+        self.rope = rope_table(cfg.ctx, cfg.head_size, cfg.rope_theta)
+
+    def tensor_items(self):
+        for name, raw, ty, rows, cols in self._it:
+            yield name, (raw, ty, rows, cols)

@@ -1,0 +1,175 @@
+/*
+ * gpullama3_hip.h — C-ABI of libgpullama_hip.so, the MI355X-native replacement for the
+ * TornadoVM TaskGraph layer of beehive-lab/GPULlama3.java.
+ *
+ * What it replaces (all paths relative to /root/reference/src/main/java/org/beehive/gpullama3/, "J/"):
+ *   interface TornadoVMMasterPlan          J/tornadovm/TornadoVMMasterPlan.java:30-85
+ *     initializeTornadoVMPlan(state,model) :55-70   -> gl3_create + gl3_upload_* + gl3_finalize
+ *     forceCopyInReadOnlyData()            :79      -> gl3_finalize
+ *     tornadoVMForwardDecode(position)     :81      -> gl3_forward_decode
+ *     freeTornadoExecutionPlan()           :84      -> gl3_destroy
+ *   TornadoVMMasterPlanBatchPrefillDecode.tornadoVMForwardBatchPrefill()
+ *                                          J/tornadovm/TornadoVMMasterPlanBatchPrefillDecode.java:107-123
+ *                                                   -> gl3_forward_prefill
+ *   TornadoVMMasterPlanPrefillDecode.tornadoVMForwardPrefill(position)
+ *                                          J/tornadovm/TornadoVMMasterPlanPrefillDecode.java:116
+ *                                                   -> gl3_forward_prefill(n = 1)
+ * In the reference, inputs cross this seam by side effect through the shared State object
+ * (J/inference/state/State.java:28-100: embeddingX, wrapXBatch, batchStartPosHolder, wrapLogits) and
+ * TornadoWeights (J/inference/weights/tornado/TornadoWeights.java:20-48).  Here every argument is
+ * explicit: token ids in, logits (or the greedy argmax, Sampler.java:21-28) out; the embedding row
+ * gather that InferenceCore.forwardTornadoVM does on the host (J/inference/InferenceCore.java:956-980)
+ * happens on the device.
+ *
+ * Ownership: the library owns all device memory for the ctx lifetime.  Every host pointer passed in
+ * stays owned by the caller and only has to be valid during the call (weights: the caller's mmap'd
+ * GGUF tensor-data segment, J/tensor/GGUF.java:105-137; raw ggml block layout, J/tensor/GGMLType.java:5-21).
+ * Errors: every function returns a gl3_status (0 = OK, negative = error); no C++ exception crosses
+ * the ABI; gl3_last_error() gives the message (the Java shim maps non-zero to RuntimeException, as the
+ * reference throws UnsupportedOperationException / TornadoOutOfMemoryException —
+ * J/tornadovm/plan/ForwardPlanFactory.java:84-86).
+ * Threading: a gl3_ctx is not re-entrant but may be called from any thread, never concurrently
+ * (the reference serialises inference with a lock, J/server/InferenceService.java:59).  forward_*
+ * return only after the requested outputs are in host memory.
+ */
+#ifndef GPULLAMA3_HIP_H
+#define GPULLAMA3_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GL3_API __attribute__((visibility("default")))
+
+typedef struct gl3_ctx gl3_ctx;
+
+typedef enum {
+    GL3_OK = 0,
+    GL3_E_ARG = -1,          /* bad argument / tensor shape mismatch */
+    GL3_E_UNSUPPORTED = -2,  /* model x quantisation x mode not implemented (ForwardPlanFactory.java:80-121) */
+    GL3_E_OOM = -3,          /* hipMalloc failed (TornadoOutOfMemoryException) */
+    GL3_E_HIP = -4,          /* any other HIP runtime error */
+    GL3_E_RCCL = -5,         /* collective failed */
+    GL3_E_STATE = -6         /* call order violated (e.g. forward before finalize) */
+} gl3_status;
+
+/* model families with all three plan modes in the reference (ForwardPlanFactory.java:123-141) */
+enum { GL3_ARCH_LLAMA = 0, GL3_ARCH_QWEN3 = 1 };
+
+/* ggml tensor types of the wire format (J/tensor/GGMLType.java:5-21) */
+enum { GL3_TYPE_F32 = 0, GL3_TYPE_F16 = 1, GL3_TYPE_Q4_0 = 2, GL3_TYPE_Q8_0 = 8 };
+
+/* weight set (J/inference/weights/tornado/TornadoWeights.java:20-48; GGUF names in
+ * J/model/loader/LlamaModelLoader.java:83-98, Qwen3ModelLoader.java:96-118) */
+enum {
+    GL3_T_TOKEN_EMBD = 0,   /* token_embd.weight        [vocab x dim]  quantised */
+    GL3_T_OUTPUT_NORM = 1,  /* output_norm.weight       [dim]          F32       */
+    GL3_T_OUTPUT = 2,       /* output.weight (wcls)     [vocab x dim]  quantised; omit when tied */
+    GL3_T_ATTN_NORM = 3,    /* blk.L.attn_norm.weight   [dim]          F32       */
+    GL3_T_WQ = 4,           /* blk.L.attn_q.weight      [qDim x dim]             */
+    GL3_T_WK = 5,           /* blk.L.attn_k.weight      [kvDim x dim]            */
+    GL3_T_WV = 6,           /* blk.L.attn_v.weight      [kvDim x dim]            */
+    GL3_T_WO = 7,           /* blk.L.attn_output.weight [dim x qDim]             */
+    GL3_T_FFN_NORM = 8,     /* blk.L.ffn_norm.weight    [dim]          F32       */
+    GL3_T_W1 = 9,           /* blk.L.ffn_gate.weight    [hidden x dim]           */
+    GL3_T_W2 = 10,          /* blk.L.ffn_down.weight    [dim x hidden]           */
+    GL3_T_W3 = 11,          /* blk.L.ffn_up.weight      [hidden x dim]           */
+    GL3_T_ATTN_Q_NORM = 12, /* blk.L.attn_q_norm.weight [head_size]    F32, qwen3 */
+    GL3_T_ATTN_K_NORM = 13, /* blk.L.attn_k_norm.weight [head_size]    F32, qwen3 */
+    GL3_T_COUNT = 14
+};
+
+/* gl3_model_desc.flags */
+#define GL3_FLAG_NO_GRAPH   0x1u  /* launch the decode step kernel by kernel instead of one hipGraph replay */
+#define GL3_FLAG_LAYER_TAPS 0x2u  /* keep x after every layer for gl3_get_layer_x (parity tap)            */
+#define GL3_FLAG_FORCE_RCCL 0x4u  /* run the per-block all-reduce even when tp_size == 1 (test hook)       */
+
+/* Configuration (J/model/Configuration.java via LlamaModelLoader.java:47-63 / Qwen3ModelLoader.java:48-74)
+ * plus the plan-selection knobs the reference reads from system properties
+ * (llama.prefillBatchSize -> max_batch, TornadoVMMasterPlan.java:39-41). */
+typedef struct {
+    uint32_t struct_size;   /* sizeof(gl3_model_desc), for forward compatibility */
+    int32_t arch;           /* GL3_ARCH_* */
+    int32_t dim;            /* embedding_length */
+    int32_t hidden;         /* feed_forward_length */
+    int32_t n_layers;       /* block_count */
+    int32_t n_heads;        /* attention.head_count */
+    int32_t n_kv_heads;     /* attention.head_count_kv */
+    int32_t head_size;      /* dim / n_heads (llama) or attention.key_length (qwen3) */
+    int32_t vocab;
+    int32_t ctx;            /* context length = KV-cache rows per layer */
+    float   rms_eps;        /* attention.layer_norm_rms_epsilon */
+    int32_t weight_type;    /* GL3_TYPE_* of the matrices */
+    int32_t max_batch;      /* largest prefill chunk (llama.prefillBatchSize); <= 1: no batched prefill buffers */
+    int32_t device;         /* HIP device ordinal */
+    int32_t tp_rank;        /* tensor-parallel rank of this process (0 when tp_size == 1) */
+    int32_t tp_size;        /* tensor-parallel degree: heads / hidden units / vocab rows are split tp_size ways */
+    uint32_t flags;         /* GL3_FLAG_* */
+} gl3_model_desc;
+
+/* Per-kernel-class device time of one instrumented decode step (HIP events around every launch). */
+enum { GL3_K_MATVEC_QKV = 0, GL3_K_MATVEC_WO = 1, GL3_K_MATVEC_GATEUP = 2, GL3_K_MATVEC_DOWN = 3,
+       GL3_K_MATVEC_LOGITS = 4, GL3_K_ATTENTION = 5, GL3_K_OTHER = 6, GL3_K_COLLECTIVE = 7, GL3_K_COUNT = 8 };
+typedef struct {
+    double   ms[GL3_K_COUNT];        /* summed event-to-event time per class */
+    uint32_t launches[GL3_K_COUNT];
+    uint64_t bytes[GL3_K_COUNT];     /* algorithmic HBM bytes per class (weights + vectors), SURVEY.md §8d */
+} gl3_kernel_times;
+
+GL3_API const char* gl3_version(void);
+
+/* Build the plan: allocates weights/KV/scratch in HBM (TornadoVMMasterPlan ctor: graph build + JIT are
+ * replaced by precompiled gfx950 code objects). */
+GL3_API int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out);
+
+/* Copy one tensor to HBM (FIRST_EXECUTION copy-in of the reference).  `host` is raw ggml blocks for the
+ * FULL tensor, also under tensor parallelism (the library keeps only this rank's slice).  The library may
+ * repack (split scale/quant planes); bytes moved per token are unchanged. */
+GL3_API int32_t gl3_upload_tensor(gl3_ctx* ctx, int32_t tensor_id, int32_t layer, const void* host,
+                                  uint64_t bytes, int32_t ggml_type);
+
+/* freq_cis_real / freq_cis_imag as the host precomputes them (J/inference/operation/RoPE.java:6-37);
+ * n = rows * head_size/2 floats, rows >= ctx. */
+GL3_API int32_t gl3_upload_rope(gl3_ctx* ctx, const float* cr, const float* ci, uint64_t n);
+
+/* Join a tensor-parallel group: `unique_id` is the RCCL id made by gl3_tp_unique_id on rank 0 and
+ * broadcast by the host (torch.distributed / any side channel).  Must precede gl3_finalize. */
+GL3_API int32_t gl3_tp_unique_id(void* out, uint64_t bytes);   /* bytes >= 128 */
+GL3_API int32_t gl3_tp_init(gl3_ctx* ctx, const void* unique_id, uint64_t bytes);
+
+/* forceCopyInReadOnlyData(): checks that every tensor arrived, ties wcls to token_embd when
+ * GL3_T_OUTPUT was not uploaded (AbstractModelLoader.java:194), captures the decode hipGraph. */
+GL3_API int32_t gl3_finalize(gl3_ctx* ctx);
+
+/* One decode step (InferenceCore.forwardTornadoVM + plan.tornadoVMForwardDecode(position)).
+ * logits_out: caller-allocated f32[vocab] or NULL; argmax_out: first index of the maximum or NULL. */
+GL3_API int32_t gl3_forward_decode(gl3_ctx* ctx, int32_t token, int32_t position, float* logits_out,
+                                   int32_t* argmax_out);
+
+/* Batched prefill of tokens[0..n) at positions start_pos.. (no logits, as the reference skips them).
+ * n <= max_batch. */
+GL3_API int32_t gl3_forward_prefill(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t start_pos);
+
+/* Parity taps. */
+GL3_API int32_t gl3_get_x(gl3_ctx* ctx, float* out /* f32[dim] */);
+GL3_API int32_t gl3_get_layer_x(gl3_ctx* ctx, int32_t layer, float* out /* f32[dim], needs GL3_FLAG_LAYER_TAPS */);
+GL3_API int32_t gl3_get_kv(gl3_ctx* ctx, int32_t layer, int32_t position, float* k_out, float* v_out /* f32[kvDim/tp] */);
+
+GL3_API int32_t gl3_reset_kv(gl3_ctx* ctx);
+
+/* One decode step launched kernel by kernel with HIP events around every launch. */
+GL3_API int32_t gl3_profile_decode(gl3_ctx* ctx, int32_t token, int32_t position, gl3_kernel_times* out);
+
+/* RunMetrics slots (TornadoVMMasterPlanSingleToken.java:40-54): plan creation and weight copy-in, ms. */
+GL3_API int32_t gl3_get_init_ms(gl3_ctx* ctx, double* plan_ms, double* copy_in_ms);
+
+GL3_API void gl3_destroy(gl3_ctx* ctx);
+GL3_API const char* gl3_last_error(gl3_ctx* ctx);  /* ctx may be NULL: last create error */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
