@@ -5,8 +5,8 @@
 // (J/tornadovm/layers/type/q8_0/LlamaQ8_0FFNLayers.java:111-230, LogitsQ8_0Layer.java:60-95) fused down to
 // six launches per layer:
 //   1 qkv matvec   = attn_rms_reduce + attn_rms_apply + qkv_projection        (RMSNorm + act-quant in prologue)
-//   2 attention    = rope_and_kv_cache + attention (split over the sequence)
-//   3 combine      = split-KV combine (as Qwen3's combineSplitKVAttention, ...Layered.java:1368)
+//   2 scores       = rope_and_kv_cache + q.k scores (tiles of 64 timesteps)
+//   3 softmax + PV = softmax and weighted V sum, t ascending
 //   4 wo matvec    = attn_output_proj (+ residual)
 //   5 gate/up      = ffn_rms_reduce + rms_ffn_gate_up (SwiGLU epilogue)
 //   6 down matvec  = ffn_down_proj (+ residual)
@@ -34,57 +34,37 @@ static bool env_flag(const char* name, bool dflt) {
 }
 
 // ------------------------------------------------------------------------------------------------ matvec launch
-struct MatvecPlan { int wgs, rows_per_wave, g; };
-
-// Balanced static partition: prefer a workgroup count that is a multiple of the 256 CUs and divides the rows
-// evenly (per-CU HBM throughput is capped near 10 B/clk, so every CU must get the same share).
-static MatvecPlan plan_matvec(int rows, int max_g) {
-    MatvecPlan p{};
-    const int cands[] = {1024, 768, 512, 256};
-    for (int wgs : cands) {
-        if (rows % (wgs * WAVES) == 0) { p.wgs = wgs; p.rows_per_wave = rows / (wgs * WAVES); break; }
-    }
-    if (!p.wgs) {
-        p.rows_per_wave = (rows + 1024 * WAVES - 1) / (1024 * WAVES);
-        p.wgs = (rows + p.rows_per_wave * WAVES - 1) / (p.rows_per_wave * WAVES);
-    }
-    static const int force_g = getenv("GL3_G") ? atoi(getenv("GL3_G")) : 0;
-    p.g = 1;
-    for (int g = max_g; g >= 1; g >>= 1)
-        if (p.rows_per_wave % g == 0 || p.rows_per_wave > 2 * g) { p.g = g; break; }
-    if (force_g) p.g = force_g > max_g ? max_g : force_g;
-    return p;
+static size_t matvec_smem(int pro, int epi, const Q8Mat& w) {
+    const int nm = epi == EPI_SWIGLU ? 2 : 1;
+    return (size_t)w.ng * 4 * 32 + (size_t)w.ng * 4 * 4 + (pro == PRO_RMS ? (size_t)w.k * 4 : 0) + (size_t)2 * nm * w.ng * 64 * 4 + 64;
 }
 
 template <int PRO, int EPI>
-static void launch_matvec_t(const MatvecArgs& a, const MatvecPlan& p, size_t smem, hipStream_t s, bool nt) {
-#define GL3_MV(G, NT) hipLaunchKernelGGL((matvec_q8_kernel<PRO, EPI, G, NT>), dim3(p.wgs), dim3(WG), smem, s, a)
-    if (nt) {
-        if (p.g >= 4 && EPI != EPI_SWIGLU) GL3_MV(4, true);
-        else if (p.g >= 2) GL3_MV(2, true);
-        else GL3_MV(1, true);
-    } else {
-        if (p.g >= 4 && EPI != EPI_SWIGLU) GL3_MV(4, false);
-        else if (p.g >= 2) GL3_MV(2, false);
-        else GL3_MV(1, false);
-    }
-#undef GL3_MV
+static void launch_matvec_t(const MatvecArgs& a, int wgs, size_t smem, hipStream_t s, bool nt) {
+    if (nt) hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, true>), dim3(wgs), dim3(MV_THREADS), smem, s, a);
+    else hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, false>), dim3(wgs), dim3(MV_THREADS), smem, s, a);
 }
 
+template <int PRO, int EPI>
+static hipError_t allow_big_lds() {
+    hipError_t e = hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+}
+
+// rows_valid / out / resid_in may address a slice (tensor parallel row split); w holds exactly that slice.
 static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const Q8Mat* w2, const float* x,
                           const float* norm_w, float* out, const float* resid_in) {
     static const bool nt = env_flag("GL3_NT", true);
+    static const int max_wgs = getenv("GL3_WGS") ? atoi(getenv("GL3_WGS")) : 1024;
     MatvecArgs a{};
-    a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.k = w.k; a.nbp = w.nbp;
+    a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.k = w.k; a.ng = w.ng; a.nstrips = w.nstrips;
     a.x = x; a.norm_w = norm_w; a.eps = ctx->d.rms_eps; a.out = out; a.resid_in = resid_in;
-    const MatvecPlan p = plan_matvec(w.rows, epi == EPI_SWIGLU ? 2 : 4);
-    a.rows_per_wave = p.rows_per_wave;
-    const int nct = (w.nbp + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
-    const size_t smem = (size_t)nct * 2048 + (size_t)nct * CHUNK_BLOCKS * 4 + 64;
-    if (pro == PRO_RMS && epi == EPI_STORE) launch_matvec_t<PRO_RMS, EPI_STORE>(a, p, smem, ctx->stream, nt);
-    else if (pro == PRO_QUANT && epi == EPI_RESID) launch_matvec_t<PRO_QUANT, EPI_RESID>(a, p, smem, ctx->stream, nt);
-    else if (pro == PRO_RMS && epi == EPI_SWIGLU) launch_matvec_t<PRO_RMS, EPI_SWIGLU>(a, p, smem, ctx->stream, nt);
-    else launch_matvec_t<PRO_QUANT, EPI_STORE>(a, p, smem, ctx->stream, nt);
+    const int wgs = w.nstrips < max_wgs ? w.nstrips : max_wgs;
+    const size_t smem = matvec_smem(pro, epi, w);
+    if (pro == PRO_RMS && epi == EPI_STORE) launch_matvec_t<PRO_RMS, EPI_STORE>(a, wgs, smem, ctx->stream, nt);
+    else if (pro == PRO_QUANT && epi == EPI_RESID) launch_matvec_t<PRO_QUANT, EPI_RESID>(a, wgs, smem, ctx->stream, nt);
+    else launch_matvec_t<PRO_RMS, EPI_SWIGLU>(a, wgs, smem, ctx->stream, nt);
 }
 
 // ------------------------------------------------------------------------------------------------ decode step
@@ -112,15 +92,28 @@ struct Prof {
 
 static uint64_t mv_bytes(const Q8Mat& w) { return w.algo_bytes() + (uint64_t)w.k * 4 + (uint64_t)w.rows * 4; }
 
+// Tensor parallelism keeps the reference's arithmetic bit for bit: every matrix is split by OUTPUT rows (heads /
+// hidden units / dim rows / vocab rows), so each dot product is still evaluated in full, in order, by one rank;
+// the activations are re-assembled with an in-place all-gather (4 per layer + 1 for the logits).
+static int32_t all_gather(gl3_ctx* ctx, float* buf, int count_per_rank, Prof& pr) {
+    if (!ctx->use_rccl) return GL3_OK;
+    pr.begin(GL3_K_COLLECTIVE, 0);
+    GL3_NCCL(ncclAllGather(buf + (size_t)ctx->d.tp_rank * count_per_rank, buf, count_per_rank, ncclFloat, ctx->comm, ctx->stream));
+    pr.end();
+    return GL3_OK;
+}
+
 static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* kt) {
     const gl3_model_desc& d = ctx->d;
     hipStream_t s = ctx->stream;
     Prof pr{ctx, kt};
-    const bool tp = ctx->use_rccl;
+    const int rank = d.tp_rank;
     const size_t kv_layer = (size_t)d.ctx * ctx->kv_dim_l;
+    const int kvmul = d.n_heads / d.n_kv_heads;
+    int32_t r;
 
     pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
-    hipLaunchKernelGGL(embed_q8_kernel, dim3(1), dim3(WG), 0, s, ctx->emb.w, ctx->emb.nbp, d.dim, ctx->dyn, ctx->x);
+    hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn, ctx->x);
     pr.end();
 
     for (int l = 0; l < d.n_layers; ++l) {
@@ -132,52 +125,42 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         AttnArgs aa{};
         aa.qkv = ctx->qkv; aa.kcache = ctx->kcache + l * kv_layer; aa.vcache = ctx->vcache + l * kv_layer;
         aa.rope_cr = ctx->rope_cr; aa.rope_ci = ctx->rope_ci; aa.qnorm = L.qnorm; aa.knorm = L.knorm;
-        aa.dyn = ctx->dyn; aa.part = ctx->part; aa.n_heads = ctx->heads_l; aa.n_kv_heads = ctx->kv_heads_l;
-        aa.hs = d.head_size; aa.q_dim = ctx->q_dim_l; aa.kv_dim = ctx->kv_dim_l; aa.n_split = ctx->n_split;
+        aa.dyn = ctx->dyn; aa.att = ctx->att; aa.xb = ctx->xb + (size_t)rank * ctx->q_dim_l;
+        aa.n_heads = ctx->heads_l; aa.n_kv_heads = ctx->kv_heads_l;
+        aa.hs = d.head_size; aa.q_dim = ctx->q_dim_l; aa.kv_dim = ctx->kv_dim_l; aa.ctx = d.ctx;
         aa.eps = d.rms_eps; aa.arch = d.arch;
         pr.begin(GL3_K_ATTENTION, 0);
-        hipLaunchKernelGGL(attn_partial_kernel, dim3(ctx->heads_l * ctx->n_split), dim3(WG), 0, s, aa);
-        hipLaunchKernelGGL(attn_combine_kernel, dim3(ctx->heads_l), dim3(WG), 0, s, ctx->part, ctx->xb, d.head_size,
-                           ctx->n_split);
+        const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
+        hipLaunchKernelGGL(attn_scores_kernel, dim3(ctx->n_tsplit, ctx->kv_heads_l), dim3(64 * kvmul), sm1, s, aa);
+        hipLaunchKernelGGL(attn_softmax_pv_kernel, dim3(ctx->heads_l * ((d.head_size + 63) / 64)), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
         pr.end();
+        if ((r = all_gather(ctx, ctx->xb, ctx->q_dim_l, pr)) != GL3_OK) return r;
 
-        // x += Wo . xb ; under tensor parallelism rank 0 carries the residual and the partials are all-reduced
+        // x[rows of this rank] += Wo[rows, :] . xb
         pr.begin(GL3_K_MATVEC_WO, mv_bytes(L.wo));
-        launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, tp ? ctx->y : ctx->x,
-                      (!tp || d.tp_rank == 0) ? ctx->x : nullptr);
+        launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->x + (size_t)rank * ctx->dim_l,
+                      ctx->x + (size_t)rank * ctx->dim_l);
         pr.end();
-        if (tp) {
-            pr.begin(GL3_K_COLLECTIVE, 0);
-            GL3_NCCL(ncclAllReduce(ctx->y, ctx->x, d.dim, ncclFloat, ncclSum, ctx->comm, s));
-            pr.end();
-        }
+        if ((r = all_gather(ctx, ctx->x, ctx->dim_l, pr)) != GL3_OK) return r;
 
         pr.begin(GL3_K_MATVEC_GATEUP, mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4);
-        launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb, nullptr);
+        launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr);
         pr.end();
+        if ((r = all_gather(ctx, ctx->hb, ctx->hidden_l, pr)) != GL3_OK) return r;
 
         pr.begin(GL3_K_MATVEC_DOWN, mv_bytes(L.w2));
-        launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, tp ? ctx->y : ctx->x,
-                      (!tp || d.tp_rank == 0) ? ctx->x : nullptr);
+        launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->x + (size_t)rank * ctx->dim_l,
+                      ctx->x + (size_t)rank * ctx->dim_l);
         pr.end();
-        if (tp) {
-            pr.begin(GL3_K_COLLECTIVE, 0);
-            GL3_NCCL(ncclAllReduce(ctx->y, ctx->x, d.dim, ncclFloat, ncclSum, ctx->comm, s));
-            pr.end();
-        }
+        if ((r = all_gather(ctx, ctx->x, ctx->dim_l, pr)) != GL3_OK) return r;
         if (ctx->taps) hipMemcpyAsync(ctx->taps + (size_t)l * d.dim, ctx->x, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, s);
     }
     if (want_logits) {
         pr.begin(GL3_K_MATVEC_LOGITS, mv_bytes(ctx->wcls) + d.dim * 4);
         launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm,
-                      ctx->logits + (size_t)d.tp_rank * ctx->vocab_l, nullptr);
+                      ctx->logits + (size_t)rank * ctx->vocab_l, nullptr);
         pr.end();
-        if (tp && d.tp_size > 1) {
-            pr.begin(GL3_K_COLLECTIVE, 0);
-            GL3_NCCL(ncclAllGather(ctx->logits + (size_t)d.tp_rank * ctx->vocab_l, ctx->logits, ctx->vocab_l, ncclFloat,
-                                   ctx->comm, s));
-            pr.end();
-        }
+        if ((r = all_gather(ctx, ctx->logits, ctx->vocab_l, pr)) != GL3_OK) return r;
     }
     GL3_HIP(hipGetLastError());
     pr.collect();
@@ -192,7 +175,7 @@ static int32_t dmalloc(gl3_ctx* ctx, T** p, size_t n) {
 }
 
 static int32_t alloc_mat(gl3_ctx* ctx, Q8Mat& m, int rows, int k) {
-    m.rows = rows; m.k = k; m.nbp = ((k / 32) + 7) / 8 * 8;
+    m.rows = rows; m.k = k; m.ng = ((k / 32) + 3) / 4; m.nstrips = (rows + 15) / 16;
     GL3_HIP(hipMalloc((void**)&m.w, m.bytes()));
     return GL3_OK;
 }
@@ -221,14 +204,14 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     const int tp = d.tp_size < 1 ? 1 : d.tp_size;
     ctx->d.tp_size = tp;
     if (d.tp_rank < 0 || d.tp_rank >= tp) return bail(GL3_E_ARG, "tp_rank out of range");
-    if (d.n_heads % tp || d.n_kv_heads % tp || d.hidden % (32 * tp) || d.vocab % tp)
-        return bail(GL3_E_UNSUPPORTED, "tp_size must divide n_heads, n_kv_heads, hidden/32 and vocab");
+    if (d.n_heads % tp || d.n_kv_heads % tp || d.hidden % (16 * tp) || d.vocab % (16 * tp) || d.dim % (16 * tp))
+        return bail(GL3_E_UNSUPPORTED, "tp_size must divide n_heads, n_kv_heads, hidden/16, dim/16 and vocab/16");
+    if (d.n_heads / d.n_kv_heads > 16) return bail(GL3_E_UNSUPPORTED, "more than 16 query heads per kv head");
     ctx->q_dim = d.n_heads * d.head_size; ctx->kv_dim = d.n_kv_heads * d.head_size;
     ctx->heads_l = d.n_heads / tp; ctx->kv_heads_l = d.n_kv_heads / tp;
     ctx->q_dim_l = ctx->heads_l * d.head_size; ctx->kv_dim_l = ctx->kv_heads_l * d.head_size;
-    ctx->hidden_l = d.hidden / tp; ctx->vocab_l = d.vocab / tp;
-    ctx->n_split = 8;
-    while ((d.ctx + ctx->n_split - 1) / ctx->n_split > ATT_MAX_T) ctx->n_split *= 2;
+    ctx->hidden_l = d.hidden / tp; ctx->vocab_l = d.vocab / tp; ctx->dim_l = d.dim / tp;
+    ctx->n_tsplit = (d.ctx + ATT_TT - 1) / ATT_TT;
     ctx->use_rccl = tp > 1 || (d.flags & GL3_FLAG_FORCE_RCCL);
 
 #define TRY(x) do { int32_t r_ = (x); if (r_ != GL3_OK) return bail(r_, ""); } while (0)
@@ -239,10 +222,10 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     ctx->layers.resize(d.n_layers);
     for (auto& L : ctx->layers) {
         TRY(alloc_mat(ctx, L.wqkv, ctx->q_dim_l + 2 * ctx->kv_dim_l, d.dim));
-        TRY(alloc_mat(ctx, L.wo, d.dim, ctx->q_dim_l));
+        TRY(alloc_mat(ctx, L.wo, ctx->dim_l, ctx->q_dim));
         TRY(alloc_mat(ctx, L.w1, ctx->hidden_l, d.dim));
         TRY(alloc_mat(ctx, L.w3, ctx->hidden_l, d.dim));
-        TRY(alloc_mat(ctx, L.w2, d.dim, ctx->hidden_l));
+        TRY(alloc_mat(ctx, L.w2, ctx->dim_l, d.hidden));
         TRY(dmalloc(ctx, &L.attn_norm, d.dim));
         TRY(dmalloc(ctx, &L.ffn_norm, d.dim));
         if (d.arch == GL3_ARCH_QWEN3) { TRY(dmalloc(ctx, &L.qnorm, d.head_size)); TRY(dmalloc(ctx, &L.knorm, d.head_size)); }
@@ -254,12 +237,17 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP(hipMemset(ctx->kcache, 0, kvn * 4));
     TRYHIP(hipMemset(ctx->vcache, 0, kvn * 4));
     TRY(dmalloc(ctx, &ctx->x, d.dim));
-    TRY(dmalloc(ctx, &ctx->y, d.dim));
     TRY(dmalloc(ctx, &ctx->qkv, ctx->q_dim_l + 2 * ctx->kv_dim_l));
-    TRY(dmalloc(ctx, &ctx->xb, ctx->q_dim_l));
-    TRY(dmalloc(ctx, &ctx->hb, ctx->hidden_l));
+    TRY(dmalloc(ctx, &ctx->xb, ctx->q_dim));
+    TRY(dmalloc(ctx, &ctx->hb, d.hidden));
     TRY(dmalloc(ctx, &ctx->logits, d.vocab));
-    TRY(dmalloc(ctx, &ctx->part, (size_t)ctx->heads_l * ctx->n_split * (d.head_size + 2)));
+    TRY(dmalloc(ctx, &ctx->att, (size_t)ctx->heads_l * d.ctx));
+    TRYHIP((allow_big_lds<PRO_RMS, EPI_STORE>()));
+    TRYHIP((allow_big_lds<PRO_QUANT, EPI_RESID>()));
+    TRYHIP((allow_big_lds<PRO_RMS, EPI_SWIGLU>()));
+    TRYHIP(hipFuncSetAttribute((const void*)attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    TRYHIP(hipFuncSetAttribute((const void*)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    if ((size_t)d.ctx * 4 + 16 > 128 * 1024) return bail(GL3_E_UNSUPPORTED, "context length above 32k not supported by the decode attention kernel");
     TRY(dmalloc(ctx, &ctx->dyn, 4));
     TRY(dmalloc(ctx, &ctx->argmax, 1));
     if (d.flags & GL3_FLAG_LAYER_TAPS) TRY(dmalloc(ctx, &ctx->taps, (size_t)d.n_layers * d.dim));
@@ -291,8 +279,8 @@ void gl3_destroy(gl3_ctx* ctx) {
         f(L.wqkv.w); f(L.wo.w); f(L.w1.w); f(L.w3.w); f(L.w2.w);
         f(L.attn_norm); f(L.ffn_norm); f(L.qnorm); f(L.knorm);
     }
-    f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->x); f(ctx->y); f(ctx->qkv);
-    f(ctx->xb); f(ctx->hb); f(ctx->logits); f(ctx->part); f(ctx->dyn); f(ctx->argmax); f(ctx->taps); f(ctx->staging);
+    f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->x); f(ctx->qkv);
+    f(ctx->xb); f(ctx->hb); f(ctx->logits); f(ctx->att); f(ctx->dyn); f(ctx->argmax); f(ctx->taps); f(ctx->staging);
     if (ctx->h_dyn) hipHostFree(ctx->h_dyn);
     if (ctx->h_logits) hipHostFree(ctx->h_logits);
     if (ctx->h_argmax) hipHostFree(ctx->h_argmax);
@@ -312,26 +300,20 @@ static int32_t stage(gl3_ctx* ctx, const void* host, size_t bytes) {
     return GL3_OK;
 }
 
-// src: full [rows_full x k_full] GGUF Q8_0 tensor on the host; keeps rows [r0, r0+m.rows) (placed at dst_row0 of m)
-// and 32-blocks [b0, b0 + m.k/32).
+// src: full [rows_full x k_full] GGUF Q8_0 tensor on the host; keeps rows [r0, r0+sub_rows), placed at row
+// dst_row0 (multiple of 16) of m.  Only the kept rows are staged (tensor-parallel ranks upload 1/tp of the bytes).
 static int32_t upload_q8(gl3_ctx* ctx, Q8Mat& m, int dst_row0, int sub_rows, const void* host, uint64_t bytes, int rows_full,
-                         int k_full, long r0, int b0) {
-    const int nb_full = k_full / 32, nb = m.k / 32;
+                         int k_full, long r0) {
+    const int nb_full = k_full / 32;
+    if (k_full != m.k) GL3_FAIL(GL3_E_ARG, "tensor inner dimension mismatch");
     if (bytes != (uint64_t)rows_full * nb_full * 34) GL3_FAIL(GL3_E_ARG, "tensor byte size does not match its shape");
-    const uint8_t* h = (const uint8_t*)host;
-    long src_r0 = r0;
-    if (nb == nb_full) {   // row slice: upload only the rows this rank keeps
-        h += (size_t)r0 * nb_full * 34;
-        int32_t r = stage(ctx, h, (size_t)sub_rows * nb_full * 34);
-        if (r != GL3_OK) return r;
-        src_r0 = 0;
-    } else {
-        int32_t r = stage(ctx, h, bytes);
-        if (r != GL3_OK) return r;
-    }
-    const long total = (long)sub_rows * m.nbp;
-    hipLaunchKernelGGL(repack_q8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->staging,
-                       m.w + (size_t)dst_row0 * m.nbp * 34, sub_rows, nb, m.nbp, src_r0, b0, nb_full);
+    if (dst_row0 % 16) GL3_FAIL(GL3_E_UNSUPPORTED, "sub-matrix row offset must be a multiple of 16");
+    const uint8_t* h = (const uint8_t*)host + (size_t)r0 * nb_full * 34;
+    int32_t r = stage(ctx, h, (size_t)sub_rows * nb_full * 34);
+    if (r != GL3_OK) return r;
+    const long total = (long)((sub_rows + 15) & ~15) * m.ng * 4;
+    hipLaunchKernelGGL(repack_q8t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->staging,
+                       m.w + (size_t)(dst_row0 / 16) * m.ng * TILE_BYTES, sub_rows, nb_full, m.ng, 0L, 0, nb_full);
     GL3_HIP(hipStreamSynchronize(ctx->stream));
     return GL3_OK;
 }
@@ -359,23 +341,23 @@ int32_t gl3_upload_tensor(gl3_ctx* ctx, int32_t id, int32_t layer, const void* h
     if (id > GL3_T_OUTPUT && (layer < 0 || layer >= d.n_layers)) GL3_FAIL(GL3_E_ARG, "layer out of range");
     gl3_layer* L = id > GL3_T_OUTPUT ? &ctx->layers[layer] : nullptr;
     switch (id) {
-    case GL3_T_TOKEN_EMBD: r = upload_q8(ctx, ctx->emb, 0, d.vocab, host, bytes, d.vocab, d.dim, 0, 0); break;
+    case GL3_T_TOKEN_EMBD: r = upload_q8(ctx, ctx->emb, 0, d.vocab, host, bytes, d.vocab, d.dim, 0); break;
     case GL3_T_OUTPUT:
         if (!ctx->wcls_owned) { r = alloc_mat(ctx, ctx->wcls, ctx->vocab_l, d.dim); ctx->wcls_owned = (r == GL3_OK); }
-        if (r == GL3_OK) r = upload_q8(ctx, ctx->wcls, 0, ctx->vocab_l, host, bytes, d.vocab, d.dim, (long)rank * ctx->vocab_l, 0);
+        if (r == GL3_OK) r = upload_q8(ctx, ctx->wcls, 0, ctx->vocab_l, host, bytes, d.vocab, d.dim, (long)rank * ctx->vocab_l);
         break;
     case GL3_T_OUTPUT_NORM: r = upload_f32(ctx, ctx->out_norm, d.dim, host, bytes, type); break;
     case GL3_T_ATTN_NORM: r = upload_f32(ctx, L->attn_norm, d.dim, host, bytes, type); break;
     case GL3_T_FFN_NORM: r = upload_f32(ctx, L->ffn_norm, d.dim, host, bytes, type); break;
     case GL3_T_ATTN_Q_NORM: r = upload_f32(ctx, L->qnorm, d.head_size, host, bytes, type); break;
     case GL3_T_ATTN_K_NORM: r = upload_f32(ctx, L->knorm, d.head_size, host, bytes, type); break;
-    case GL3_T_WQ: r = upload_q8(ctx, L->wqkv, 0, ctx->q_dim_l, host, bytes, ctx->q_dim, d.dim, (long)rank * ctx->q_dim_l, 0); break;
-    case GL3_T_WK: r = upload_q8(ctx, L->wqkv, ctx->q_dim_l, ctx->kv_dim_l, host, bytes, ctx->kv_dim, d.dim, (long)rank * ctx->kv_dim_l, 0); break;
-    case GL3_T_WV: r = upload_q8(ctx, L->wqkv, ctx->q_dim_l + ctx->kv_dim_l, ctx->kv_dim_l, host, bytes, ctx->kv_dim, d.dim, (long)rank * ctx->kv_dim_l, 0); break;
-    case GL3_T_WO: r = upload_q8(ctx, L->wo, 0, d.dim, host, bytes, d.dim, ctx->q_dim, 0, rank * (ctx->q_dim_l / 32)); break;
-    case GL3_T_W1: r = upload_q8(ctx, L->w1, 0, ctx->hidden_l, host, bytes, d.hidden, d.dim, (long)rank * ctx->hidden_l, 0); break;
-    case GL3_T_W3: r = upload_q8(ctx, L->w3, 0, ctx->hidden_l, host, bytes, d.hidden, d.dim, (long)rank * ctx->hidden_l, 0); break;
-    case GL3_T_W2: r = upload_q8(ctx, L->w2, 0, d.dim, host, bytes, d.dim, d.hidden, 0, rank * (ctx->hidden_l / 32)); break;
+    case GL3_T_WQ: r = upload_q8(ctx, L->wqkv, 0, ctx->q_dim_l, host, bytes, ctx->q_dim, d.dim, (long)rank * ctx->q_dim_l); break;
+    case GL3_T_WK: r = upload_q8(ctx, L->wqkv, ctx->q_dim_l, ctx->kv_dim_l, host, bytes, ctx->kv_dim, d.dim, (long)rank * ctx->kv_dim_l); break;
+    case GL3_T_WV: r = upload_q8(ctx, L->wqkv, ctx->q_dim_l + ctx->kv_dim_l, ctx->kv_dim_l, host, bytes, ctx->kv_dim, d.dim, (long)rank * ctx->kv_dim_l); break;
+    case GL3_T_WO: r = upload_q8(ctx, L->wo, 0, ctx->dim_l, host, bytes, d.dim, ctx->q_dim, (long)rank * ctx->dim_l); break;
+    case GL3_T_W1: r = upload_q8(ctx, L->w1, 0, ctx->hidden_l, host, bytes, d.hidden, d.dim, (long)rank * ctx->hidden_l); break;
+    case GL3_T_W3: r = upload_q8(ctx, L->w3, 0, ctx->hidden_l, host, bytes, d.hidden, d.dim, (long)rank * ctx->hidden_l); break;
+    case GL3_T_W2: r = upload_q8(ctx, L->w2, 0, ctx->dim_l, host, bytes, d.dim, d.hidden, (long)rank * ctx->dim_l); break;
     default: GL3_FAIL(GL3_E_ARG, "unknown tensor id");
     }
     if (r != GL3_OK) return r;
@@ -446,7 +428,8 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
     if (!(ctx->have_global & (1u << GL3_T_OUTPUT))) {   // tied: wcls = this rank's vocab rows of token_embd
         ctx->wcls = ctx->emb;
         ctx->wcls.rows = ctx->vocab_l;
-        ctx->wcls.w = ctx->emb.w + (size_t)d.tp_rank * ctx->vocab_l * ctx->emb.nbp * 34;
+        ctx->wcls.nstrips = (ctx->vocab_l + 15) / 16;
+        ctx->wcls.w = ctx->emb.w + (size_t)(d.tp_rank * ctx->vocab_l / 16) * ctx->emb.ng * TILE_BYTES;
         ctx->wcls_owned = false;
     }
     if (ctx->staging) { hipFree(ctx->staging); ctx->staging = nullptr; ctx->staging_bytes = 0; }
@@ -546,6 +529,23 @@ int32_t gl3_get_kv(gl3_ctx* ctx, int32_t layer, int32_t pos, float* k_out, float
     const size_t off = ((size_t)layer * ctx->d.ctx + pos) * ctx->kv_dim_l;
     GL3_HIP(hipMemcpy(k_out, ctx->kcache + off, sizeof(float) * ctx->kv_dim_l, hipMemcpyDeviceToHost));
     GL3_HIP(hipMemcpy(v_out, ctx->vcache + off, sizeof(float) * ctx->kv_dim_l, hipMemcpyDeviceToHost));
+    return GL3_OK;
+}
+
+int32_t gl3_get_buffer(gl3_ctx* ctx, int32_t which, float* out, uint64_t n) {
+    if (!ctx || !out) return GL3_E_ARG;
+    const float* src = nullptr;
+    uint64_t cap = 0;
+    switch (which) {
+    case 0: src = ctx->qkv; cap = ctx->q_dim_l + 2 * ctx->kv_dim_l; break;
+    case 1: src = ctx->xb; cap = ctx->q_dim; break;
+    case 2: src = ctx->hb; cap = ctx->d.hidden; break;
+    case 3: src = ctx->logits; cap = ctx->d.vocab; break;
+    default: GL3_FAIL(GL3_E_ARG, "unknown buffer id");
+    }
+    if (n > cap) GL3_FAIL(GL3_E_ARG, "buffer shorter than requested");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    GL3_HIP(hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
     return GL3_OK;
 }
 

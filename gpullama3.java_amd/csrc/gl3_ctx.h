@@ -10,10 +10,12 @@
 
 #include "../../include/gpullama3_hip.h"
 
-struct Q8Mat {               // one repacked (Q8R) matrix, see gl3_decode_kernels.h
+struct Q8Mat {               // one repacked (Q8T) matrix, see gl3_decode_kernels.h
     uint8_t* w = nullptr;
-    int rows = 0, k = 0, nbp = 0;
-    size_t bytes() const { return (size_t)rows * nbp * 34; }
+    int rows = 0, k = 0;
+    int ng = 0;              // tile groups per strip = ceil(k/32 / 4)
+    int nstrips = 0;         // ceil(rows / 16)
+    size_t bytes() const { return (size_t)nstrips * ng * 2176; }
     size_t algo_bytes() const { return (size_t)rows * (k / 32) * 34; }   // GGUF bytes (no padding)
 };
 
@@ -26,8 +28,8 @@ struct gl3_layer {
 struct gl3_ctx {
     gl3_model_desc d{};
     // derived (local = this tensor-parallel rank's share)
-    int q_dim = 0, kv_dim = 0, heads_l = 0, kv_heads_l = 0, q_dim_l = 0, kv_dim_l = 0, hidden_l = 0, vocab_l = 0;
-    int n_split = 8;
+    int q_dim = 0, kv_dim = 0, heads_l = 0, kv_heads_l = 0, q_dim_l = 0, kv_dim_l = 0, hidden_l = 0, vocab_l = 0, dim_l = 0;
+    int n_tsplit = 1;        // ceil(ctx / 64) score tiles
     hipStream_t stream = nullptr;
     // weights
     Q8Mat emb, wcls;
@@ -39,7 +41,7 @@ struct gl3_ctx {
     uint64_t rope_n = 0;
     // state
     float *kcache = nullptr, *vcache = nullptr;   // [L][ctx][kv_dim_l]
-    float *x = nullptr, *qkv = nullptr, *xb = nullptr, *hb = nullptr, *y = nullptr, *logits = nullptr, *part = nullptr;
+    float *x = nullptr, *qkv = nullptr, *xb = nullptr, *hb = nullptr, *logits = nullptr, *att = nullptr;
     float* taps = nullptr;                        // [L][dim] when GL3_FLAG_LAYER_TAPS
     int *dyn = nullptr, *argmax = nullptr;        // dyn[0] = token, dyn[1] = position
     int* h_dyn = nullptr;                         // pinned

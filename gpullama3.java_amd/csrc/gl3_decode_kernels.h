@@ -5,116 +5,95 @@
 //   matrixVectorGenericWithResidualQ8_0Byte :2888-2906, fullyFusedRmsNormFFNGateUpQ8 :3386-3549,
 //   processHeadsFlashAttention :784-906, ropeRotationWithCacheCopy :495-542) and
 //   J/tornadovm/kernels/TransformerComputeKernels.java (convertQ8_0toFP32 :95-126, reductionOneBlock* :149-208)
-// but follows the ARITHMETIC of the pure-Java CPU path (the parity oracle), not of those GPU kernels:
-//   * Q8_0 matvec = dotQ8Activation (J/tensor/standard/Q8_0FloatTensor.java:90-123): the activation is
-//     quantised to int8 per 32-block (amax/127, f16-rounded scale, round-half-away) and the dot is
-//     int8 x int8 -> int32 (v_dot4_i32_i8), scaled by wScale*aScale in f32;
-//   * RMSNorm eps / RoPE tables come from the configuration, not from literals (SURVEY.md §7 hard parts);
-//   * exp / sqrt are evaluated in double and cast, as java.lang.Math does.
-// Only the ORDER of f32 reductions differs from the oracle (wave/tree reductions instead of a strictly
-// sequential sum); every element-wise operation is bit-identical (compiled with -ffp-contract=off).
+// but reproduces the ARITHMETIC of the pure-Java CPU path (the parity oracle) BIT FOR BIT:
+//   * Q8_0 matvec = dotQ8Activation (J/tensor/standard/Q8_0FloatTensor.java:90-123): activation quantised to
+//     int8 per 32-block (amax/127, f16-rounded scale, round-half-away), int8 x int8 -> int32 (v_dot4_i32_i8),
+//     p_b = isum * (wScale * aScale) in f32, and result += p_b STRICTLY IN BLOCK ORDER;
+//   * every other reduction (RMSNorm sum of squares, q.k dot, softmax denominator, weighted V sum) is also
+//     evaluated in the reference's left-to-right order with one f32 rounding per step, no FMA contraction
+//     (-ffp-contract=off); exp / sqrt are evaluated in double and cast, as java.lang.Math does.
+// Why bit-exact and not "close": the reference re-quantises activations to int8 before every matmul, so a
+// 1-ulp difference in any f32 sum flips an int8 somewhere and grows to ~1e-2 in the logits within a layer
+// (measured).  Only the same summation order meets the 1e-3 north-star tolerance.
 //
-// Weight layout in HBM ("Q8R", built once at upload by repack_q8_kernel): a row of nb 32-element blocks is
-// padded to a multiple of 8 blocks and cut into chunks of <= 64 blocks; a chunk of n blocks is stored as
-//   [n x f16 scale][n x 16 B quants 0..15][n x 16 B quants 16..31]          (34 n bytes, as in GGUF)
-// so one wavefront reads a chunk with three fully coalesced loads (2 B, 16 B, 16 B per lane; lane = block).
+// In-order sums at HBM speed: v_mfma_f32_16x16x4_f32 with B = 1.0 is bit-identical to four sequential f32
+// adds per row (D = fl(A[k] + D), k ascending; verified on MI355X by scripts/probes/mfma_chain_probe.hip), so
+// a wavefront advances 16 rows x 4 blocks of the strictly ordered block sum per instruction on the otherwise
+// idle matrix pipe.
+//
+// Weight layout in HBM ("Q8T", built once at upload by repack_q8t_kernel): rows are grouped in strips of 16
+// and 32-element blocks in groups of 4; tile (strip, g) holds 64 blocks, lane l = (row l&15, block 4g + l>>4):
+//   [64 x f16 scale][64 x 16 B quants 0..15][64 x 16 B quants 16..31]      (2176 B = 64 GGUF blocks)
+// = exactly the A-operand layout of the 16x16x4 MFMA, read with three fully coalesced loads per wavefront.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace gl3 {
 
-constexpr int WG = 256;            // 4 wavefronts of 64
-constexpr int WAVES = WG / 64;
-constexpr int CHUNK_BLOCKS = 64;   // blocks per chunk = lanes per wave
-constexpr int CHUNK_BYTES = 34 * CHUNK_BLOCKS;
+constexpr int TILE_BYTES = 2176;       // 64 Q8_0 blocks
+constexpr int MV_PRODUCERS = 4;        // wavefronts streaming weights
+constexpr int MV_THREADS = 64 * (MV_PRODUCERS + 1);   // + 1 wavefront running the ordered sums on the MFMA pipe
 
 enum { PRO_RMS = 0, PRO_QUANT = 1 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2 };
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 struct MatvecArgs {
-    const uint8_t* w;        // Q8R rows
+    const uint8_t* w;        // Q8T tiles
     const uint8_t* w2;       // second matrix (EPI_SWIGLU: w = gate W1, w2 = up W3)
-    int rows;                // output rows
+    int rows;                // valid output rows
     int k;                   // input length (multiple of 32)
-    int nbp;                 // padded blocks per row (multiple of 8)
-    int rows_per_wave;       // contiguous rows owned by one wave
+    int ng;                  // tile groups per strip = padded blocks / 4
+    int nstrips;             // 16-row strips
     const float* x;          // input vector f32[k]
     const float* norm_w;     // PRO_RMS: RMSNorm weight f32[k]
     float eps;
-    float* out;              // EPI_STORE: out[row]; EPI_SWIGLU: hb[row]
-    const float* resid_in;   // EPI_RESID: out[row] = resid_in[row] + acc  (resid_in may be NULL: out[row] = acc)
+    float* out;              // EPI_STORE: out[row]; EPI_SWIGLU: hb[row]; EPI_RESID: out[row] = resid_in[row] + acc
+    const float* resid_in;   // may be NULL (tensor-parallel ranks > 0)
 };
 
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
     return v;
 }
 
+// Strict left-to-right f32 sum of n floats held in LDS, executed redundantly by every lane of the calling
+// wavefront (uniform addresses -> LDS broadcast).  SQ = true sums x*x (InferenceCore.rmsnorm :41).
+template <bool SQ>
+__device__ __forceinline__ float seq_sum_lds(const float* v, int n) {
+    float s = 0.f;
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(v + i);
+        if (SQ) { s = s + a.x * a.x; s = s + a.y * a.y; s = s + a.z * a.z; s = s + a.w * a.w; }
+        else { s = s + a.x; s = s + a.y; s = s + a.z; s = s + a.w; }
+    }
+    for (; i < n; ++i) s = SQ ? s + v[i] * v[i] : s + v[i];
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------------
-// Activation prologue: (optional RMSNorm) + Q8_0 activation quantisation into LDS.
-//   InferenceCore.rmsnorm  J/inference/InferenceCore.java:39-48
-//   quantisation           J/tensor/standard/Q8_0FloatTensor.java:96-118
-// LDS image per chunk c: xq[c*2048 + bl*16] = quants 0..15 of block bl, xq[c*2048 + 1024 + bl*16] = 16..31;
-// xs[c*64 + bl] = f16-rounded activation scale.  Every workgroup builds its own copy (deterministic).
-template <int PRO>
-__device__ __forceinline__ void quantize_to_lds(const float* __restrict__ x, const float* __restrict__ nw, float eps,
-                                                int k, int nct, uint8_t* xq, float* xs, float* red) {
-    const int t = threadIdx.x;
-    const int nquads = k >> 2;
-    float scale = 1.0f;
-    if (PRO == PRO_RMS) {
-        float ss = 0.f;
-        for (int qd = t; qd < nquads; qd += WG) {
-            const float4 v = *reinterpret_cast<const float4*>(x + 4 * qd);
-            ss += v.x * v.x; ss += v.y * v.y; ss += v.z * v.z; ss += v.w * v.w;
-        }
-        ss = wave_sum(ss);
-        if ((t & 63) == 0) red[t >> 6] = ss;
-        __syncthreads();
-        float tot = ((red[0] + red[1]) + red[2]) + red[3];
-        tot /= (float)k;
-        tot += eps;
-        scale = (float)(1.0 / sqrt((double)tot));
-    }
-    // zero the padded tail (blocks k/32 .. nct*64) so ragged chunks read finite data
-    for (int b = (k >> 5) + t; b < nct * CHUNK_BLOCKS; b += WG) {
-        xs[b] = 0.f;
-        int4 z = {0, 0, 0, 0};
-        *reinterpret_cast<int4*>(xq + (b >> 6) * 2048 + (b & 63) * 16) = z;
-        *reinterpret_cast<int4*>(xq + (b >> 6) * 2048 + 1024 + (b & 63) * 16) = z;
-    }
-    for (int qd = t; qd < nquads; qd += WG) {   // 8 consecutive threads own one 32-element block
-        float4 v = *reinterpret_cast<const float4*>(x + 4 * qd);
-        if (PRO == PRO_RMS) {
-            const float4 w = *reinterpret_cast<const float4*>(nw + 4 * qd);
-            v.x = w.x * (scale * v.x); v.y = w.y * (scale * v.y); v.z = w.z * (scale * v.z); v.w = w.w * (scale * v.w);
-        }
-        float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-        amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
-        const float qs = amax / 127.0f;
-        const float ainv = qs != 0.f ? 1.0f / qs : 0.f;
-        float s0 = v.x * ainv, s1 = v.y * ainv, s2 = v.z * ainv, s3 = v.w * ainv;
-        const int q0 = (int)(s0 + copysignf(0.5f, s0)), q1 = (int)(s1 + copysignf(0.5f, s1));
-        const int q2 = (int)(s2 + copysignf(0.5f, s2)), q3 = (int)(s3 + copysignf(0.5f, s3));
-        const uint32_t packed = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) |
-                                ((uint32_t)(q3 & 0xFF) << 24);
-        const int b = qd >> 3, wd = qd & 7;
-        uint8_t* dst = xq + (b >> 6) * 2048 + (wd >= 4 ? 1024 : 0) + (b & 63) * 16 + (wd & 3) * 4;
-        *reinterpret_cast<uint32_t*>(dst) = packed;
-        if (wd == 0) xs[b] = (float)(_Float16)qs;   // Float.float16ToFloat(Float.floatToFloat16(qs))
-    }
-    __syncthreads();
+// Activation quantisation into LDS (Q8_0FloatTensor.java:96-118): 8 consecutive threads own one 32-block.
+// xq[32*b ..] = int8 quants of block b, xs[b] = f16-rounded activation scale.  v = value already normalised.
+__device__ __forceinline__ void quantize_quad(float4 v, int qd, uint8_t* xq, float* xs) {
+    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float qs = amax / 127.0f;
+    const float ainv = qs != 0.f ? 1.0f / qs : 0.f;
+    const float s0 = v.x * ainv, s1 = v.y * ainv, s2 = v.z * ainv, s3 = v.w * ainv;
+    const int q0 = (int)(s0 + copysignf(0.5f, s0)), q1 = (int)(s1 + copysignf(0.5f, s1));
+    const int q2 = (int)(s2 + copysignf(0.5f, s2)), q3 = (int)(s3 + copysignf(0.5f, s3));
+    const uint32_t packed = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) |
+                            ((uint32_t)(q3 & 0xFF) << 24);
+    *reinterpret_cast<uint32_t*>(xq + 4 * qd) = packed;                  // byte 32*b + 4*(qd&7)
+    if ((qd & 7) == 0) xs[qd >> 3] = (float)(_Float16)qs;               // float16ToFloat(floatToFloat16(qs))
 }
 
 __device__ __forceinline__ int dot32(const int4& a0, const int4& a1, const int4& b0, const int4& b1) {
@@ -142,76 +121,124 @@ __device__ __forceinline__ uint16_t ld2(const uint8_t* p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Dequant-fused Q8_0 matvec.  One wavefront owns `rows_per_wave` contiguous rows and walks them G at a time
-// (NM = 2 for the fused gate/up pair); lane = block within a 64-block chunk.  HBM-bound: per row-chunk a wave
-// issues 3 coalesced loads (128 B + 1 KiB + 1 KiB), straight to VGPRs, non-temporal (each byte is read once).
-template <int PRO, int EPI, int G, bool NT>
-__global__ __launch_bounds__(WG) void matvec_q8_kernel(const MatvecArgs a) {
+// Dequant-fused Q8_0 matvec, bit-exact to FloatTensor.matmul + dotQ8Activation.
+// Workgroup = 4 producer wavefronts + 1 chain wavefront.  Per 16-row strip the producers stream the strip's
+// tiles (lane = one 32-block of one row: 3 coalesced non-temporal loads, 8 v_dot4, p = isum*(wScale*aScale))
+// into a double-buffered LDS array; the chain wavefront then adds the p's of each row in block order with
+// v_mfma_f32_16x16x4_f32 (B = 1.0) while the producers already stream the next strip.
+//   LDS: xq[ng*128] | xs[ng*4] f32 | xf[k] f32 (PRO_RMS) | pbuf[2][NM][ng*64] f32 | red[4]
+template <int PRO, int EPI, bool NT>
+__global__ __launch_bounds__(MV_THREADS) void matvec_q8t_kernel(const MatvecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
-    const int nct = (a.nbp + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nb4 = a.ng * 4;
     uint8_t* xq = smem;
-    float* xs = reinterpret_cast<float*>(smem + nct * 2048);
-    float* red = xs + nct * CHUNK_BLOCKS;
+    float* xs = reinterpret_cast<float*>(smem + (size_t)nb4 * 32);
+    float* xf = xs + nb4;
+    float* pbuf = xf + (PRO == PRO_RMS ? a.k : 0);
+    float* red = pbuf + (size_t)2 * NM * a.ng * 64;
 
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * WAVES + (threadIdx.x >> 6);
-    const int row_begin = gw * a.rows_per_wave;
-    const int row_end = min(a.rows, row_begin + a.rows_per_wave);
-    const size_t stride = (size_t)a.nbp * 34;
-
-    quantize_to_lds<PRO>(a.x, a.norm_w, a.eps, a.k, nct, xq, xs, red);
-
-    for (int row0 = row_begin; row0 < row_end; row0 += G) {
-        float acc[NM][G];
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-#pragma unroll
-            for (int r = 0; r < G; ++r) acc[m][r] = 0.f;
-
-        for (int c = 0; c < nct; ++c) {
-            const int n = min(CHUNK_BLOCKS, a.nbp - c * CHUNK_BLOCKS);   // wave-uniform
-            if (lane < n) {
-                uint16_t sc[NM][G];
-                int4 lo[NM][G], hi[NM][G];
-#pragma unroll
-                for (int m = 0; m < NM; ++m)
-#pragma unroll
-                    for (int r = 0; r < G; ++r) {
-                        const int row = min(row0 + r, row_end - 1);      // ragged last group re-reads a valid row
-                        const uint8_t* p = (m == 0 ? a.w : a.w2) + (size_t)row * stride + (size_t)c * CHUNK_BYTES;
-                        sc[m][r] = ld2<NT>(p + 2 * lane);
-                        lo[m][r] = ld16<NT>(p + 2 * n + 16 * lane);
-                        hi[m][r] = ld16<NT>(p + 18 * n + 16 * lane);
-                    }
-                const int4 xlo = *reinterpret_cast<const int4*>(xq + c * 2048 + lane * 16);
-                const int4 xhi = *reinterpret_cast<const int4*>(xq + c * 2048 + 1024 + lane * 16);
-                const float xsc = xs[c * CHUNK_BLOCKS + lane];
-#pragma unroll
-                for (int m = 0; m < NM; ++m)
-#pragma unroll
-                    for (int r = 0; r < G; ++r) {
-                        const int isum = dot32(lo[m][r], hi[m][r], xlo, xhi);
-                        acc[m][r] += (float)isum * (h2f(sc[m][r]) * xsc);   // result += isum * (wScale * aScale)
-                    }
-            }
+    // ---- prologue: (RMSNorm) + activation quantisation, identical in every workgroup
+    const int nquads = a.k >> 2;
+    float scale = 1.0f;
+    if (PRO == PRO_RMS) {
+        for (int qd = t; qd < nquads; qd += MV_THREADS)
+            *reinterpret_cast<float4*>(xf + 4 * qd) = *reinterpret_cast<const float4*>(a.x + 4 * qd);
+        __syncthreads();
+        if (wave == MV_PRODUCERS) {                  // InferenceCore.rmsnorm :41 — strict left-to-right sum
+            const float ss = seq_sum_lds<true>(xf, a.k);
+            if (lane == 0) red[0] = ss;
         }
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-#pragma unroll
-            for (int r = 0; r < G; ++r) acc[m][r] = wave_sum(acc[m][r]);
+        __syncthreads();
+        float ss = red[0];
+        ss /= (float)a.k;
+        ss += a.eps;
+        scale = (float)(1.0 / sqrt((double)ss));
+    }
+    for (int b = (a.k >> 5) + t; b < nb4; b += MV_THREADS) {   // zero-padded blocks
+        xs[b] = 0.f;
+        const int4 z = {0, 0, 0, 0};
+        *reinterpret_cast<int4*>(xq + 32 * b) = z;
+        *reinterpret_cast<int4*>(xq + 32 * b + 16) = z;
+    }
+    for (int qd = t; qd < nquads; qd += MV_THREADS) {
+        float4 v;
+        if (PRO == PRO_RMS) {
+            v = *reinterpret_cast<const float4*>(xf + 4 * qd);
+            const float4 w = *reinterpret_cast<const float4*>(a.norm_w + 4 * qd);
+            v.x = w.x * (scale * v.x); v.y = w.y * (scale * v.y); v.z = w.z * (scale * v.z); v.w = w.w * (scale * v.w);
+        } else {
+            v = *reinterpret_cast<const float4*>(a.x + 4 * qd);
+        }
+        quantize_quad(v, qd, xq, xs);
+    }
+    __syncthreads();
 
-        if (lane == 0) {
+    // ---- main loop over this workgroup's strips
+    const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
+    int it = 0;
+    if (wave < MV_PRODUCERS) {
+        for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x, ++it) {
+            float* pb = pbuf + (size_t)(it & 1) * NM * a.ng * 64;
+            for (int g0 = wave; g0 < a.ng; g0 += MV_PRODUCERS * 4) {
+                uint16_t sc[NM][4];
+                int4 lo[NM][4], hi[NM][4];
 #pragma unroll
-            for (int r = 0; r < G; ++r) {
-                const int row = row0 + r;
-                if (row < row_end) {
-                    if (EPI == EPI_STORE) a.out[row] = acc[0][r];
-                    if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + acc[0][r] : acc[0][r];
-                    if (EPI == EPI_SWIGLU) {   // InferenceCore.java:155-158, exp in double
-                        float g = acc[0][r];
-                        g = g / (float)(1.0 + exp(-(double)g));
-                        a.out[row] = g * acc[NM - 1][r];
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + u * MV_PRODUCERS;
+                    if (g < a.ng) {
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+                            const uint8_t* p = (m == 0 ? a.w : a.w2) + (size_t)strip * strip_bytes + (size_t)g * TILE_BYTES;
+                            sc[m][u] = ld2<NT>(p + 2 * lane);
+                            lo[m][u] = ld16<NT>(p + 128 + 16 * lane);
+                            hi[m][u] = ld16<NT>(p + 1152 + 16 * lane);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + u * MV_PRODUCERS;
+                    if (g < a.ng) {
+                        const int xb = 4 * g + (lane >> 4);
+                        const int4 xlo = *reinterpret_cast<const int4*>(xq + 32 * xb);
+                        const int4 xhi = *reinterpret_cast<const int4*>(xq + 32 * xb + 16);
+                        const float xsc = xs[xb];
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+                            const int isum = dot32(lo[m][u], hi[m][u], xlo, xhi);
+                            pb[(size_t)m * a.ng * 64 + g * 64 + lane] = (float)isum * (h2f(sc[m][u]) * xsc);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x, ++it) {
+            __syncthreads();
+            const float* pb = pbuf + (size_t)(it & 1) * NM * a.ng * 64;
+            v4f acc[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) acc[m] = (v4f){0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < a.ng; ++g) {          // result += p_b, b ascending: 4 blocks x 16 rows per MFMA
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[(size_t)m * a.ng * 64 + g * 64 + lane], 1.0f, acc[m], 0, 0, 0);
+            }
+            if ((lane & 15) == 0) {                   // D[i][j]: row i = 4*(lane>>4) + reg, all 16 columns identical
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = strip * 16 + 4 * (lane >> 4) + r;
+                    if (row < a.rows) {
+                        if (EPI == EPI_STORE) a.out[row] = acc[0][r];
+                        if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + acc[0][r] : acc[0][r];
+                        if (EPI == EPI_SWIGLU) {      // InferenceCore.java:155-158, exp in double
+                            float gte = acc[0][r];
+                            gte = gte / (float)(1.0 + exp(-(double)gte));
+                            a.out[row] = gte * acc[NM - 1][r];
+                        }
                     }
                 }
             }
@@ -222,29 +249,29 @@ __global__ __launch_bounds__(WG) void matvec_q8_kernel(const MatvecArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // Embedding row gather + dequant: x[i] = q * d  (token_embedding_table.copyTo, InferenceCore.java:61;
 // replaces the host row copy of forwardTornadoVM :956-980 + convertQ8_0toFP32).
-__global__ __launch_bounds__(WG) void embed_q8_kernel(const uint8_t* __restrict__ emb, int nbp, int dim,
-                                                       const int* __restrict__ dyn, float* __restrict__ x) {
+__global__ __launch_bounds__(256) void embed_q8t_kernel(const uint8_t* __restrict__ emb, int ng, int dim,
+                                                         const int* __restrict__ dyn, float* __restrict__ x) {
     const int token = dyn[0];
-    const uint8_t* row = emb + (size_t)token * nbp * 34;
-    for (int i = threadIdx.x; i < dim; i += WG) {
-        const int b = i >> 5, c = b >> 6, bl = b & 63, j = i & 31;
-        const int n = min(CHUNK_BLOCKS, nbp - c * CHUNK_BLOCKS);
-        const uint8_t* p = row + (size_t)c * CHUNK_BYTES;
-        const float d = h2f(*reinterpret_cast<const uint16_t*>(p + 2 * bl));
-        const int8_t q = (int8_t)p[(j < 16 ? 2 * n : 18 * n) + 16 * bl + (j & 15)];
+    const uint8_t* strip = emb + (size_t)(token >> 4) * ng * TILE_BYTES;
+    const int i16 = token & 15;
+    for (int i = threadIdx.x; i < dim; i += 256) {
+        const int b = i >> 5, j = i & 31;
+        const uint8_t* p = strip + (size_t)(b >> 2) * TILE_BYTES;
+        const int l = i16 + 16 * (b & 3);
+        const float d = h2f(*reinterpret_cast<const uint16_t*>(p + 2 * l));
+        const int8_t q = (int8_t)p[(j < 16 ? 128 : 1152) + 16 * l + (j & 15)];
         x[i] = (float)q * d;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Decode attention, split over the sequence.  Grid = n_heads x n_split workgroups.
-//   scores / softmax / weighted V sum: InferenceCore.java:98-137 (Qwen3 :631-663)
-//   RoPE (adjacent pairs) :75-87, Qwen3 per-head RMSNorm + NeoX RoPE :594-619, KV write :92-93
-// The qkv matvec leaves RAW q|k|v in `qkv`; this kernel rotates q (and the new k) on the fly, the split
-// that owns `pos` of head h with h % kvMul == 0 writes the rotated k and v into the cache, and every
-// split takes the row for t == pos from registers instead of the cache (no intra-launch read-after-write).
+// Decode attention, part 1: RoPE + KV-cache write + scores.   Grid = (n_tsplit, n_kv_heads), block = 64 x kvMul.
+//   RoPE (adjacent pairs) InferenceCore.java:75-87; Qwen3 per-head RMSNorm + NeoX RoPE :594-619;
+//   KV write :92-93; score = scalarDot(q_h, K[t]) / sqrt(head_size) :108-116 (strict j order, mul then add).
+// One workgroup owns a kv head and a tile of 64 timesteps: thread = (query head of the group, timestep).
+// The K tile is staged through LDS with coalesced loads (row pitch hs+1: conflict-free per-lane rows).
 struct AttnArgs {
-    const float* qkv;        // raw [qDim | kvDim | kvDim]
+    const float* qkv;        // raw [qDim | kvDim | kvDim] from the qkv projection
     float* kcache;           // [ctx][kvDim] of this layer
     float* vcache;
     const float* rope_cr;    // [ctx][hs/2]
@@ -252,16 +279,16 @@ struct AttnArgs {
     const float* qnorm;      // qwen3: f32[hs] (else NULL)
     const float* knorm;
     const int* dyn;          // dyn[1] = position
-    float* part;             // [H][S][hs + 2]  (m, l, o[hs])
-    int n_heads, n_kv_heads, hs, q_dim, kv_dim, n_split;
+    float* att;              // [n_heads][ctx] scores
+    float* xb;               // [qDim] attention output
+    int n_heads, n_kv_heads, hs, q_dim, kv_dim, ctx;
     float eps;
     int arch;
 };
 
-// rotate one head vector held in LDS: v[hs]; Llama pairs (2i,2i+1), NeoX pairs (i, i+hs/2)
-__device__ __forceinline__ void rope_head(float* v, int hs, const float* cr, const float* ci, int arch, int t, int nthreads) {
+__device__ __forceinline__ void rope_head(float* v, int hs, const float* cr, const float* ci, int arch, int t0, int nthreads) {
     const int half = hs >> 1;
-    for (int i = t; i < half; i += nthreads) {
+    for (int i = t0; i < half; i += nthreads) {
         const float fcr = cr[i], fci = ci[i];
         const int i0 = arch == 0 ? 2 * i : i, i1 = arch == 0 ? 2 * i + 1 : i + half;
         const float v0 = v[i0], v1 = v[i1];
@@ -270,136 +297,106 @@ __device__ __forceinline__ void rope_head(float* v, int hs, const float* cr, con
     }
 }
 
-// per-head RMSNorm in LDS by one wavefront-sized group (hs <= 256): out = w * (ss * x)
-__device__ __forceinline__ void head_rmsnorm(float* v, const float* w, int hs, float eps, float* red) {
-    const int t = threadIdx.x;
+// rmsnorm(v, v, w, hs) by ONE thread (strict order), InferenceCore.rmsnorm applied per head (:594-600)
+__device__ __forceinline__ void head_rmsnorm_1t(float* v, const float* w, int hs, float eps) {
     float ss = 0.f;
-    for (int i = t; i < hs; i += WG) ss += v[i] * v[i];
-    ss = wave_sum(ss);
-    if ((t & 63) == 0) red[t >> 6] = ss;
-    __syncthreads();
-    float tot = ((red[0] + red[1]) + red[2]) + red[3];
-    __syncthreads();
-    tot /= (float)hs;
-    tot += eps;
-    const float sc = (float)(1.0 / sqrt((double)tot));
-    for (int i = t; i < hs; i += WG) v[i] = w[i] * (sc * v[i]);
-    __syncthreads();
+    for (int i = 0; i < hs; ++i) ss = ss + v[i] * v[i];
+    ss /= (float)hs;
+    ss += eps;
+    ss = (float)(1.0 / sqrt((double)ss));
+    for (int i = 0; i < hs; ++i) v[i] = w[i] * (ss * v[i]);
 }
 
-constexpr int ATT_MAX_T = 1024;   // timesteps one split can hold in LDS
+constexpr int ATT_TT = 64;   // timesteps per score workgroup
 
-__global__ __launch_bounds__(WG) void attn_partial_kernel(const AttnArgs a) {
-    __shared__ float q_s[256], k_s[256], sc_s[ATT_MAX_T], red[WAVES], o_s[WG];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int h = blockIdx.x / a.n_split, sp = blockIdx.x % a.n_split;
-    const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads, kvh = h / kvmul;
+__global__ void attn_scores_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads;
+    float* q_s = sm;                         // [kvmul][hs]
+    float* kt = q_s + kvmul * hs;            // [ATT_TT][hs + 1]
+    const int t = threadIdx.x, nthr = blockDim.x;
+    const int sp = blockIdx.x, kvh = blockIdx.y;
     const int pos = a.dyn[1];
-    const int span = (pos + 1 + a.n_split - 1) / a.n_split;
-    const int t0 = sp * span, t1 = min(pos + 1, t0 + span);
-    float* part = a.part + ((size_t)h * a.n_split + sp) * (hs + 2);
-    if (t0 >= t1) {               // empty split
-        if (t == 0) { part[0] = -INFINITY; part[1] = 0.f; }
-        return;
-    }
+    const int t0 = sp * ATT_TT;
+    if (t0 > pos) return;
+    const int t1 = min(pos + 1, t0 + ATT_TT);
     const bool owns_pos = (t1 == pos + 1);
-    for (int i = t; i < hs; i += WG) {
-        q_s[i] = a.qkv[h * hs + i];
-        if (owns_pos) k_s[i] = a.qkv[a.q_dim + kvh * hs + i];
-    }
+    const int pitch = hs + 1;
+    // raw q of the group's heads, raw k of this kv head (owner only, into its tile row)
+    for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.qkv[(kvh * kvmul) * hs + i];
+    float* krow = kt + (pos - t0) * pitch;
+    if (owns_pos) for (int i = t; i < hs; i += nthr) krow[i] = a.qkv[a.q_dim + kvh * hs + i];
     __syncthreads();
     if (a.arch == 1) {
-        head_rmsnorm(q_s, a.qnorm, hs, a.eps, red);
-        if (owns_pos) head_rmsnorm(k_s, a.knorm, hs, a.eps, red);
+        if (t < kvmul) head_rmsnorm_1t(q_s + t * hs, a.qnorm, hs, a.eps);
+        if (owns_pos && t == kvmul) head_rmsnorm_1t(krow, a.knorm, hs, a.eps);
+        __syncthreads();
     }
     const float* cr = a.rope_cr + (size_t)pos * (hs >> 1);
     const float* ci = a.rope_ci + (size_t)pos * (hs >> 1);
-    rope_head(q_s, hs, cr, ci, a.arch, t, WG);
-    if (owns_pos) rope_head(k_s, hs, cr, ci, a.arch, t, WG);
+    for (int h = 0; h < kvmul; ++h) rope_head(q_s + h * hs, hs, cr, ci, a.arch, t, nthr);
+    if (owns_pos) rope_head(krow, hs, cr, ci, a.arch, t, nthr);
+    // K tile rows t0 .. t1-1 from the cache (all but the row of `pos`, which is in LDS already)
+    const int nrows_cache = owns_pos ? (t1 - 1 - t0) : (t1 - t0);
+    const int q4 = hs >> 2;
+    for (int i = t; i < nrows_cache * q4; i += nthr) {
+        const int r = i / q4, c = i % q4;
+        const float4 v = *reinterpret_cast<const float4*>(a.kcache + (size_t)(t0 + r) * a.kv_dim + kvh * hs + 4 * c);
+        float* d = kt + r * pitch + 4 * c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
     __syncthreads();
-    if (owns_pos && (h % kvmul) == 0) {          // KV write, InferenceCore.java:92-93
-        for (int i = t; i < hs; i += WG) {
-            a.kcache[(size_t)pos * a.kv_dim + kvh * hs + i] = k_s[i];
+    if (owns_pos) {                              // KV write, InferenceCore.java:92-93
+        for (int i = t; i < hs; i += nthr) {
+            a.kcache[(size_t)pos * a.kv_dim + kvh * hs + i] = krow[i];
             a.vcache[(size_t)pos * a.kv_dim + kvh * hs + i] = a.qkv[a.q_dim + a.kv_dim + kvh * hs + i];
         }
     }
-    // ---- scores: lpt = hs/4 lanes per timestep, float4 each
-    const int lpt = hs >> 2, tpi = WG / lpt;      // timesteps per iteration
-    const int sub = t % lpt, tslot = t / lpt;
-    const float sqrt_hs = (float)sqrt((double)hs);
-    const float4 qv = *reinterpret_cast<const float4*>(&q_s[4 * sub]);
-    for (int tb = t0; tb < t1; tb += tpi) {
-        const int tt = tb + tslot;
-        float s = 0.f;
-        if (tt < t1) {
-            float4 kv;
-            if (tt == pos) kv = *reinterpret_cast<const float4*>(&k_s[4 * sub]);
-            else kv = *reinterpret_cast<const float4*>(a.kcache + (size_t)tt * a.kv_dim + kvh * hs + 4 * sub);
-            s = qv.x * kv.x; s += qv.y * kv.y; s += qv.z * kv.z; s += qv.w * kv.w;
-        }
-        for (int m = lpt >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);   // lpt <= 64 lanes, aligned groups
-        if (tt < t1 && sub == 0) sc_s[tt - t0] = s / sqrt_hs;
+    const int hq = t >> 6, r = t & 63;           // wavefront = query head of the group, lane = timestep
+    if (hq < kvmul && t0 + r < t1) {
+        const float* q = q_s + hq * hs;
+        const float* kk = kt + r * pitch;
+        float score = 0.f;
+        for (int j = 0; j < hs; ++j) score = score + q[j] * kk[j];
+        const float sqrt_hs = (float)sqrt((double)hs);
+        a.att[(size_t)(kvh * kvmul + hq) * a.ctx + t0 + r] = score / sqrt_hs;
     }
-    __syncthreads();
-    // ---- local softmax numerators (max, exp in double, sum)
-    const int nt = t1 - t0;
-    float mx = -INFINITY;
-    for (int i = t; i < nt; i += WG) mx = fmaxf(mx, sc_s[i]);
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float ls = 0.f;
-    for (int i = t; i < nt; i += WG) {
-        const float p = (float)exp((double)(sc_s[i] - mx));
-        sc_s[i] = p;
-        ls += p;
-    }
-    ls = wave_sum(ls);
-    if (lane == 0) red[wave] = ls;
-    __syncthreads();
-    ls = ((red[0] + red[1]) + red[2]) + red[3];
-    // ---- o[j] = sum_t p_t * V[t][j]; hs lanes over j, WG/hs groups over t
-    const int groups = max(1, WG / hs);
-    const int j = t % hs, grp = t / hs;
-    float o = 0.f;
-    if (grp < groups && j < hs) {
-        for (int tt = t0 + grp; tt < t1; tt += groups) {
-            const float v = (tt == pos) ? a.qkv[a.q_dim + a.kv_dim + kvh * hs + j]
-                                        : a.vcache[(size_t)tt * a.kv_dim + kvh * hs + j];
-            o = sc_s[tt - t0] * v + o;
-        }
-        o_s[grp * hs + j] = o;
-    }
-    __syncthreads();
-    if (t < hs) {
-        float tot = o_s[t];
-        for (int g = 1; g < groups; ++g) tot += o_s[g * hs + t];
-        part[2 + t] = tot;
-    }
-    if (t == 0) { part[0] = mx; part[1] = ls; }
 }
 
-// Combine the splits of one head: xb[h*hs + j] = sum_s w_s o_s[j] / sum_s w_s l_s, w_s = exp(m_s - M).
-__global__ __launch_bounds__(WG) void attn_combine_kernel(const float* __restrict__ part, float* __restrict__ xb,
-                                                           int hs, int n_split) {
-    const int h = blockIdx.x, t = threadIdx.x;
-    const float* p = part + (size_t)h * n_split * (hs + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < n_split; ++s) M = fmaxf(M, p[s * (hs + 2)]);
-    float L = 0.f;
-    for (int j = t; j < hs; j += WG) {
-        float o = 0.f;
-        L = 0.f;
-        for (int s = 0; s < n_split; ++s) {
-            const float m = p[s * (hs + 2)];
-            if (m == -INFINITY) continue;
-            const float w = (float)exp((double)(m - M));
-            L += w * p[s * (hs + 2) + 1];
-            o += w * p[s * (hs + 2) + 2 + j];
+// Decode attention, part 2: softmax + weighted V sum.   Grid = n_heads x ceil(hs/64), block = 64.
+//   FloatTensor.softmaxInPlace :211-219 (max, exp in double, strict sum, divide); saxpyInPlace :221-227 with
+//   t ascending: xb[j] = a_t * v[t][j] + xb[j].  Dynamic LDS: e[ctx].
+__global__ __launch_bounds__(64) void attn_softmax_pv_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float e_s[];
+    const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads;
+    const int nj = (hs + 63) / 64;
+    const int h = blockIdx.x / nj, j = (blockIdx.x % nj) * 64 + threadIdx.x;
+    const int lane = threadIdx.x, kvh = h / kvmul;
+    const int n = a.dyn[1] + 1;
+    const float* sc = a.att + (size_t)h * a.ctx;
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) { const float s = sc[i]; e_s[i] = s; mx = fmaxf(mx, s); }
+    mx = wave_max(mx);
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) e_s[i] = (float)exp((double)(e_s[i] - mx));
+    __syncthreads();
+    const float sum = seq_sum_lds<false>(e_s, n);
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) e_s[i] = e_s[i] / sum;
+    __syncthreads();
+    if (j < hs) {
+        const float* v = a.vcache + kvh * hs + j;
+        float acc = 0.f;
+        int tt = 0;
+        for (; tt + 8 <= n; tt += 8) {
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = v[(size_t)(tt + u) * a.kv_dim];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = e_s[tt + u] * vv[u] + acc;
         }
-        xb[h * hs + j] = o / L;
+        for (; tt < n; ++tt) acc = e_s[tt] * v[(size_t)tt * a.kv_dim] + acc;
+        a.xb[h * hs + j] = acc;
     }
 }
 
@@ -432,18 +429,19 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// One-time layout transform at upload: GGUF Q8_0 blocks (34 B: f16 d + 32 x int8, GGMLType.java:13) of the
-// row range [r0, r0+rows) and block range [b0, b0+nb) of a [*, nb_full*32] matrix -> Q8R chunks.
-__global__ void repack_q8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int nb, int nbp,
-                                 long r0, int b0, int nb_full) {
+// One-time layout transform at upload: GGUF Q8_0 blocks (34 B: f16 d + 32 x int8, GGMLType.java:13) of rows
+// [r0, r0+rows) and blocks [b0, b0+nb) of a [*, nb_full*32] matrix -> Q8T tiles.  One thread per destination
+// (row, block) slot incl. zero padding (rows -> x16, blocks -> x4).
+__global__ void repack_q8t_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int nb, int ng,
+                                  long r0, int b0, int nb_full) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)rows * nbp) return;
-    const int row = (int)(idx / nbp), pb = (int)(idx % nbp);
-    const int c = pb >> 6, bl = pb & 63;
-    const int n = min(CHUNK_BLOCKS, nbp - c * CHUNK_BLOCKS);
-    uint8_t* base = dst + (size_t)row * nbp * 34 + (size_t)c * CHUNK_BYTES;
+    const int rows16 = (rows + 15) & ~15, nb4 = ng * 4;
+    if (idx >= (long)rows16 * nb4) return;
+    const int row = (int)(idx / nb4), pb = (int)(idx % nb4);
+    uint8_t* tile = dst + ((size_t)(row >> 4) * ng + (pb >> 2)) * TILE_BYTES;
+    const int l = (row & 15) + 16 * (pb & 3);
     uint16_t h[17];
-    if (pb < nb) {
+    if (row < rows && pb < nb) {
         const uint16_t* s = reinterpret_cast<const uint16_t*>(src + ((size_t)(r0 + row) * nb_full + b0 + pb) * 34);
 #pragma unroll
         for (int i = 0; i < 17; ++i) h[i] = s[i];
@@ -451,9 +449,9 @@ __global__ void repack_q8_kernel(const uint8_t* __restrict__ src, uint8_t* __res
 #pragma unroll
         for (int i = 0; i < 17; ++i) h[i] = 0;
     }
-    *reinterpret_cast<uint16_t*>(base + 2 * bl) = h[0];
-    uint16_t* lo = reinterpret_cast<uint16_t*>(base + 2 * n + 16 * bl);
-    uint16_t* hi = reinterpret_cast<uint16_t*>(base + 18 * n + 16 * bl);
+    *reinterpret_cast<uint16_t*>(tile + 2 * l) = h[0];
+    uint16_t* lo = reinterpret_cast<uint16_t*>(tile + 128 + 16 * l);
+    uint16_t* hi = reinterpret_cast<uint16_t*>(tile + 1152 + 16 * l);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { lo[i] = h[1 + i]; hi[i] = h[9 + i]; }
 }

@@ -126,6 +126,11 @@ class HipMasterPlan:
         hip.check(hip.lib().gl3_get_kv(self._ctx, layer, pos, _p(k), _p(v)), self._ctx)
         return k, v
 
+    def buffer(self, which: int, n: int):
+        out = np.empty(n, np.float32)
+        hip.check(hip.lib().gl3_get_buffer(self._ctx, which, _p(out), n), self._ctx)
+        return out
+
     def reset_kv(self):
         hip.check(hip.lib().gl3_reset_kv(self._ctx), self._ctx)
 

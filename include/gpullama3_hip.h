@@ -158,6 +158,10 @@ GL3_API int32_t gl3_get_x(gl3_ctx* ctx, float* out /* f32[dim] */);
 GL3_API int32_t gl3_get_layer_x(gl3_ctx* ctx, int32_t layer, float* out /* f32[dim], needs GL3_FLAG_LAYER_TAPS */);
 GL3_API int32_t gl3_get_kv(gl3_ctx* ctx, int32_t layer, int32_t position, float* k_out, float* v_out /* f32[kvDim/tp] */);
 
+/* Debug/parity tap: copy a scratch buffer of the LAST executed layer to the host.
+ * which: 0 = raw q|k|v of the qkv projection, 1 = attention output xb, 2 = hb (SwiGLU output), 3 = logits. */
+GL3_API int32_t gl3_get_buffer(gl3_ctx* ctx, int32_t which, float* out, uint64_t n_floats);
+
 GL3_API int32_t gl3_reset_kv(gl3_ctx* ctx);
 
 /* One decode step launched kernel by kernel with HIP events around every launch. */

@@ -1,9 +1,10 @@
 """Parity of the HIP decode path (through the C-ABI) against the CPU oracle and the golden fixtures.
 
-Tolerance (BASELINE.json north_star): logits / per-layer activations within 1e-3 relative
-(max |a-b| / max |b|), greedy token ids identical.  Only the order of f32 reductions differs from the
-oracle, so the observed error is ~1e-6; the asserted bound is the north-star 1e-3, and a much tighter
-5e-5 bound is asserted on the tiny fixtures to catch real bugs.
+Bar: BIT-EXACT.  BASELINE.json's north star asks for logits within 1e-3 relative and identical greedy ids;
+because the reference re-quantises activations to int8 before every matmul, a 1-ulp difference in any f32
+reduction grows to ~1e-2 in the logits (measured), so the HIP kernels evaluate every reduction in
+the reference's order and the tests assert exact equality of logits, per-layer activations and the KV cache
+(np.array_equal on f32), which implies both north-star conditions.
 """
 import os
 
@@ -14,7 +15,6 @@ import __graft_entry__ as ge
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-TOL = 1e-3
 
 
 def rel(a, b):
@@ -36,19 +36,15 @@ def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed):
     plan = plan_mod.HipMasterPlan(m, flags=hip.FLAG_LAYER_TAPS)
     toks = g["tokens"]
     n_prompt = len(g["prompt"])
-    worst = 0.0
     for pos in range(g["logits"].shape[0]):
         lg = plan.tornadoVMForwardDecode(int(toks[pos]), pos)
-        e = rel(lg, g["logits"][pos])
-        worst = max(worst, e)
-        assert e < TOL, (pos, e)
+        assert np.array_equal(lg, g["logits"][pos]), (pos, rel(lg, g["logits"][pos]))
         if pos >= n_prompt - 1:
             assert int(np.argmax(lg)) == toks[pos + 1], pos          # greedy ids identical
-    assert worst < 5e-5, worst
     for l in range(m.cfg.n_layers):
-        assert rel(plan.layer_x(l), g["last_layer_x"][l]) < TOL
+        assert np.array_equal(plan.layer_x(l), g["last_layer_x"][l])
         k, v = plan.kv(l, g["logits"].shape[0] - 1)
-        assert rel(k, g["k_last"][l]) < TOL and rel(v, g["v_last"][l]) < TOL
+        assert np.array_equal(k, g["k_last"][l]) and np.array_equal(v, g["v_last"][l])
     plan.freeTornadoExecutionPlan()
 
 
@@ -63,10 +59,10 @@ def test_decode_matches_c_oracle_live(pkg, orc, planmod, cfg):
     for pos, t in enumerate(toks):
         ref, lx = o.forward(t, pos, layer_x=True)
         got = plan.tornadoVMForwardDecode(t, pos)
-        assert rel(got, ref) < TOL, (pos, rel(got, ref))
+        assert np.array_equal(got, ref), (pos, rel(got, ref))
         for l in range(m.cfg.n_layers):
-            assert rel(plan.layer_x(l), lx[l]) < TOL
-        assert plan.forward_decode_argmax(t, pos) == orc.argmax(got)     # device argmax = first max of ITS logits
+            assert np.array_equal(plan.layer_x(l), lx[l])
+        assert plan.forward_decode_argmax(t, pos) == orc.argmax(ref)     # device argmax = first index of the max
     plan.freeTornadoExecutionPlan()
 
 
@@ -91,7 +87,7 @@ def test_sequential_prefill_then_decode(pkg, orc, planmod):
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 12)
     plan.prefill(toks[:11], 0)
     o.prefill(toks[:11], 0)
-    assert rel(plan.tornadoVMForwardDecode(toks[11], 11), o.forward(toks[11], 11)) < TOL
+    assert np.array_equal(plan.tornadoVMForwardDecode(toks[11], 11), o.forward(toks[11], 11))
     plan.freeTornadoExecutionPlan()
 
 
