@@ -36,7 +36,7 @@ static bool env_flag(const char* name, bool dflt) {
 // ------------------------------------------------------------------------------------------------ matvec launch
 static size_t matvec_smem(int pro, int epi, const Q8Mat& w) {
     const int nm = epi == EPI_SWIGLU ? 2 : 1;
-    return (size_t)w.ng * 4 * 32 + (size_t)w.ng * 4 * 4 + (pro == PRO_RMS ? (size_t)w.k * 4 : 0) + (size_t)2 * nm * w.ng * 64 * 4 + 64;
+    return (size_t)w.ng * 4 * 32 + (size_t)w.ng * 4 * 4 + (pro == PRO_RMS ? (size_t)(w.k + 32) * 4 : 0) + (size_t)2 * nm * w.ng * 64 * 4 + 64;
 }
 
 template <int PRO, int EPI>
@@ -56,7 +56,7 @@ static hipError_t allow_big_lds() {
 static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const Q8Mat* w2, const float* x,
                           const float* norm_w, float* out, const float* resid_in) {
     static const bool nt = env_flag("GL3_NT", true);
-    static const int max_wgs = getenv("GL3_WGS") ? atoi(getenv("GL3_WGS")) : 1024;
+    static const int max_wgs = getenv("GL3_WGS") ? atoi(getenv("GL3_WGS")) : 512;   // 2 resident workgroups per CU
     MatvecArgs a{};
     a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.k = w.k; a.ng = w.ng; a.nstrips = w.nstrips;
     a.x = x; a.norm_w = norm_w; a.eps = ctx->d.rms_eps; a.out = out; a.resid_in = resid_in;
@@ -180,7 +180,30 @@ static int32_t alloc_mat(gl3_ctx* ctx, Q8Mat& m, int rows, int k) {
     return GL3_OK;
 }
 
+__global__ __launch_bounds__(256) void debug_sumsq_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float* xf = reinterpret_cast<float*>(smem);
+    uint8_t* scratch = smem + (size_t)(n + 32) * 4;
+    for (int i = threadIdx.x; i < n + 32; i += 256) xf[i] = i < n ? x[i] : 0.f;
+    __syncthreads();
+    BlockBarrier bb;
+    const float s = exact_sumsq_lds(xf, n, scratch, threadIdx.x, bb);
+    if (threadIdx.x == 0) *out = s;
+}
+
 extern "C" {
+
+int32_t gl3_debug_sumsq(int32_t device, const float* x, int32_t n, float* out) {
+    if (!x || !out || n < 1024 || n > 5120 || (n & 3)) return GL3_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return GL3_E_HIP;
+    float *dx = nullptr, *dout = nullptr;
+    if (hipMalloc((void**)&dx, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&dout, 4) != hipSuccess) return GL3_E_OOM;
+    hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(debug_sumsq_kernel, dim3(1), dim3(256), (size_t)(n + 32) * 4 + SS_SCRATCH_BYTES, 0, dx, n, dout);
+    const hipError_t e = hipMemcpy(out, dout, 4, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dout);
+    return e == hipSuccess ? GL3_OK : GL3_E_HIP;
+}
 
 const char* gl3_version(void) { return "gpullama3-hip 0.1 (gfx950)"; }
 
@@ -504,6 +527,52 @@ int32_t gl3_profile_decode(gl3_ctx* ctx, int32_t token, int32_t pos, gl3_kernel_
     int32_t r = set_dyn(ctx, token, pos);
     if (r != GL3_OK) return r;
     return enqueue_decode(ctx, true, out);
+}
+
+int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* out_us, uint64_t* bytes_per_launch) {
+    if (!ctx || !out_us || iters <= 0) return GL3_E_ARG;
+    if (!ctx->finalized) GL3_FAIL(GL3_E_STATE, "profile before gl3_finalize");
+    if (klass < GL3_K_MATVEC_QKV || klass > GL3_K_MATVEC_LOGITS) GL3_FAIL(GL3_E_ARG, "only matvec classes can be profiled");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    const gl3_model_desc& d = ctx->d;
+    const int rank = d.tp_rank;
+    hipEvent_t e0, e1;
+    GL3_HIP(hipEventCreate(&e0)); GL3_HIP(hipEventCreate(&e1));
+    auto sweep = [&]() {
+        const int nl = klass == GL3_K_MATVEC_LOGITS ? 1 : d.n_layers;
+        for (int l = 0; l < nl; ++l) {
+            gl3_layer& L = ctx->layers[l];
+            switch (klass) {
+            case GL3_K_MATVEC_QKV: launch_matvec(ctx, PRO_RMS, EPI_STORE, L.wqkv, nullptr, ctx->x, L.attn_norm, ctx->qkv, nullptr); break;
+            case GL3_K_MATVEC_WO: launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->qkv, nullptr); break;
+            case GL3_K_MATVEC_GATEUP: launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr); break;
+            case GL3_K_MATVEC_DOWN: launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->qkv, nullptr); break;
+            default: launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm, ctx->logits + (size_t)rank * ctx->vocab_l, nullptr); break;
+            }
+        }
+        return nl;
+    };
+    sweep();                                            // warm-up
+    GL3_HIP(hipEventRecord(e0, ctx->stream));
+    long n = 0;
+    for (int i = 0; i < iters; ++i) n += sweep();
+    GL3_HIP(hipEventRecord(e1, ctx->stream));
+    GL3_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    GL3_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *out_us = (double)ms * 1e3 / (double)n;
+    if (bytes_per_launch) {
+        const gl3_layer& L = ctx->layers[0];
+        switch (klass) {
+        case GL3_K_MATVEC_QKV: *bytes_per_launch = mv_bytes(L.wqkv) + d.dim * 4; break;
+        case GL3_K_MATVEC_WO: *bytes_per_launch = mv_bytes(L.wo); break;
+        case GL3_K_MATVEC_GATEUP: *bytes_per_launch = mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4; break;
+        case GL3_K_MATVEC_DOWN: *bytes_per_launch = mv_bytes(L.w2); break;
+        default: *bytes_per_launch = mv_bytes(ctx->wcls) + d.dim * 4; break;
+        }
+    }
+    return GL3_OK;
 }
 
 int32_t gl3_get_x(gl3_ctx* ctx, float* out) {

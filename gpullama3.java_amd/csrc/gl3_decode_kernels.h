@@ -29,16 +29,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gl3_seqsum.h"
+
 namespace gl3 {
 
 constexpr int TILE_BYTES = 2176;       // 64 Q8_0 blocks
 constexpr int MV_PRODUCERS = 4;        // wavefronts streaming weights
-constexpr int MV_THREADS = 64 * (MV_PRODUCERS + 1);   // + 1 wavefront running the ordered sums on the MFMA pipe
+constexpr int MV_AUX = 4;               // wavefronts running the prologue; the first one then runs the ordered sums
+constexpr int MV_THREADS = 64 * (MV_PRODUCERS + MV_AUX);
 
 enum { PRO_RMS = 0, PRO_QUANT = 1 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+
+#ifdef GL3_MV_TIMING
+__device__ long long gl3_mv_stamp[32];
+#define MV_STAMP(i, cond) do { if (blockIdx.x == 0 && (cond)) gl3_mv_stamp[i] = clock64(); } while (0)
+#else
+#define MV_STAMP(i, cond)
+#endif
 
 struct MatvecArgs {
     const uint8_t* w;        // Q8T tiles
@@ -122,123 +132,205 @@ __device__ __forceinline__ uint16_t ld2(const uint8_t* p) {
 
 // ---------------------------------------------------------------------------------------------------
 // Dequant-fused Q8_0 matvec, bit-exact to FloatTensor.matmul + dotQ8Activation.
-// Workgroup = 4 producer wavefronts + 1 chain wavefront.  Per 16-row strip the producers stream the strip's
-// tiles (lane = one 32-block of one row: 3 coalesced non-temporal loads, 8 v_dot4, p = isum*(wScale*aScale))
-// into a double-buffered LDS array; the chain wavefront then adds the p's of each row in block order with
-// v_mfma_f32_16x16x4_f32 (B = 1.0) while the producers already stream the next strip.
-//   LDS: xq[ng*128] | xs[ng*4] f32 | xf[k] f32 (PRO_RMS) | pbuf[2][NM][ng*64] f32 | red[4]
+// Workgroup = 8 wavefronts with three roles:
+//   producers (waves 0-3): stream the weight tiles of the workgroup's 16-row strips (lane = one 32-block of one
+//       row: 3 coalesced non-temporal loads, 8 v_dot4, p = isum*(wScale*aScale)) into a double-buffered LDS
+//       array.  Their first loads are issued BEFORE the activation is ready, so HBM latency hides the prologue;
+//   aux (waves 4-7): the prologue — RMSNorm with the exact in-order sum of squares (gl3_seqsum.h) and the
+//       Q8_0 activation quantisation into LDS; waves 5-7 then retire;
+//   chain (wave 4): adds the p's of each row in block order with v_mfma_f32_16x16x4_f32 (B = 1.0) and applies
+//       the epilogue while the producers already stream the next strip.
+// Register pressure is the maximum of the roles, not their sum (wave-uniform branches).
+//   LDS: xq[ng*128] | xs[ng*4] f32 | xf[k + 32] f32 (PRO_RMS) | pbuf[2][NM][ng*64] f32 | red[4] | sync[4]
 template <int PRO, int EPI, bool NT>
-__global__ __launch_bounds__(MV_THREADS) void matvec_q8t_kernel(const MatvecArgs a) {
+__global__ __launch_bounds__(MV_THREADS, 4) void matvec_q8t_kernel(const MatvecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int CH = (NM == 1) ? 8 : 4;             // tiles in flight per producer wave
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nb4 = a.ng * 4;
     uint8_t* xq = smem;
     float* xs = reinterpret_cast<float*>(smem + (size_t)nb4 * 32);
     float* xf = xs + nb4;
-    float* pbuf = xf + (PRO == PRO_RMS ? a.k : 0);
-    float* red = pbuf + (size_t)2 * NM * a.ng * 64;
+    float* pbuf = xf + (PRO == PRO_RMS ? a.k + 32 : 0);     // 32 zero floats pad xf for exact_sumsq_lds
+    float* red = pbuf + (size_t)2 * NM * a.ng * 64;         // [0] plain-chain result
+    int* sync_w = reinterpret_cast<int*>(red + 4);          // [0] aux sub-barrier counter, [1] activation-ready flag
+    const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
+    MV_STAMP(0, t == 0);
+    if (t < 2) sync_w[t] = 0;
 
-    // ---- prologue: (RMSNorm) + activation quantisation, identical in every workgroup
+    if (wave < MV_PRODUCERS) {
+        // ------------------------------------------------------------------ producers
+        const int nt = (a.ng - wave + MV_PRODUCERS - 1) / MV_PRODUCERS;      // tiles g = wave + 4*i of a strip
+        uint16_t sc[NM][CH];
+        int4 lo[NM][CH], hi[NM][CH];
+        auto issue = [&](int strip, int i0) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                if (i0 + u < nt) {
+                    const int g = wave + (i0 + u) * MV_PRODUCERS;
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        const uint8_t* p = (m == 0 ? a.w : a.w2) + (size_t)strip * strip_bytes + (size_t)g * TILE_BYTES;
+                        sc[m][u] = ld2<NT>(p + 2 * lane);
+                        lo[m][u] = ld16<NT>(p + 128 + 16 * lane);
+                        hi[m][u] = ld16<NT>(p + 1152 + 16 * lane);
+                    }
+                }
+            }
+        };
+        auto compute = [&](int i0, float* pb) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                if (i0 + u < nt) {
+                    const int g = wave + (i0 + u) * MV_PRODUCERS;
+                    const int xb = 4 * g + (lane >> 4);
+                    const int4 xlo = *reinterpret_cast<const int4*>(xq + 32 * xb);
+                    const int4 xhi = *reinterpret_cast<const int4*>(xq + 32 * xb + 16);
+                    const float xsc = xs[xb];
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        const int isum = dot32(lo[m][u], hi[m][u], xlo, xhi);
+                        pb[(size_t)m * a.ng * 64 + g * 64 + lane] = (float)isum * (h2f(sc[m][u]) * xsc);
+                    }
+                }
+            }
+        };
+        int strip = blockIdx.x;
+        __syncthreads();                                         // the only prologue barrier the producers join
+        if (strip < a.nstrips) issue(strip, 0);                  // HBM latency hides the activation prologue
+        while (__hip_atomic_load(&sync_w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        MV_STAMP(3, t == 0);
+        int it = 0;
+        for (; strip < a.nstrips; strip += gridDim.x, ++it) {
+            float* pb = pbuf + (size_t)(it & 1) * NM * a.ng * 64;
+            for (int i0 = 0; i0 < nt; i0 += CH) {
+                if (it != 0 || i0 != 0) issue(strip, i0);
+                compute(i0, pb);
+            }
+            MV_STAMP(4 + 2 * it, t == 0 && it < 4);
+            __syncthreads();
+            MV_STAMP(5 + 2 * it, t == 0 && it < 4);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- aux waves: prologue
+    const int ta = t - 64 * MV_PRODUCERS;                // 0..255
     const int nquads = a.k >> 2;
     float scale = 1.0f;
-    if (PRO == PRO_RMS) {
-        for (int qd = t; qd < nquads; qd += MV_THREADS)
-            *reinterpret_cast<float4*>(xf + 4 * qd) = *reinterpret_cast<const float4*>(a.x + 4 * qd);
-        __syncthreads();
-        if (wave == MV_PRODUCERS) {                  // InferenceCore.rmsnorm :41 — strict left-to-right sum
-            const float ss = seq_sum_lds<true>(xf, a.k);
-            if (lane == 0) red[0] = ss;
+    constexpr int NXV = (PRO == PRO_RMS) ? 5 : 14;       // quads of the activation held in registers per aux thread
+    float4 nwv[5], xv[NXV];                              // this thread's RMSNorm weights and activations
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+        const int qd = ta + 256 * i;
+        if (qd < nquads) {
+            xv[i] = *reinterpret_cast<const float4*>(a.x + 4 * qd);
+            if (PRO == PRO_RMS) nwv[i] = *reinterpret_cast<const float4*>(a.norm_w + 4 * qd);
         }
-        __syncthreads();
-        float ss = red[0];
+    }
+    __syncthreads();                                     // activation loads are queued ahead of the weight stream
+    SubBarrier aux_sync{&sync_w[0], MV_AUX, 0};
+    if (PRO == PRO_RMS) {
+        if (nquads <= NXV * 256) {
+#pragma unroll
+            for (int i = 0; i < NXV; ++i) { const int qd = ta + 256 * i; if (qd < nquads) *reinterpret_cast<float4*>(xf + 4 * qd) = xv[i]; }
+        } else {
+            for (int qd = ta; qd < nquads; qd += 256)
+                *reinterpret_cast<float4*>(xf + 4 * qd) = *reinterpret_cast<const float4*>(a.x + 4 * qd);
+        }
+        if (ta < 32) xf[a.k + ta] = 0.f;
+        aux_sync();
+        MV_STAMP(1, ta == 0);
+        // InferenceCore.rmsnorm :41 — the strict left-to-right sum of squares, evaluated exactly in parallel
+        // (gl3_seqsum.h); pbuf is free during the prologue and serves as its scratch.
+        float ss;
+        if ((size_t)2 * NM * a.ng * 64 * 4 >= SS_SCRATCH_BYTES && a.k >= 1024 && a.k <= 5120) {
+            ss = exact_sumsq_lds(xf, a.k, reinterpret_cast<uint8_t*>(pbuf), ta, aux_sync);
+        } else {
+            if (wave == MV_PRODUCERS) {
+                const float s1 = seq_sum_lds<true>(xf, a.k);
+                if (lane == 0) red[0] = s1;
+            }
+            aux_sync();
+            ss = red[0];
+        }
+        MV_STAMP(2, ta == 0);
         ss /= (float)a.k;
         ss += a.eps;
         scale = (float)(1.0 / sqrt((double)ss));
     }
-    for (int b = (a.k >> 5) + t; b < nb4; b += MV_THREADS) {   // zero-padded blocks
+    for (int b = (a.k >> 5) + ta; b < nb4; b += 256) {   // zero-padded blocks
         xs[b] = 0.f;
         const int4 z = {0, 0, 0, 0};
         *reinterpret_cast<int4*>(xq + 32 * b) = z;
         *reinterpret_cast<int4*>(xq + 32 * b + 16) = z;
     }
-    for (int qd = t; qd < nquads; qd += MV_THREADS) {
-        float4 v;
-        if (PRO == PRO_RMS) {
-            v = *reinterpret_cast<const float4*>(xf + 4 * qd);
-            const float4 w = *reinterpret_cast<const float4*>(a.norm_w + 4 * qd);
-            v.x = w.x * (scale * v.x); v.y = w.y * (scale * v.y); v.z = w.z * (scale * v.z); v.w = w.w * (scale * v.w);
-        } else {
-            v = *reinterpret_cast<const float4*>(a.x + 4 * qd);
-        }
-        quantize_quad(v, qd, xq, xs);
-    }
-    __syncthreads();
-
-    // ---- main loop over this workgroup's strips
-    const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
-    int it = 0;
-    if (wave < MV_PRODUCERS) {
-        for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x, ++it) {
-            float* pb = pbuf + (size_t)(it & 1) * NM * a.ng * 64;
-            for (int g0 = wave; g0 < a.ng; g0 += MV_PRODUCERS * 4) {
-                uint16_t sc[NM][4];
-                int4 lo[NM][4], hi[NM][4];
+    if (nquads <= NXV * 256) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int g = g0 + u * MV_PRODUCERS;
-                    if (g < a.ng) {
-#pragma unroll
-                        for (int m = 0; m < NM; ++m) {
-                            const uint8_t* p = (m == 0 ? a.w : a.w2) + (size_t)strip * strip_bytes + (size_t)g * TILE_BYTES;
-                            sc[m][u] = ld2<NT>(p + 2 * lane);
-                            lo[m][u] = ld16<NT>(p + 128 + 16 * lane);
-                            hi[m][u] = ld16<NT>(p + 1152 + 16 * lane);
-                        }
-                    }
+        for (int i = 0; i < NXV; ++i) {
+            const int qd = ta + 256 * i;
+            if (qd < nquads) {
+                float4 v = xv[i];
+                if (PRO == PRO_RMS) {
+                    const float4 w = nwv[i];
+                    v.x = w.x * (scale * v.x); v.y = w.y * (scale * v.y); v.z = w.z * (scale * v.z); v.w = w.w * (scale * v.w);
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int g = g0 + u * MV_PRODUCERS;
-                    if (g < a.ng) {
-                        const int xb = 4 * g + (lane >> 4);
-                        const int4 xlo = *reinterpret_cast<const int4*>(xq + 32 * xb);
-                        const int4 xhi = *reinterpret_cast<const int4*>(xq + 32 * xb + 16);
-                        const float xsc = xs[xb];
-#pragma unroll
-                        for (int m = 0; m < NM; ++m) {
-                            const int isum = dot32(lo[m][u], hi[m][u], xlo, xhi);
-                            pb[(size_t)m * a.ng * 64 + g * 64 + lane] = (float)isum * (h2f(sc[m][u]) * xsc);
-                        }
-                    }
-                }
+                quantize_quad(v, qd, xq, xs);
             }
-            __syncthreads();
         }
     } else {
-        for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x, ++it) {
-            __syncthreads();
-            const float* pb = pbuf + (size_t)(it & 1) * NM * a.ng * 64;
-            v4f acc[NM];
-#pragma unroll
-            for (int m = 0; m < NM; ++m) acc[m] = (v4f){0.f, 0.f, 0.f, 0.f};
-            for (int g = 0; g < a.ng; ++g) {          // result += p_b, b ascending: 4 blocks x 16 rows per MFMA
-#pragma unroll
-                for (int m = 0; m < NM; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[(size_t)m * a.ng * 64 + g * 64 + lane], 1.0f, acc[m], 0, 0, 0);
+        for (int qd = ta; qd < nquads; qd += 256) {
+            float4 v = *reinterpret_cast<const float4*>(a.x + 4 * qd);
+            if (PRO == PRO_RMS) {
+                const float4 w = *reinterpret_cast<const float4*>(a.norm_w + 4 * qd);
+                v.x = w.x * (scale * v.x); v.y = w.y * (scale * v.y); v.z = w.z * (scale * v.z); v.w = w.w * (scale * v.w);
             }
-            if ((lane & 15) == 0) {                   // D[i][j]: row i = 4*(lane>>4) + reg, all 16 columns identical
+            quantize_quad(v, qd, xq, xs);
+        }
+    }
+    aux_sync();                                          // xq / xs complete
+    if (ta == 0) __hip_atomic_store(&sync_w[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (wave != MV_PRODUCERS) return;                    // waves 5-7 retire; wave 4 becomes the chain wavefront
+
+    // ---------------------------------------------------------------------- chain wavefront
+    int it = 0;
+    for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x, ++it) {
+        __syncthreads();
+        MV_STAMP(16 + 2 * it, lane == 0 && it < 4);
+        const float* pb = pbuf + (size_t)(it & 1) * NM * a.ng * 64;
+        v4f acc[NM];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = strip * 16 + 4 * (lane >> 4) + r;
-                    if (row < a.rows) {
-                        if (EPI == EPI_STORE) a.out[row] = acc[0][r];
-                        if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + acc[0][r] : acc[0][r];
-                        if (EPI == EPI_SWIGLU) {      // InferenceCore.java:155-158, exp in double
-                            float gte = acc[0][r];
-                            gte = gte / (float)(1.0 + exp(-(double)gte));
-                            a.out[row] = gte * acc[NM - 1][r];
-                        }
+        for (int m = 0; m < NM; ++m) acc[m] = (v4f){0.f, 0.f, 0.f, 0.f};
+        int g = 0;
+        for (; g + 8 <= a.ng; g += 8) {               // result += p_b, b ascending: 4 blocks x 16 rows per MFMA
+            float av[NM][8];
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) av[m][u] = pb[(size_t)m * a.ng * 64 + (g + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int m = 0; m < NM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][u], 1.0f, acc[m], 0, 0, 0);
+        }
+        for (; g < a.ng; ++g)
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[(size_t)m * a.ng * 64 + g * 64 + lane], 1.0f, acc[m], 0, 0, 0);
+        MV_STAMP(17 + 2 * it, lane == 0 && it < 4);
+        if ((lane & 15) == 0) {                       // D[i][j]: row i = 4*(lane>>4) + reg, all 16 columns identical
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = strip * 16 + 4 * (lane >> 4) + r;
+                if (row < a.rows) {
+                    if (EPI == EPI_STORE) a.out[row] = acc[0][r];
+                    if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + acc[0][r] : acc[0][r];
+                    if (EPI == EPI_SWIGLU) {          // InferenceCore.java:155-158, exp in double
+                        float gte = acc[0][r];
+                        gte = gte / (float)(1.0 + exp(-(double)gte));
+                        a.out[row] = gte * acc[NM - 1][r];
                     }
                 }
             }

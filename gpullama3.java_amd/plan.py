@@ -139,6 +139,12 @@ class HipMasterPlan:
         hip.check(hip.lib().gl3_profile_decode(self._ctx, token, position, C.byref(kt)), self._ctx)
         return {n: dict(ms=kt.ms[i], launches=kt.launches[i], bytes=kt.bytes[i]) for i, n in enumerate(hip.K_NAMES)}
 
+    def profile_kernel(self, klass: str, iters: int = 10) -> dict:
+        """One kernel class, back-to-back over every layer's weights, one HIP event pair (see gl3_profile_kernel)."""
+        us, nb = C.c_double(), C.c_uint64()
+        hip.check(hip.lib().gl3_profile_kernel(self._ctx, hip.K_NAMES.index(klass), iters, C.byref(us), C.byref(nb)), self._ctx)
+        return dict(avg_us=us.value, bytes_per_launch=nb.value, gbs=nb.value / us.value / 1e3)
+
     def init_ms(self):
         a, b = C.c_double(), C.c_double()
         hip.check(hip.lib().gl3_get_init_ms(self._ctx, C.byref(a), C.byref(b)), self._ctx)

@@ -162,10 +162,19 @@ GL3_API int32_t gl3_get_kv(gl3_ctx* ctx, int32_t layer, int32_t position, float*
  * which: 0 = raw q|k|v of the qkv projection, 1 = attention output xb, 2 = hb (SwiGLU output), 3 = logits. */
 GL3_API int32_t gl3_get_buffer(gl3_ctx* ctx, int32_t which, float* out, uint64_t n_floats);
 
+/* Test hook: the strictly sequential f32 sum of squares of x[0..n) (InferenceCore.rmsnorm's reduce), evaluated
+ * by the same exact parallel device routine the kernels use (1024 <= n <= 5120, multiple of 4; device = ordinal). */
+GL3_API int32_t gl3_debug_sumsq(int32_t device, const float* x, int32_t n, float* out);
+
 GL3_API int32_t gl3_reset_kv(gl3_ctx* ctx);
 
 /* One decode step launched kernel by kernel with HIP events around every launch. */
 GL3_API int32_t gl3_profile_decode(gl3_ctx* ctx, int32_t token, int32_t position, gl3_kernel_times* out);
+
+/* Average device time of ONE kernel class, measured with a single HIP event pair around `iters` sweeps over all
+ * layers (back-to-back launches of that kernel on every layer's own weights, so nothing is cache-resident).
+ * klass: GL3_K_MATVEC_*; out_us = mean per launch (includes the ~1.5 us inter-kernel boundary). */
+GL3_API int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* out_us, uint64_t* bytes_per_launch);
 
 /* RunMetrics slots (TornadoVMMasterPlanSingleToken.java:40-54): plan creation and weight copy-in, ms. */
 GL3_API int32_t gl3_get_init_ms(gl3_ctx* ctx, double* plan_ms, double* copy_in_ms);
