@@ -162,6 +162,19 @@ def main():
                     traffic=None, avg_us=dom["avg_us"], bytes_per_launch=dom["bytes_per_launch"],
                     method="HIP event pair around 20 sweeps x %d layers of back-to-back launches on the plan's stream" % cfg.n_layers)
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read in-process; take the FETCH_SIZE figure of the
+    # committed rocprofv3 --pmc pass of this same command (profiles/rNN_pmc_fetch_summary.csv, x2 gfx950 correction)
+    try:
+        import csv
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_summary.csv")))[-1]
+        for r in csv.reader(open(f)):
+            if "matvec_q8t_kernel<0, 2" in r[0] and world == 1 and args.model == "llama-3-8b":
+                roofline["traffic"] = int(r[-1])
+                roofline["traffic_source"] = os.path.relpath(f, ROOT) + " (FETCH_SIZE, separate rocprofv3 --pmc pass)"
+    except Exception:
+        pass
+
     # whole-token algorithmic bytes: weights + norms + KV read/write + logits
     L, kvd = cfg.n_layers, cfg.kv_dim
     mat_elems = L * (cfg.q_dim * cfg.dim + 2 * kvd * cfg.dim + cfg.dim * cfg.q_dim + 3 * cfg.hidden * cfg.dim) + cfg.vocab * cfg.dim
