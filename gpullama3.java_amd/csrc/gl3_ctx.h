@@ -15,7 +15,7 @@ struct Q8Mat {               // one repacked (Q8T) matrix, see gl3_decode_kernel
     int rows = 0, k = 0;
     int ng = 0;              // tile groups per strip = ceil(k/32 / 4)
     int nstrips = 0;         // ceil(rows / 16)
-    size_t bytes() const { return (size_t)nstrips * ng * 2176; }
+    size_t bytes() const { return (size_t)(nstrips + (nstrips & 1)) * ng * 2176; }   // even #strips: the prefill GEMM reads 32-row groups
     size_t algo_bytes() const { return (size_t)rows * (k / 32) * 34; }   // GGUF bytes (no padding)
 };
 

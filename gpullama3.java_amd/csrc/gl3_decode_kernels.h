@@ -341,7 +341,7 @@ __global__ __launch_bounds__(MV_THREADS, 4) void matvec_q8t_kernel(const MatvecA
 // ---------------------------------------------------------------------------------------------------
 // Embedding row gather + dequant: x[i] = q * d  (token_embedding_table.copyTo, InferenceCore.java:61;
 // replaces the host row copy of forwardTornadoVM :956-980 + convertQ8_0toFP32).
-__global__ __launch_bounds__(256) void embed_q8t_kernel(const uint8_t* __restrict__ emb, int ng, int dim,
+static __global__ __launch_bounds__(256) void embed_q8t_kernel(const uint8_t* __restrict__ emb, int ng, int dim,
                                                          const int* __restrict__ dyn, float* __restrict__ x) {
     const int token = dyn[0];
     const uint8_t* strip = emb + (size_t)(token >> 4) * ng * TILE_BYTES;
@@ -401,7 +401,7 @@ __device__ __forceinline__ void head_rmsnorm_1t(float* v, const float* w, int hs
 
 constexpr int ATT_TT = 64;   // timesteps per score workgroup
 
-__global__ void attn_scores_kernel(const AttnArgs a) {
+static __global__ void attn_scores_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads;
     float* q_s = sm;                         // [kvmul][hs]
@@ -458,7 +458,7 @@ __global__ void attn_scores_kernel(const AttnArgs a) {
 // Decode attention, part 2: softmax + weighted V sum.   Grid = n_heads x ceil(hs/64), block = 64.
 //   FloatTensor.softmaxInPlace :211-219 (max, exp in double, strict sum, divide); saxpyInPlace :221-227 with
 //   t ascending: xb[j] = a_t * v[t][j] + xb[j].  Dynamic LDS: e[ctx].
-__global__ __launch_bounds__(64) void attn_softmax_pv_kernel(const AttnArgs a) {
+static __global__ __launch_bounds__(64) void attn_softmax_pv_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float e_s[];
     const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads;
     const int nj = (hs + 63) / 64;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64) void attn_softmax_pv_kernel(const AttnArgs a) {
 // Greedy sampling on the device: first index of the maximum (strict >), FloatTensor.argmax
 // J/tensor/standard/FloatTensor.java:138-151 — NOT the strided-scan tie-break of the reference's
 // argmaxLogits (TransformerComputeKernels.java:25-59).
-__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ v, int n, int* __restrict__ out) {
+static __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ v, int n, int* __restrict__ out) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     const int t = threadIdx.x;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 // One-time layout transform at upload: GGUF Q8_0 blocks (34 B: f16 d + 32 x int8, GGMLType.java:13) of rows
 // [r0, r0+rows) and blocks [b0, b0+nb) of a [*, nb_full*32] matrix -> Q8T tiles.  One thread per destination
 // (row, block) slot incl. zero padding (rows -> x16, blocks -> x4).
-__global__ void repack_q8t_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int nb, int ng,
+static __global__ void repack_q8t_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int nb, int ng,
                                   long r0, int b0, int nb_full) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int rows16 = (rows + 15) & ~15, nb4 = ng * 4;

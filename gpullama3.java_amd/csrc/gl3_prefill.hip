@@ -1,8 +1,401 @@
-// gl3_prefill.hip — batched prefill (placeholder until the MFMA path lands in this file).
+// gl3_prefill.hip — batched prefill (gl3_forward_prefill with max_batch > 1).
+//
+// Replaces the reference's batched-prefill task graphs
+//   J/tornadovm/layers/type/q8_0/prefill/LlamaQ8_0LayersBatchPrefillMMA.java:84-219 (tensor-core path, CUDA only) and
+//   ...LlamaQ8_0LayersBatchPrefill.java (scalar path), kernels in J/tornadovm/kernels/TransformerBatchPrefillKernels.java
+// but computes what the CPU path computes, bit for bit: InferenceCoreBatchPrefillDecode.batchForwardJavaPrefill
+// (J/inference/InferenceCoreBatchPrefillDecode.java:62-168) = per token exactly forwardJava without the logits.
+// The reference's MMA path is W8A16 (f16 activations); the CPU oracle is W8A8 with per-32-block int8 activations
+// (Q8_0FloatTensor.java:90-123), and that is what the GEMM below does on CDNA4's int8 matrix cores:
+//   one v_mfma_i32_32x32x32_i8 = the int32 dot of one Q8_0 block for a 32-row x 32-token tile (exact), then
+//   acc = acc + float(isum) * (wScale * aScale) on the VALU, blocks ascending — the reference's f32 order.
 #include "gl3_ctx.h"
+#include "gl3_decode_kernels.h"
 
-struct gl3_prefill_state { int unused; };
+using namespace gl3;
 
-int32_t gl3_prefill_alloc(gl3_ctx* ctx) { (void)ctx; return GL3_OK; }
-void gl3_prefill_free(gl3_ctx* ctx) { (void)ctx; }
-int32_t gl3_prefill_run(gl3_ctx* ctx, const int32_t*, int32_t, int32_t) { GL3_FAIL(GL3_E_UNSUPPORTED, "batched prefill not built"); }
+struct gl3_prefill_state {
+    int max_batch = 0;
+    int32_t* tokens = nullptr;          // [M]
+    float* X = nullptr;                 // [M][dim] residual stream
+    uint8_t* XQ = nullptr;              // [M][maxk] int8 activations
+    float* XS = nullptr;                // [M][maxk/32] activation scales
+    float* QKV = nullptr;               // [M][q_dim + 2 kv_dim]
+    float* AO = nullptr;                // [M][q_dim] attention output
+    float* HB = nullptr;                // [M][hidden]
+    float* ATT = nullptr;               // [M][n_heads][ctx] scores
+    int maxk = 0;
+};
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------
+// token_embedding_table.copyTo per token (batchForwardJavaPrefill :96)
+__global__ __launch_bounds__(256) void pf_embed_kernel(const uint8_t* __restrict__ emb, int ng, int dim,
+                                                        const int32_t* __restrict__ tokens, float* __restrict__ X) {
+    const int token = tokens[blockIdx.x];
+    const uint8_t* strip = emb + (size_t)(token >> 4) * ng * TILE_BYTES;
+    const int i16 = token & 15;
+    float* x = X + (size_t)blockIdx.x * dim;
+    for (int i = threadIdx.x; i < dim; i += 256) {
+        const int b = i >> 5, j = i & 31;
+        const uint8_t* p = strip + (size_t)(b >> 2) * TILE_BYTES;
+        const int l = i16 + 16 * (b & 3);
+        const float d = h2f(*reinterpret_cast<const uint16_t*>(p + 2 * l));
+        const int8_t q = (int8_t)p[(j < 16 ? 128 : 1152) + 16 * l + (j & 15)];
+        x[i] = (float)q * d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per token: (RMSNorm with the exact in-order sum of squares) + Q8_0 activation quantisation.
+// One workgroup of 256 threads per token.  NORM = false: plain quantisation of an f32 row.
+template <bool NORM>
+__global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restrict__ in, int k, int in_stride,
+                                                             const float* __restrict__ norm_w, float eps,
+                                                             uint8_t* __restrict__ XQ, float* __restrict__ XS, int maxk) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float* xf = reinterpret_cast<float*>(smem);                 // [k + 32]
+    uint8_t* scratch = smem + (size_t)(k + 32) * 4;             // SS_SCRATCH_BYTES
+    float* red = reinterpret_cast<float*>(scratch + SS_SCRATCH_BYTES);
+    const int t = threadIdx.x, b = blockIdx.x;
+    const float* x = in + (size_t)b * in_stride;
+    const int nquads = k >> 2;
+    float scale = 1.0f;
+    if (NORM) {
+        for (int qd = t; qd < nquads; qd += 256)
+            *reinterpret_cast<float4*>(xf + 4 * qd) = *reinterpret_cast<const float4*>(x + 4 * qd);
+        if (t < 32) xf[k + t] = 0.f;
+        __syncthreads();
+        float ss;
+        if (k >= 1024 && k <= 5120) {
+            BlockBarrier bb;
+            ss = exact_sumsq_lds(xf, k, scratch, t, bb);
+        } else {
+            if (t < 64) { const float s1 = seq_sum_lds<true>(xf, k); if (t == 0) red[0] = s1; }
+            __syncthreads();
+            ss = red[0];
+        }
+        ss /= (float)k;
+        ss += eps;
+        scale = (float)(1.0 / sqrt((double)ss));
+    }
+    uint8_t* xq = XQ + (size_t)b * maxk;
+    float* xs = XS + (size_t)b * (maxk >> 5);
+    for (int qd = t; qd < nquads; qd += 256) {
+        float4 v;
+        if (NORM) {
+            v = *reinterpret_cast<const float4*>(xf + 4 * qd);
+            const float4 w = *reinterpret_cast<const float4*>(norm_w + 4 * qd);
+            v.x = w.x * (scale * v.x); v.y = w.y * (scale * v.y); v.z = w.z * (scale * v.z); v.w = w.w * (scale * v.w);
+        } else {
+            v = *reinterpret_cast<const float4*>(x + 4 * qd);
+        }
+        quantize_quad(v, qd, xq, xs);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Batched Q8_0 matmul: out[b][n] = sum_blocks float(isum) * (wScale * aScale), blocks ascending
+// (FloatTensor.matmul(context, ...) :102-111 with dotQ8Activation).  Workgroup = 4 wavefronts = 32 weight rows x
+// 256 tokens; wavefront = 32 rows x 64 tokens = two 32x32 int8 MFMA tiles per Q8_0 block.
+// A operand (weights) and its 16 per-lane scales come straight from the Q8T tiles (L2), B operand from XQ.
+struct GemmArgs {
+    const uint8_t* w; const uint8_t* w2;  // Q8T matrices (w2: up projection for the SwiGLU epilogue)
+    int rows, ng, nb;                     // valid rows, tile groups per strip, real blocks per row (k/32)
+    const uint8_t* XQ; const float* XS; int maxk;
+    int ntok;
+    float* out; int out_stride;           // EPI_STORE / EPI_SWIGLU: out[b*stride + row]; EPI_RESID: out +=
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void pf_gemm_kernel(const GemmArgs a) {
+    constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tl = lane & 31, hi = lane >> 5;
+    const int rg = blockIdx.y;                         // 32-row group
+    const int tok0 = blockIdx.x * 256 + wave * 64;     // this wavefront's 64 tokens
+    if (tok0 >= a.ntok) return;
+    // A-fragment addressing: weight row rg*32 + tl, 16-byte half `hi` of block blk
+    const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
+    const uint8_t* wrow[NM];
+    const uint8_t* wsc[NM][4];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const uint8_t* base = (m == 0 ? a.w : a.w2) + (size_t)(rg * 2) * strip_bytes;
+        wrow[m] = base + (size_t)(tl >> 4) * strip_bytes + (hi ? 1152 : 128) + 16 * (tl & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)       // scales of rows 8q + 4hi + (0..3): 4 consecutive f16 in the tile's scale area
+            wsc[m][q] = base + (size_t)(q >> 1) * strip_bytes + 2 * (8 * (q & 1) + 4 * hi);
+    }
+    int tok[2];
+    const uint8_t* xq[2];
+    const float* xs[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        tok[tt] = min(a.ntok - 1, tok0 + 32 * tt + tl);
+        xq[tt] = a.XQ + (size_t)tok[tt] * a.maxk + 16 * hi;
+        xs[tt] = a.XS + (size_t)tok[tt] * (a.maxk >> 5);
+    }
+    float acc[NM][2][16];
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][tt][r] = 0.f;
+
+    for (int blk = 0; blk < a.nb; ++blk) {
+        const size_t toff = (size_t)(blk >> 2) * TILE_BYTES;
+        const int lsel = 16 * (blk & 3);
+        v4i_t bf[2];
+        float xsc[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            bf[tt] = *reinterpret_cast<const v4i_t*>(xq[tt] + 32 * blk);
+            xsc[tt] = xs[tt][blk];
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const v4i_t af = *reinterpret_cast<const v4i_t*>(wrow[m] + toff + 16 * lsel);
+            float wsf[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 s4 = *reinterpret_cast<const uint2*>(wsc[m][q] + toff + 2 * lsel);
+                wsf[4 * q + 0] = h2f((uint16_t)(s4.x & 0xFFFF)); wsf[4 * q + 1] = h2f((uint16_t)(s4.x >> 16));
+                wsf[4 * q + 2] = h2f((uint16_t)(s4.y & 0xFFFF)); wsf[4 * q + 3] = h2f((uint16_t)(s4.y >> 16));
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                v16i_t c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[tt], c, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)          // result += isum * (wScale * aScale)
+                    acc[m][tt][r] = acc[m][tt][r] + (float)c[r] * (wsf[r] * xsc[tt]);
+            }
+        }
+    }
+    // C layout: token = lane & 31 (column), weight row = (r & 3) + 8 * (r >> 2) + 4 * hi
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int b = tok0 + 32 * tt + tl;
+        if (b >= a.ntok) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row >= a.rows) continue;
+            float* o = a.out + (size_t)b * a.out_stride + row;
+            if (EPI == EPI_STORE) *o = acc[0][tt][r];
+            if (EPI == EPI_RESID) *o = *o + acc[0][tt][r];
+            if (EPI == EPI_SWIGLU) {
+                float g = acc[0][tt][r];
+                g = g / (float)(1.0 + exp(-(double)g));
+                *o = g * acc[NM - 1][tt][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RoPE on q and k of every token + KV-cache write (batchForwardJavaPrefill :106-121; Qwen3 adds the per-head
+// RMSNorm, InferenceCore.java:594-600).  Grid = (n_heads + n_kv_heads, ntok), block = 64.
+struct RopeArgs {
+    float* QKV; int qkv_stride; float* kcache; float* vcache; const float* cr; const float* ci;
+    const float* qnorm; const float* knorm; int n_heads, n_kv_heads, hs, q_dim, kv_dim, start_pos, arch; float eps;
+};
+
+__global__ __launch_bounds__(64) void pf_rope_kv_kernel(const RopeArgs a) {
+    __shared__ float v[256];
+    const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, hs = a.hs;
+    const int pos = a.start_pos + b;
+    const bool is_k = h >= a.n_heads;
+    const int hk = is_k ? h - a.n_heads : h;
+    float* src = a.QKV + (size_t)b * a.qkv_stride + (is_k ? a.q_dim + hk * hs : hk * hs);
+    for (int i = t; i < hs; i += 64) v[i] = src[i];
+    __syncthreads();
+    if (a.arch == 1) {
+        if (t == 0) head_rmsnorm_1t(v, is_k ? a.knorm : a.qnorm, hs, a.eps);
+        __syncthreads();
+    }
+    rope_head(v, hs, a.cr + (size_t)pos * (hs >> 1), a.ci + (size_t)pos * (hs >> 1), a.arch, t, 64);
+    __syncthreads();
+    if (!is_k) {
+        for (int i = t; i < hs; i += 64) src[i] = v[i];
+    } else {
+        const float* vsrc = a.QKV + (size_t)b * a.qkv_stride + a.q_dim + a.kv_dim + hk * hs;
+        for (int i = t; i < hs; i += 64) {
+            a.kcache[(size_t)pos * a.kv_dim + hk * hs + i] = v[i];
+            a.vcache[(size_t)pos * a.kv_dim + hk * hs + i] = vsrc[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Batched attention (batchForwardJavaPrefill :123-145: sequential per token, identical arithmetic to decode).
+// Scores: grid = (n_tsplit, n_kv_heads, ntok), block = 64 x kvMul; all K rows come from the cache.
+struct PfAttnArgs {
+    const float* Q; int q_stride;       // roped q rows [ntok][...]
+    const float* kcache; const float* vcache;
+    float* att;                          // [ntok][n_heads][ctx]
+    float* out; int out_stride;          // [ntok][q_dim]
+    int n_heads, n_kv_heads, hs, kv_dim, ctx, start_pos;
+};
+
+__global__ void pf_attn_scores_kernel(const PfAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads, pitch = hs + 1;
+    float* q_s = sm;
+    float* kt = q_s + kvmul * hs;
+    const int t = threadIdx.x, nthr = blockDim.x;
+    const int sp = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int pos = a.start_pos + b;
+    const int t0 = sp * ATT_TT;
+    if (t0 > pos) return;
+    const int t1 = min(pos + 1, t0 + ATT_TT);
+    for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.Q[(size_t)b * a.q_stride + (kvh * kvmul) * hs + i];
+    const int q4 = hs >> 2;
+    for (int i = t; i < (t1 - t0) * q4; i += nthr) {
+        const int r = i / q4, c = i % q4;
+        const float4 v = *reinterpret_cast<const float4*>(a.kcache + (size_t)(t0 + r) * a.kv_dim + kvh * hs + 4 * c);
+        float* d = kt + r * pitch + 4 * c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int hq = t >> 6, r = t & 63;
+    if (hq < kvmul && t0 + r < t1) {
+        const float* q = q_s + hq * hs;
+        const float* kk = kt + r * pitch;
+        float score = 0.f;
+        for (int j = 0; j < hs; ++j) score = score + q[j] * kk[j];
+        const float sqrt_hs = (float)sqrt((double)hs);
+        a.att[((size_t)b * a.n_heads + kvh * kvmul + hq) * a.ctx + t0 + r] = score / sqrt_hs;
+    }
+}
+
+// softmax + weighted V sum: grid = (n_heads * ceil(hs/64), ntok), block = 64
+__global__ __launch_bounds__(64) void pf_attn_softmax_pv_kernel(const PfAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float e_s[];
+    const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads;
+    const int nj = (hs + 63) / 64;
+    const int h = blockIdx.x / nj, j = (blockIdx.x % nj) * 64 + threadIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x, kvh = h / kvmul;
+    const int n = a.start_pos + b + 1;
+    const float* sc = a.att + ((size_t)b * a.n_heads + h) * a.ctx;
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) { const float s = sc[i]; e_s[i] = s; mx = fmaxf(mx, s); }
+    mx = wave_max(mx);
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) e_s[i] = (float)exp((double)(e_s[i] - mx));
+    __syncthreads();
+    const float sum = seq_sum_lds<false>(e_s, n);
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) e_s[i] = e_s[i] / sum;
+    __syncthreads();
+    if (j < hs) {
+        const float* v = a.vcache + kvh * hs + j;
+        float acc = 0.f;
+        int tt = 0;
+        for (; tt + 8 <= n; tt += 8) {
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = v[(size_t)(tt + u) * a.kv_dim];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = e_s[tt + u] * vv[u] + acc;
+        }
+        for (; tt < n; ++tt) acc = e_s[tt] * v[(size_t)tt * a.kv_dim] + acc;
+        a.out[(size_t)b * a.out_stride + h * hs + j] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
+    const gl3_model_desc& d = ctx->d;
+    gl3_prefill_state* p = new gl3_prefill_state();
+    ctx->pf = p;
+    p->max_batch = d.max_batch;
+    const size_t M = d.max_batch;
+    p->maxk = d.hidden > ctx->q_dim ? d.hidden : ctx->q_dim;
+    if (d.dim > p->maxk) p->maxk = d.dim;
+    GL3_HIP(hipMalloc((void**)&p->tokens, M * sizeof(int32_t)));
+    GL3_HIP(hipMalloc((void**)&p->X, M * d.dim * 4));
+    GL3_HIP(hipMalloc((void**)&p->XQ, M * p->maxk));
+    GL3_HIP(hipMalloc((void**)&p->XS, M * (p->maxk / 32) * 4));
+    GL3_HIP(hipMalloc((void**)&p->QKV, M * (ctx->q_dim + 2 * ctx->kv_dim) * 4));
+    GL3_HIP(hipMalloc((void**)&p->AO, M * ctx->q_dim * 4));
+    GL3_HIP(hipMalloc((void**)&p->HB, M * d.hidden * 4));
+    GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    return GL3_OK;
+}
+
+void gl3_prefill_free(gl3_ctx* ctx) {
+    gl3_prefill_state* p = ctx->pf;
+    if (!p) return;
+    auto f = [](void* q) { if (q) hipFree(q); };
+    f(p->tokens); f(p->X); f(p->XQ); f(p->XS); f(p->QKV); f(p->AO); f(p->HB); f(p->ATT);
+    delete p;
+    ctx->pf = nullptr;
+}
+
+template <int EPI>
+static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok, float* out, int out_stride) {
+    gl3_prefill_state* p = ctx->pf;
+    GemmArgs a{};
+    a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.ng = w.ng; a.nb = w.k / 32;
+    a.XQ = p->XQ; a.XS = p->XS; a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride;
+    // Q8T strips hold 16 rows; a 32-row group needs an even number of strips (padded rows are zero weights)
+    dim3 grid((ntok + 255) / 256, (w.nstrips + 1) / 2);
+    hipLaunchKernelGGL((pf_gemm_kernel<EPI>), grid, dim3(256), 0, ctx->stream, a);
+}
+
+int32_t gl3_prefill_run(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t start_pos) {
+    gl3_prefill_state* p = ctx->pf;
+    const gl3_model_desc& d = ctx->d;
+    if (d.tp_size > 1) GL3_FAIL(GL3_E_UNSUPPORTED, "batched prefill under tensor parallelism is not implemented: use max_batch = 1");
+    for (int i = 0; i < n; ++i)
+        if (tokens[i] < 0 || tokens[i] >= d.vocab) GL3_FAIL(GL3_E_ARG, "token id out of range");
+    GL3_HIP(hipSetDevice(d.device));
+    hipStream_t s = ctx->stream;
+    GL3_HIP(hipMemcpyAsync(p->tokens, tokens, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    const int kvmul = d.n_heads / d.n_kv_heads;
+    const int qkv_dim = ctx->q_dim + 2 * ctx->kv_dim;
+    const size_t kv_layer = (size_t)d.ctx * ctx->kv_dim;
+    hipLaunchKernelGGL(pf_embed_kernel, dim3(n), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, p->tokens, p->X);
+    auto nq_smem = [&](int k) { return (size_t)(k + 32) * 4 + SS_SCRATCH_BYTES + 64; };
+    for (int l = 0; l < d.n_layers; ++l) {
+        gl3_layer& L = ctx->layers[l];
+        hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, d.dim, L.attn_norm, d.rms_eps,
+                           p->XQ, p->XS, p->maxk);
+        launch_gemm<EPI_STORE>(ctx, L.wqkv, nullptr, n, p->QKV, qkv_dim);
+        RopeArgs ra{};
+        ra.QKV = p->QKV; ra.qkv_stride = qkv_dim; ra.kcache = ctx->kcache + l * kv_layer; ra.vcache = ctx->vcache + l * kv_layer;
+        ra.cr = ctx->rope_cr; ra.ci = ctx->rope_ci; ra.qnorm = L.qnorm; ra.knorm = L.knorm; ra.n_heads = d.n_heads;
+        ra.n_kv_heads = d.n_kv_heads; ra.hs = d.head_size; ra.q_dim = ctx->q_dim; ra.kv_dim = ctx->kv_dim; ra.start_pos = start_pos;
+        ra.arch = d.arch; ra.eps = d.rms_eps;
+        hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(d.n_heads + d.n_kv_heads, n), dim3(64), 0, s, ra);
+        PfAttnArgs aa{};
+        aa.Q = p->QKV; aa.q_stride = qkv_dim; aa.kcache = ra.kcache; aa.vcache = ra.vcache; aa.att = p->ATT; aa.out = p->AO;
+        aa.out_stride = ctx->q_dim; aa.n_heads = d.n_heads; aa.n_kv_heads = d.n_kv_heads; aa.hs = d.head_size; aa.kv_dim = ctx->kv_dim;
+        aa.ctx = d.ctx; aa.start_pos = start_pos;
+        const int nsplit = (start_pos + n + ATT_TT - 1) / ATT_TT;
+        const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
+        hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, d.n_kv_heads, n), dim3(64 * kvmul), sm1, s, aa);
+        hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(d.n_heads * ((d.head_size + 63) / 64), n), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
+        hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->AO, ctx->q_dim, ctx->q_dim, (const float*)nullptr,
+                           0.f, p->XQ, p->XS, p->maxk);
+        launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, p->X, d.dim);
+        hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, d.dim, L.ffn_norm, d.rms_eps,
+                           p->XQ, p->XS, p->maxk);
+        launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, p->HB, d.hidden);
+        hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->HB, d.hidden, d.hidden, (const float*)nullptr, 0.f,
+                           p->XQ, p->XS, p->maxk);
+        launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, p->X, d.dim);
+    }
+    // keep the decode path's x in step with the last prefilled token (parity tap gl3_get_x)
+    GL3_HIP(hipMemcpyAsync(ctx->x, p->X + (size_t)(n - 1) * d.dim, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, s));
+    GL3_HIP(hipGetLastError());
+    GL3_HIP(hipStreamSynchronize(s));
+    return GL3_OK;
+}

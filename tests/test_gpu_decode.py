@@ -107,3 +107,33 @@ def test_error_behaviour(pkg, planmod):
     with pytest.raises(hip.Gl3Error) as e:
         plan_mod.HipMasterPlan(m4)                            # Q4_0: GL3_E_UNSUPPORTED in this build
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("cfg,batch,chunks", [("tiny-llama", 8, [8, 8, 5]), ("mid-llama", 64, [40, 64, 3]), ("mid-qwen3", 32, [30, 7]),
+                                             ("tiny-llama-tied", 512, [37])])
+def test_batched_prefill_is_bit_identical_to_the_cpu_path(pkg, orc, planmod, cfg, batch, chunks):
+    """tornadoVMForwardBatchPrefill (MFMA int8 GEMM path) vs batchForwardJavaPrefill: same KV cache, same x of the
+    last token, and the decode step that follows returns the same logits — all bit for bit.  Ragged chunk sizes
+    (not multiples of 32 / 64 / 256) and chunks that start at a non-zero position are covered."""
+    plan_mod, hip = planmod
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], seed=33)
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=batch)
+    o = orc.COracle(m)
+    n = sum(chunks)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, n + 2)
+    pos = 0
+    for c in chunks:
+        plan.tornadoVMForwardBatchPrefill(toks[pos:pos + c], pos)
+        o.prefill(toks[pos:pos + c], pos)
+        pos += c
+        assert np.array_equal(plan.x(), o.x())
+    for l in range(m.cfg.n_layers):
+        for p in (0, 1, n // 2, n - 1):
+            k, v = plan.kv(l, p)
+            ko, vo = o.kv(l, p)
+            assert np.array_equal(k, ko) and np.array_equal(v, vo), (l, p)
+    for i in range(2):
+        assert np.array_equal(plan.tornadoVMForwardDecode(toks[n + i], n + i), o.forward(toks[n + i], n + i))
+    with pytest.raises(hip.Gl3Error):
+        plan.tornadoVMForwardBatchPrefill(toks[:batch + 1] if batch + 1 <= len(toks) else list(toks) * 300, 0)   # chunk > max_batch
+    plan.freeTornadoExecutionPlan()
