@@ -95,10 +95,34 @@ static uint64_t mv_bytes(const Q8Mat& w) { return w.algo_bytes() + (uint64_t)w.k
 // Tensor parallelism keeps the reference's arithmetic bit for bit: every matrix is split by OUTPUT rows (heads /
 // hidden units / dim rows / vocab rows), so each dot product is still evaluated in full, in order, by one rank;
 // the activations are re-assembled with an in-place all-gather (4 per layer + 1 for the logits).
-static int32_t all_gather(gl3_ctx* ctx, float* buf, int count_per_rank, Prof& pr) {
+enum { GB_XB = 0, GB_X = 1, GB_HB = 2, GB_LOGITS = 3 };
+static float* gather_buf(gl3_ctx* c, int which) {
+    return which == GB_XB ? c->xb : which == GB_X ? c->x : which == GB_HB ? c->hb : c->logits;
+}
+
+static int32_t all_gather(gl3_ctx* ctx, int which, int count_per_rank, Prof& pr) {
     if (!ctx->use_rccl) return GL3_OK;
+    float* buf = gather_buf(ctx, which);
     pr.begin(GL3_K_COLLECTIVE, 0);
-    GL3_NCCL(ncclAllGather(buf + (size_t)ctx->d.tp_rank * count_per_rank, buf, count_per_rank, ncclFloat, ctx->comm, ctx->stream));
+    if (ctx->lgrp) {                                   // in-process test transport (see gl3_local_group)
+        gl3_local_group* g = ctx->lgrp;
+        const int me = ctx->d.tp_rank;
+        GL3_HIP(hipEventRecord(g->ready[me], ctx->stream));
+        g->barrier();                                  // every rank's slice is enqueued
+        for (int p = 0; p < g->n; ++p) {
+            if (p == me) continue;
+            GL3_HIP(hipStreamWaitEvent(ctx->stream, g->ready[p], 0));
+            GL3_HIP(hipMemcpyAsync(buf + (size_t)p * count_per_rank, gather_buf(g->ranks[p], which) + (size_t)p * count_per_rank,
+                                   (size_t)count_per_rank * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        GL3_HIP(hipEventRecord(g->done[me], ctx->stream));
+        g->barrier();                                  // nobody overwrites a slice a peer is still copying
+        for (int p = 0; p < g->n; ++p)
+            if (p != me) GL3_HIP(hipStreamWaitEvent(ctx->stream, g->done[p], 0));
+        g->barrier();                                  // events may be re-recorded from here on
+    } else {
+        GL3_NCCL(ncclAllGather(buf + (size_t)ctx->d.tp_rank * count_per_rank, buf, count_per_rank, ncclFloat, ctx->comm, ctx->stream));
+    }
     pr.end();
     return GL3_OK;
 }
@@ -134,25 +158,25 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         hipLaunchKernelGGL(attn_scores_kernel, dim3(ctx->n_tsplit, ctx->kv_heads_l), dim3(64 * kvmul), sm1, s, aa);
         hipLaunchKernelGGL(attn_softmax_pv_kernel, dim3(ctx->heads_l * ((d.head_size + 63) / 64)), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
         pr.end();
-        if ((r = all_gather(ctx, ctx->xb, ctx->q_dim_l, pr)) != GL3_OK) return r;
+        if ((r = all_gather(ctx, GB_XB, ctx->q_dim_l, pr)) != GL3_OK) return r;
 
         // x[rows of this rank] += Wo[rows, :] . xb
         pr.begin(GL3_K_MATVEC_WO, mv_bytes(L.wo));
         launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->x + (size_t)rank * ctx->dim_l,
                       ctx->x + (size_t)rank * ctx->dim_l);
         pr.end();
-        if ((r = all_gather(ctx, ctx->x, ctx->dim_l, pr)) != GL3_OK) return r;
+        if ((r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
 
         pr.begin(GL3_K_MATVEC_GATEUP, mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4);
         launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr);
         pr.end();
-        if ((r = all_gather(ctx, ctx->hb, ctx->hidden_l, pr)) != GL3_OK) return r;
+        if ((r = all_gather(ctx, GB_HB, ctx->hidden_l, pr)) != GL3_OK) return r;
 
         pr.begin(GL3_K_MATVEC_DOWN, mv_bytes(L.w2));
         launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->x + (size_t)rank * ctx->dim_l,
                       ctx->x + (size_t)rank * ctx->dim_l);
         pr.end();
-        if ((r = all_gather(ctx, ctx->x, ctx->dim_l, pr)) != GL3_OK) return r;
+        if ((r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
         if (ctx->taps) hipMemcpyAsync(ctx->taps + (size_t)l * d.dim, ctx->x, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, s);
     }
     if (want_logits) {
@@ -160,7 +184,7 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm,
                       ctx->logits + (size_t)rank * ctx->vocab_l, nullptr);
         pr.end();
-        if ((r = all_gather(ctx, ctx->logits, ctx->vocab_l, pr)) != GL3_OK) return r;
+        if ((r = all_gather(ctx, GB_LOGITS, ctx->vocab_l, pr)) != GL3_OK) return r;
     }
     GL3_HIP(hipGetLastError());
     pr.collect();
@@ -413,6 +437,36 @@ int32_t gl3_tp_unique_id(void* out, uint64_t bytes) {
     return GL3_OK;
 }
 
+int32_t gl3_local_group_create(int32_t n, gl3_local_group** out) {
+    if (n < 1 || !out) return GL3_E_ARG;
+    gl3_local_group* g = new gl3_local_group();
+    g->n = n; g->ranks.assign(n, nullptr); g->ready.resize(n); g->done.resize(n);
+    for (int i = 0; i < n; ++i) {
+        if (hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming) != hipSuccess) { delete g; return GL3_E_HIP; }
+    }
+    *out = g;
+    return GL3_OK;
+}
+
+void gl3_local_group_destroy(gl3_local_group* g) {
+    if (!g) return;
+    for (auto e : g->ready) hipEventDestroy(e);
+    for (auto e : g->done) hipEventDestroy(e);
+    delete g;
+}
+
+int32_t gl3_tp_attach_local(gl3_ctx* ctx, gl3_local_group* g) {
+    if (!ctx || !g) return GL3_E_ARG;
+    if (ctx->finalized) GL3_FAIL(GL3_E_STATE, "attach after finalize");
+    if (g->n != ctx->d.tp_size) GL3_FAIL(GL3_E_ARG, "local group size differs from tp_size");
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->ranks[ctx->d.tp_rank] = ctx;
+    ctx->lgrp = g;
+    ctx->use_rccl = true;
+    return GL3_OK;
+}
+
 int32_t gl3_tp_init(gl3_ctx* ctx, const void* unique_id, uint64_t bytes) {
     if (!ctx) return GL3_E_ARG;
     if (!unique_id || bytes < sizeof(ncclUniqueId)) GL3_FAIL(GL3_E_ARG, "bad RCCL unique id");
@@ -447,7 +501,7 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
     for (int l = 0; l < d.n_layers; ++l)
         if ((ctx->layers[l].have & need_l) != need_l) GL3_FAIL(GL3_E_STATE, "layer " + std::to_string(l) + ": tensors missing");
     if (!ctx->rope_cr) GL3_FAIL(GL3_E_STATE, "rope tables not uploaded");
-    if (ctx->use_rccl && !ctx->comm) GL3_FAIL(GL3_E_STATE, "tensor parallel plan without gl3_tp_init");
+    if (ctx->use_rccl && !ctx->comm && !ctx->lgrp) GL3_FAIL(GL3_E_STATE, "tensor parallel plan without gl3_tp_init");
     if (!(ctx->have_global & (1u << GL3_T_OUTPUT))) {   // tied: wcls = this rank's vocab rows of token_embd
         ctx->wcls = ctx->emb;
         ctx->wcls.rows = ctx->vocab_l;
@@ -457,7 +511,7 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
     }
     if (ctx->staging) { hipFree(ctx->staging); ctx->staging = nullptr; ctx->staging_bytes = 0; }
     ctx->finalized = true;
-    if (!(d.flags & GL3_FLAG_NO_GRAPH) && !env_flag("GL3_NO_GRAPH", false)) {
+    if (!(d.flags & GL3_FLAG_NO_GRAPH) && !env_flag("GL3_NO_GRAPH", false) && !ctx->lgrp) {
         const double t0 = now_ms();
         int32_t r = capture(ctx, true, &ctx->graph, &ctx->graph_exec);
         if (r != GL3_OK) {   // e.g. a collective that cannot be captured: run eagerly instead

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,6 +25,22 @@ struct gl3_layer {
     Q8Mat wqkv, wo, w1, w3, w2;
     float *attn_norm = nullptr, *ffn_norm = nullptr, *qnorm = nullptr, *knorm = nullptr;
     uint32_t have = 0;       // bit per tensor id
+};
+
+// test-only tensor-parallel transport: ranks are host threads of one process sharing one device
+struct gl3_local_group {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0, generation = 0;
+    std::vector<struct gl3_ctx*> ranks;
+    std::vector<hipEvent_t> ready, done;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const int gen = generation;
+        if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
 };
 
 struct gl3_ctx {
@@ -57,7 +75,8 @@ struct gl3_ctx {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;          // decode step incl. logits
     ncclComm_t comm = nullptr;
-    bool use_rccl = false;
+    gl3_local_group* lgrp = nullptr;
+    bool use_rccl = false;                        // tensor-parallel gathers are active (RCCL or local group)
     std::vector<hipEvent_t> ev;
     // metrics
     double plan_ms = 0, copy_in_ms = 0;

@@ -43,6 +43,9 @@ _SIGS = {  # symbol -> (restype, argtypes): exactly the declarations of include/
     "gl3_upload_rope": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "gl3_tp_unique_id": (C.c_int32, [C.c_void_p, C.c_uint64]),
     "gl3_tp_init": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "gl3_local_group_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "gl3_local_group_destroy": (None, [C.c_void_p]),
+    "gl3_tp_attach_local": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "gl3_finalize": (C.c_int32, [C.c_void_p]),
     "gl3_forward_decode": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gl3_forward_prefill": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),

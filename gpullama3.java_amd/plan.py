@@ -29,7 +29,7 @@ def _p(a: np.ndarray):
 
 class HipMasterPlan:
     def __init__(self, model, prefill_batch_size: int = 1, device: int = 0, tp_rank: int = 0, tp_size: int = 1,
-                 flags: int = 0, unique_id: bytes | None = None):
+                 flags: int = 0, unique_id: bytes | None = None, local_group=None):
         """model: synth.SynthModel-like — cfg, tensors {gguf name: (raw uint8, ggml_type, rows, cols)}, rope (cr, ci)."""
         L = hip.lib()
         c = model.cfg
@@ -42,7 +42,9 @@ class HipMasterPlan:
         self.tp_size, self.tp_rank = tp_size, tp_rank
         self.max_batch = prefill_batch_size
         try:
-            if tp_size > 1 or flags & hip.FLAG_FORCE_RCCL:
+            if local_group is not None:
+                hip.check(L.gl3_tp_attach_local(self._ctx, local_group), self._ctx)
+            elif tp_size > 1 or flags & hip.FLAG_FORCE_RCCL:
                 assert unique_id is not None, "tensor parallel plan needs the RCCL unique id from rank 0"
                 buf = C.create_string_buffer(unique_id, len(unique_id))
                 hip.check(L.gl3_tp_init(self._ctx, buf, len(unique_id)), self._ctx)
@@ -155,6 +157,13 @@ class HipMasterPlan:
             self.freeTornadoExecutionPlan()
         except Exception:
             pass
+
+
+def make_local_group(n: int):
+    """Test transport: n plans in one process on one GPU (one host thread per rank)."""
+    g = C.c_void_p()
+    hip.check(hip.lib().gl3_local_group_create(n, C.byref(g)))
+    return g
 
 
 def make_unique_id() -> bytes:

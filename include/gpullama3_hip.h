@@ -140,6 +140,14 @@ GL3_API int32_t gl3_upload_rope(gl3_ctx* ctx, const float* cr, const float* ci, 
 GL3_API int32_t gl3_tp_unique_id(void* out, uint64_t bytes);   /* bytes >= 128 */
 GL3_API int32_t gl3_tp_init(gl3_ctx* ctx, const void* unique_id, uint64_t bytes);
 
+/* In-process tensor-parallel group for TESTS on one GPU: `n` plans (one host thread each, same device) exchange their
+ * slices with device-to-device copies instead of RCCL, exercising exactly the same row split, kernel arguments and
+ * gather points.  Create once, pass to every rank's gl3_tp_attach_local before gl3_finalize, destroy after the plans. */
+typedef struct gl3_local_group gl3_local_group;
+GL3_API int32_t gl3_local_group_create(int32_t n, gl3_local_group** out);
+GL3_API void gl3_local_group_destroy(gl3_local_group* g);
+GL3_API int32_t gl3_tp_attach_local(gl3_ctx* ctx, gl3_local_group* g);
+
 /* forceCopyInReadOnlyData(): checks that every tensor arrived, ties wcls to token_embd when
  * GL3_T_OUTPUT was not uploaded (AbstractModelLoader.java:194), captures the decode hipGraph. */
 GL3_API int32_t gl3_finalize(gl3_ctx* ctx);
