@@ -1,0 +1,34 @@
+"""Tensor-parallel partition of the forward pass (host-side description of what gl3_create / gl3_upload_tensor do).
+
+Every matrix is split by OUTPUT rows so that each dot product stays whole and in the reference's order on one
+rank (bit-identical results); activations are re-assembled with all-gathers.  The same table drives the C++
+upload slicing (csrc/gl3_api.hip: gl3_upload_tensor) and the CPU test of the scheme (tests/test_tp_gloo.py).
+"""
+from __future__ import annotations
+
+
+def validate(cfg, tp: int) -> None:
+    """Mirrors the checks of gl3_create (GL3_E_UNSUPPORTED)."""
+    if tp < 1:
+        raise ValueError("tp_size must be >= 1")
+    if cfg.n_heads % tp or cfg.n_kv_heads % tp or cfg.hidden % (16 * tp) or cfg.vocab % (16 * tp) or cfg.dim % (16 * tp):
+        raise ValueError("tp_size must divide n_heads, n_kv_heads, hidden/16, dim/16 and vocab/16")
+
+
+def row_slices(cfg, tp: int, rank: int) -> dict:
+    """GGUF tensor suffix -> (first row, number of rows) kept by `rank`."""
+    validate(cfg, tp)
+    hs = cfg.head_size
+    ql, kvl = cfg.n_heads // tp * hs, cfg.n_kv_heads // tp * hs
+    hl, dl, vl = cfg.hidden // tp, cfg.dim // tp, cfg.vocab // tp
+    return {
+        "attn_q.weight": (rank * ql, ql), "attn_k.weight": (rank * kvl, kvl), "attn_v.weight": (rank * kvl, kvl),
+        "attn_output.weight": (rank * dl, dl), "ffn_gate.weight": (rank * hl, hl), "ffn_up.weight": (rank * hl, hl),
+        "ffn_down.weight": (rank * dl, dl), "output.weight": (rank * vl, vl),
+    }
+
+
+# all-gather points of one layer, in order: (buffer, floats per rank)
+def gather_points(cfg, tp: int):
+    hs = cfg.head_size
+    return [("xb", cfg.n_heads // tp * hs), ("x", cfg.dim // tp), ("hb", cfg.hidden // tp), ("x", cfg.dim // tp)]
