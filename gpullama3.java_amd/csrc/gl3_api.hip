@@ -223,7 +223,7 @@ int32_t gl3_debug_sumsq(int32_t device, const float* x, int32_t n, float* out) {
     float *dx = nullptr, *dout = nullptr;
     if (hipMalloc((void**)&dx, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&dout, 4) != hipSuccess) return GL3_E_OOM;
     hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(debug_sumsq_kernel, dim3(1), dim3(256), (size_t)(n + 32) * 4 + SS_SCRATCH_BYTES, 0, dx, n, dout);
+    hipLaunchKernelGGL(debug_sumsq_kernel, dim3(1), dim3(256), (size_t)(n + 32) * 4 + ss_scratch_bytes(n), 0, dx, n, dout);
     const hipError_t e = hipMemcpy(out, dout, 4, hipMemcpyDeviceToHost);
     hipFree(dx); hipFree(dout);
     return e == hipSuccess ? GL3_OK : GL3_E_HIP;

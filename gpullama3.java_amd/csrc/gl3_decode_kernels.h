@@ -246,7 +246,7 @@ __global__ __launch_bounds__(MV_THREADS, 4) void matvec_q8t_kernel(const MatvecA
         // InferenceCore.rmsnorm :41 — the strict left-to-right sum of squares, evaluated exactly in parallel
         // (gl3_seqsum.h); pbuf is free during the prologue and serves as its scratch.
         float ss;
-        if ((size_t)2 * NM * a.ng * 64 * 4 >= SS_SCRATCH_BYTES && a.k >= 1024 && a.k <= 5120) {
+        if ((size_t)2 * NM * a.ng * 64 * 4 >= ss_scratch_bytes(a.k) && a.k >= 1024 && a.k <= 5120) {
             ss = exact_sumsq_lds(xf, a.k, reinterpret_cast<uint8_t*>(pbuf), ta, aux_sync);
         } else {
             if (wave == MV_PRODUCERS) {

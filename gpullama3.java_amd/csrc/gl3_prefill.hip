@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restr
                                                              uint8_t* __restrict__ XQ, float* __restrict__ XS, int maxk) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* xf = reinterpret_cast<float*>(smem);                 // [k + 32]
-    uint8_t* scratch = smem + (size_t)(k + 32) * 4;             // SS_SCRATCH_BYTES
-    float* red = reinterpret_cast<float*>(scratch + SS_SCRATCH_BYTES);
+    uint8_t* scratch = smem + (size_t)(k + 32) * 4;             // ss_scratch_bytes(k)
+    float* red = reinterpret_cast<float*>(scratch + ss_scratch_bytes(k));
     const int t = threadIdx.x, b = blockIdx.x;
     const float* x = in + (size_t)b * in_stride;
     const int nquads = k >> 2;
@@ -363,7 +363,7 @@ int32_t gl3_prefill_run(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t 
     const int qkv_dim = ctx->q_dim + 2 * ctx->kv_dim;
     const size_t kv_layer = (size_t)d.ctx * ctx->kv_dim;
     hipLaunchKernelGGL(pf_embed_kernel, dim3(n), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, p->tokens, p->X);
-    auto nq_smem = [&](int k) { return (size_t)(k + 32) * 4 + SS_SCRATCH_BYTES + 64; };
+    auto nq_smem = [&](int k) { return (size_t)(k + 32) * 4 + ss_scratch_bytes(k) + 64; };
     for (int l = 0; l < d.n_layers; ++l) {
         gl3_layer& L = ctx->layers[l];
         hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, d.dim, L.attn_norm, d.rms_eps,

@@ -8,9 +8,9 @@
 // (and, on an exact rounding tie, on the parity of N).  So a segment of m elements that (i) starts in the
 // binade predicted by an approximate prefix sum, (ii) does not leave it and (iii) gives the same increment D
 // from an even and from an odd start is a pure translation s -> s + D, and translations compose exactly
-// (integer sums of D/u).  Each of 256 threads finds its segment's D by running the real f32 chain from two
+// (integer sums of D/u).  Each of 256 threads finds the D of its 4-element segments by running the real f32 chain from two
 // representative starts; the few "hard" segments (a binade crossing, a parity-dependent tie, the first one;
-// ~13 of 256 for Gaussian data) are replayed with real f32 adds from their true start = previous hard
+// ~18 of 1024 four-element segments for Gaussian data) are replayed with real f32 adds from their true start = previous hard
 // segment's end + (integer run sum) * u.  The premises are re-checked on the true values at every run
 // boundary (values are monotone, so boundary checks cover the interior); on any violation the naive chain
 // runs instead, so the result is always exactly the sequential sum.
@@ -28,7 +28,6 @@ __device__ long long gl3_ss_stamp[16];
 #endif
 
 constexpr int SS_T = 256;                          // threads that own a segment
-constexpr int SS_SCRATCH_BYTES = 4 * 1024;         // LDS scratch the caller must provide (16-byte aligned)
 
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
@@ -87,54 +86,47 @@ __device__ __forceinline__ float ss_chain(const float4 (&buf)[M4], float base) {
 template <int M4>
 __device__ __forceinline__ void replay_events(const float* x, int m, int nseg, int nhard, const uint32_t* es, const uint32_t* pre,
                                               const int* hlist, float& base, int& fail) {
+    static_assert(M4 == 1, "segments are one float4");
     const int lane = threadIdx.x & 63;
     for (int c0 = 0; c0 <= nhard; c0 += 64) {
+        // lane j gathers everything event c0 + j needs in ONE parallel LDS round trip
         const int j = c0 + lane;
         const bool valid = j <= nhard;
         const int h = (valid && j < nhard) ? hlist[j] : nseg;
         const int ph = (valid && j > 0) ? hlist[j - 1] : -1;
-        const int hasrun = (valid && (h - 1 > ph)) ? 1 : 0;
-        uint32_t er = 0;
+        uint32_t er = 0;                                   // 0 = no easy run before this event
         float runadd = 0.f;
-        if (hasrun) {
+        if (valid && (h - 1 > ph)) {
             const uint32_t R = pre[h - 1] - (ph >= 0 ? pre[ph] : 0u);
             er = es[ph + 1] & 0x7FFFFFFFu;
-            runadd = (float)R * u2f((er - 23u) << 23);
+            runadd = (float)R * u2f((er - 23u) << 23);     // exact: integer run sum * ulp
+        }
+        float4 sq = {0.f, 0.f, 0.f, 0.f};                  // +0 adds nothing for the trailing event
+        if (h < nseg) {
+            const float4 v = *reinterpret_cast<const float4*>(x + 4 * h);
+            sq.x = v.x * v.x; sq.y = v.y * v.y; sq.z = v.z * v.z; sq.w = v.w * v.w;
         }
         SS_STAMP(5);
         const int nev = min(64, nhard + 1 - c0);
-        float4 A[M4], B[M4];
-        ss_load<M4>(A, x, __builtin_amdgcn_readlane(h, 0), m, nseg);
-        for (int jj = 0; jj < nev; jj += 2) {
-            ss_load<M4>(B, x, jj + 1 < nev ? __builtin_amdgcn_readlane(h, (jj + 1) & 63) : nseg, m, nseg);
-            {
-                const uint32_t e_r = (uint32_t)__builtin_amdgcn_readlane((int)er, jj & 63);
-                if (__builtin_amdgcn_readlane(hasrun, jj & 63)) {
-                    fail |= (f2u(base) >> 23) != e_r;
-                    base = base + u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(runadd), jj & 63));
-                    fail |= (f2u(base) >> 23) != e_r;
-                }
-                if (c0 + jj < nhard) base = ss_chain<M4>(A, base);
+        // the sequential part: a pure register chain fed by v_readlane (lane index uniform)
+        for (int jj = 0; jj < nev; ++jj) {
+            const uint32_t e_r = (uint32_t)__builtin_amdgcn_readlane((int)er, jj);
+            const float ra = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(runadd), jj));
+            const float s0 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sq.x), jj));
+            const float s1 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sq.y), jj));
+            const float s2 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sq.z), jj));
+            const float s3 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sq.w), jj));
+            if (e_r != 0u) {
+                fail |= (f2u(base) >> 23) != e_r;
+                base = base + ra;
+                fail |= (f2u(base) >> 23) != e_r;
             }
-            if (jj + 1 >= nev) break;
-            ss_load<M4>(A, x, jj + 2 < nev ? __builtin_amdgcn_readlane(h, (jj + 2) & 63) : nseg, m, nseg);
-            {
-                const uint32_t e_r = (uint32_t)__builtin_amdgcn_readlane((int)er, (jj + 1) & 63);
-                if (__builtin_amdgcn_readlane(hasrun, (jj + 1) & 63)) {
-                    fail |= (f2u(base) >> 23) != e_r;
-                    base = base + u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(runadd), (jj + 1) & 63));
-                    fail |= (f2u(base) >> 23) != e_r;
-                }
-                if (c0 + jj + 1 < nhard) base = ss_chain<M4>(B, base);
-            }
+            base = base + s0; base = base + s1; base = base + s2; base = base + s3;
         }
     }
 }
 
-// Called by exactly 256 threads (4 wavefronts) of the workgroup.  x: n floats in LDS, 16-byte
-// aligned, n a multiple of 4, 1024 <= n <= 5120 (callers use the plain chain outside that range), followed by at least 32 readable ZERO floats (segment padding).  Returns the sequential sum of squares in every thread.
-// `t` = index of the calling thread among the 256 participating threads; `sync()` is a barrier over exactly
-// those 4 wavefronts (the whole workgroup's __syncthreads, or a sub-group barrier — see SubBarrier).
+// Barrier functors for exact_sumsq_lds: `sync()` must be a barrier over exactly the 4 participating wavefronts.
 struct BlockBarrier { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
 
 // Barrier over a subset of the workgroup's wavefronts through an LDS counter (gfx950 has no named barriers).
@@ -150,92 +142,113 @@ struct SubBarrier {
     }
 };
 
+// scratch bytes needed for n elements (16-byte aligned): header + es/pre/hlist per 4-element segment
+__host__ __device__ constexpr size_t ss_scratch_bytes(int n) { return 128 + (size_t)3 * n; }
+constexpr int SS_MAX_SPT = 5;                      // segments per thread: n <= 4 * 256 * 5 = 5120
+
 template <typename Sync>
 __device__ float exact_sumsq_lds(const float* x, int n, uint8_t* scratch, const int t, Sync& sync) {
     const int lane = t & 63, wave = t >> 6;
-    float* w_tot = reinterpret_cast<float*>(scratch);                    // [8]  predictor wave totals
-    uint32_t* w_nd = reinterpret_cast<uint32_t*>(scratch + 32);          // [8]  run-sum wave totals
-    int* w_cnt = reinterpret_cast<int*>(scratch + 64);                   // [8]  hard segments per wave
-    int* misc = reinterpret_cast<int*>(scratch + 96);                    // [0] fail flag
-    float* result = reinterpret_cast<float*>(scratch + 112);             // [0]
-    uint32_t* es = reinterpret_cast<uint32_t*>(scratch + 128);           // [256] predicted exponent | hard<<31
-    uint32_t* pre = es + SS_T;                                           // [256] inclusive prefix of D/u (mod 2^32)
-    int* hlist = reinterpret_cast<int*>(pre + SS_T);                     // [256] hard segment ids in order
-
-    const int m = ((n + SS_T - 1) / SS_T + 3) & ~3;
-    const int nseg = (n + m - 1) / m;
-    const bool own = t < nseg;
-    const int k0 = own ? t * m : n, k1 = own ? min(n, k0 + m) : n;
+    float* w_tot = reinterpret_cast<float*>(scratch);                    // [4]  predictor wave totals
+    uint32_t* w_nd = reinterpret_cast<uint32_t*>(scratch + 16);          // [4]  run-sum wave totals
+    int* w_cnt = reinterpret_cast<int*>(scratch + 32);                   // [4]  hard segments per wave
+    int* misc = reinterpret_cast<int*>(scratch + 48);                    // [0] fail flag
+    float* result = reinterpret_cast<float*>(scratch + 64);              // [0]
+    const int nseg = n >> 2;                                             // 4-element segments (one float4 each)
+    uint32_t* es = reinterpret_cast<uint32_t*>(scratch + 128);           // [nseg] predicted exponent | hard<<31
+    uint32_t* pre = es + nseg;                                           // [nseg] inclusive prefix of D/ulp (mod 2^32)
+    int* hlist = reinterpret_cast<int*>(pre + nseg);                     // [nseg] hard segment ids in order
+    const int spt = (nseg + SS_T - 1) / SS_T;
+    const int seg0 = t * spt;
     if (t == 0) misc[0] = 0;
     SS_STAMP(0);
 
-    // ---- predictor: approximate (any-order) f32 prefix of the squares before segment t
-    float q = 0.f;
-    for (int k = k0; k < k1; k += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(x + k);
-        q += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    // ---- predictor: approximate (any-order) f32 prefix of the squares before each of my segments
+    float4 a[SS_MAX_SPT];
+    float qs[SS_MAX_SPT];
+    float qt = 0.f;
+#pragma unroll
+    for (int i = 0; i < SS_MAX_SPT; ++i) {
+        qs[i] = 0.f;
+        if (i < spt && seg0 + i < nseg) {
+            const float4 v = *reinterpret_cast<const float4*>(x + 4 * (seg0 + i));
+            a[i].x = v.x * v.x; a[i].y = v.y * v.y; a[i].z = v.z * v.z; a[i].w = v.w * v.w;
+            qs[i] = (a[i].x + a[i].y) + (a[i].z + a[i].w);
+            qt += qs[i];
+        }
     }
-    const float incl = wave_incl_scan_f32(q);
-    if (lane == 63 && wave < 8) w_tot[wave] = incl;
+    const float incl = wave_incl_scan_f32(qt);
+    if (lane == 63) w_tot[wave] = incl;
     sync();
     SS_STAMP(1);
-    float P = incl - q;
-    for (int w = 0; w < wave && w < 8; ++w) P += w_tot[w];
+    float P = incl - qt;
+    for (int w = 0; w < wave; ++w) P += w_tot[w];
 
-    // ---- translation D of the segment from two representative starts (even / odd mantissa)
-    bool hard = false;
-    uint32_t nd = 0, e = 0;
-    if (own) {
-        const uint32_t rb = f2u(P) & ~1u;
-        e = rb >> 23;
-        if (t == 0 || e <= 40u || e >= 250u) hard = true;
-        else {
-            const float R0 = u2f(rb), R1 = u2f(rb | 1u);
-            float E0 = R0, E1 = R1;
-            for (int k = k0; k < k1; k += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(x + k);
-                const float a0 = v.x * v.x, a1 = v.y * v.y, a2 = v.z * v.z, a3 = v.w * v.w;
-                E0 = E0 + a0; E1 = E1 + a0; E0 = E0 + a1; E1 = E1 + a1;
-                E0 = E0 + a2; E1 = E1 + a2; E0 = E0 + a3; E1 = E1 + a3;
+    // ---- translation D of each segment from two representative starts (even / odd mantissa)
+    uint32_t ev[SS_MAX_SPT], ndp[SS_MAX_SPT];
+    uint32_t hmask = 0, ndt = 0;
+#pragma unroll
+    for (int i = 0; i < SS_MAX_SPT; ++i) {
+        ev[i] = 0; ndp[i] = ndt;
+        if (i < spt && seg0 + i < nseg) {
+            const uint32_t rb = f2u(P) & ~1u, e = rb >> 23;
+            bool hard = false;
+            uint32_t nd = 0;
+            if (seg0 + i == 0 || e <= 40u || e >= 250u) hard = true;
+            else {
+                const float R0 = u2f(rb), R1 = u2f(rb | 1u);
+                float E0 = R0, E1 = R1;
+                E0 = E0 + a[i].x; E1 = E1 + a[i].x; E0 = E0 + a[i].y; E1 = E1 + a[i].y;
+                E0 = E0 + a[i].z; E1 = E1 + a[i].z; E0 = E0 + a[i].w; E1 = E1 + a[i].w;
+                const float D0 = E0 - R0, D1 = E1 - R1;
+                const float margin = u2f((e - 23u + 13u) << 23);         // 8192 ulp: keeps the fallback rare
+                if (!(D0 == D1) || (f2u(E0) >> 23) != e || (f2u(E1) >> 23) != e || (f2u(R0 - margin) >> 23) != e ||
+                    (f2u(E0 + margin) >> 23) != e)
+                    hard = true;
+                else nd = (uint32_t)(D0 * u2f((277u - e) << 23));        // D / ulp, exact integer < 2^24
             }
-            const float D0 = E0 - R0, D1 = E1 - R1;
-            const float margin = u2f((e - 23u + 13u) << 23);             // 8192 ulp: keeps the fallback rare
-            if (!(D0 == D1) || (f2u(E0) >> 23) != e || (f2u(E1) >> 23) != e || (f2u(R0 - margin) >> 23) != e ||
-                (f2u(E0 + margin) >> 23) != e)
-                hard = true;
-            else nd = (uint32_t)(D0 * u2f((277u - e) << 23));            // D / ulp, exact integer < 2^24
+            ev[i] = e | (hard ? 0x80000000u : 0u);
+            es[seg0 + i] = ev[i];
+            hmask |= (hard ? 1u : 0u) << i;
+            ndt += nd;
+            ndp[i] = ndt;
+            P += qs[i];
         }
-        es[t] = e | (hard ? 0x80000000u : 0u);
     }
     SS_STAMP(2);
     // ---- inclusive prefix of nd (mod 2^32: only differences inside one run are used) + hard list
-    const uint32_t pin = wave_incl_scan_u32(nd);
-    const unsigned long long hb = __ballot(hard);
-    if (lane == 63 && wave < 8) { w_nd[wave] = pin; w_cnt[wave] = __popcll(hb); }
+    const uint32_t pin = wave_incl_scan_u32(ndt);
+    const uint32_t hc = (uint32_t)__popc(hmask);
+    const uint32_t hin = wave_incl_scan_u32(hc);
+    if (lane == 63) { w_nd[wave] = pin; w_cnt[wave] = (int)hin; }
     sync();
     SS_STAMP(3);
     uint32_t nbase = 0; int hbase = 0;
-    for (int w = 0; w < wave && w < 8; ++w) { nbase += w_nd[w]; hbase += w_cnt[w]; }
-    if (own) {
-        pre[t] = pin + nbase;
-        if (hard) hlist[hbase + __popcll(hb & ((1ull << lane) - 1ull))] = t;
-        else if (t > 0) { const uint32_t ep = es[t - 1]; if (!(ep >> 31) && ep != e) misc[0] = 1; }   // one binade per run
+    for (int w = 0; w < wave; ++w) { nbase += w_nd[w]; hbase += w_cnt[w]; }
+    {
+        const uint32_t nb0 = nbase + pin - ndt;
+        int hpos = hbase + (int)(hin - hc);
+#pragma unroll
+        for (int i = 0; i < SS_MAX_SPT; ++i) {
+            if (i < spt && seg0 + i < nseg) {
+                pre[seg0 + i] = nb0 + ndp[i];
+                if ((hmask >> i) & 1u) hlist[hpos++] = seg0 + i;
+                else if (i > 0) { if (!(ev[i - 1] >> 31) && (ev[i - 1] & 0x7FFFFFFFu) != (ev[i] & 0x7FFFFFFFu)) misc[0] = 1; }
+            }
+        }
     }
     sync();
+    if (seg0 > 0 && seg0 < nseg && !(ev[0] >> 31)) {                      // first segment of the thread vs its left neighbour
+        const uint32_t ep = es[seg0 - 1];
+        if (!(ep >> 31) && ep != ev[0]) misc[0] = 1;
+    }
     SS_STAMP(4);
     // ---- replay the hard segments in order (one wavefront), see replay_events
     if (wave == 0) {
-        int nhard = 0;
-        for (int w = 0; w < 8 && w * 64 < SS_T; ++w) nhard += w_cnt[w];
+        const int nhard = w_cnt[0] + w_cnt[1] + w_cnt[2] + w_cnt[3];
         float base = 0.f;
         int fail = 0;
-        switch (m >> 2) {
-        case 2: replay_events<2>(x, m, nseg, nhard, es, pre, hlist, base, fail); break;
-        case 3: replay_events<3>(x, m, nseg, nhard, es, pre, hlist, base, fail); break;
-        case 4: replay_events<4>(x, m, nseg, nhard, es, pre, hlist, base, fail); break;
-        case 5: replay_events<5>(x, m, nseg, nhard, es, pre, hlist, base, fail); break;
-        default: fail = 1; break;
-        }
+        replay_events<1>(x, 4, nseg, nhard, es, pre, hlist, base, fail);
         if (fail || misc[0]) base = naive_sumsq_lds(x, 0, n, 0.f);       // never expected: plain chain
         if (lane == 0) result[0] = base;
         SS_STAMP(6);

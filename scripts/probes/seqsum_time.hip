@@ -29,7 +29,7 @@ int main() {
         hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice);
         for (int mode = 0; mode < 2; ++mode) {
             float r = 0; long long c = 0;
-            for (int rep = 0; rep < 3; ++rep) k<<<1, 256, (n + 32) * 4 + 8192>>>(dx, n, dout, dc, mode);
+            for (int rep = 0; rep < 3; ++rep) k<<<1, 256, (n + 32) * 4 + 20000>>>(dx, n, dout, dc, mode);
             hipMemcpy(&r, dout, 4, hipMemcpyDeviceToHost); hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
             if (mode == 0) { long long st[16]; hipMemcpyFromSymbol(st, HIP_SYMBOL(gl3::gl3_ss_stamp), sizeof(st)); printf("   phase cycles:"); for (int i = 1; i < 8; ++i) printf(" %lld", st[i] - st[i-1]); printf("\n"); }
             printf("n %d %s: sum %.9g  wall_clock ticks %lld (100 MHz -> %.2f us)\n", n, mode ? "naive" : "exact-parallel", r, c, c / 100.0);
