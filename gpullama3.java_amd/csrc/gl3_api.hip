@@ -127,13 +127,30 @@ static int32_t all_gather(gl3_ctx* ctx, int which, int count_per_rank, Prof& pr)
     return GL3_OK;
 }
 
+static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores, 2 softmax+pv */) {
+    const gl3_model_desc& d = ctx->d;
+    gl3_layer& L = ctx->layers[l];
+    const size_t kv_layer = (size_t)d.ctx * ctx->kv_dim_l;
+    const int kvmul = d.n_heads / d.n_kv_heads;
+    AttnArgs aa{};
+    aa.qkv = ctx->qkv; aa.kcache = ctx->kcache + l * kv_layer; aa.vcache = ctx->vcache + l * kv_layer;
+    aa.rope_cr = ctx->rope_cr; aa.rope_ci = ctx->rope_ci; aa.qnorm = L.qnorm; aa.knorm = L.knorm;
+    aa.dyn = ctx->dyn; aa.att = ctx->att; aa.xb = ctx->xb + (size_t)d.tp_rank * ctx->q_dim_l;
+    aa.n_heads = ctx->heads_l; aa.n_kv_heads = ctx->kv_heads_l;
+    aa.hs = d.head_size; aa.q_dim = ctx->q_dim_l; aa.kv_dim = ctx->kv_dim_l; aa.ctx = d.ctx;
+    aa.eps = d.rms_eps; aa.arch = d.arch;
+    const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 4) + d.head_size) * 4;
+    const int pv_rows = d.ctx < PV_ROWS ? d.ctx : PV_ROWS;
+    const size_t sm2 = ((size_t)((d.ctx + 3) & ~3) + (size_t)pv_rows * PV_COLS) * 4;
+    if (which != 2) hipLaunchKernelGGL(attn_scores_kernel, dim3(ctx->n_tsplit, ctx->kv_heads_l), dim3(64 * kvmul), sm1, ctx->stream, aa);
+    if (which != 1) hipLaunchKernelGGL(attn_softmax_pv_kernel, dim3(ctx->heads_l * (d.head_size / PV_COLS)), dim3(256), sm2, ctx->stream, aa);
+}
+
 static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* kt) {
     const gl3_model_desc& d = ctx->d;
     hipStream_t s = ctx->stream;
     Prof pr{ctx, kt};
     const int rank = d.tp_rank;
-    const size_t kv_layer = (size_t)d.ctx * ctx->kv_dim_l;
-    const int kvmul = d.n_heads / d.n_kv_heads;
     int32_t r;
 
     pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
@@ -146,17 +163,8 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         launch_matvec(ctx, PRO_RMS, EPI_STORE, L.wqkv, nullptr, ctx->x, L.attn_norm, ctx->qkv, nullptr);
         pr.end();
 
-        AttnArgs aa{};
-        aa.qkv = ctx->qkv; aa.kcache = ctx->kcache + l * kv_layer; aa.vcache = ctx->vcache + l * kv_layer;
-        aa.rope_cr = ctx->rope_cr; aa.rope_ci = ctx->rope_ci; aa.qnorm = L.qnorm; aa.knorm = L.knorm;
-        aa.dyn = ctx->dyn; aa.att = ctx->att; aa.xb = ctx->xb + (size_t)rank * ctx->q_dim_l;
-        aa.n_heads = ctx->heads_l; aa.n_kv_heads = ctx->kv_heads_l;
-        aa.hs = d.head_size; aa.q_dim = ctx->q_dim_l; aa.kv_dim = ctx->kv_dim_l; aa.ctx = d.ctx;
-        aa.eps = d.rms_eps; aa.arch = d.arch;
         pr.begin(GL3_K_ATTENTION, 0);
-        const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
-        hipLaunchKernelGGL(attn_scores_kernel, dim3(ctx->n_tsplit, ctx->kv_heads_l), dim3(64 * kvmul), sm1, s, aa);
-        hipLaunchKernelGGL(attn_softmax_pv_kernel, dim3(ctx->heads_l * ((d.head_size + 63) / 64)), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
+        launch_attention(ctx, l, 0);
         pr.end();
         if ((r = all_gather(ctx, GB_XB, ctx->q_dim_l, pr)) != GL3_OK) return r;
 
@@ -293,8 +301,8 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP((allow_big_lds<PRO_QUANT, EPI_RESID>()));
     TRYHIP((allow_big_lds<PRO_RMS, EPI_SWIGLU>()));
     TRYHIP(hipFuncSetAttribute((const void*)attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    TRYHIP(hipFuncSetAttribute((const void*)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    if ((size_t)d.ctx * 4 + 16 > 128 * 1024) return bail(GL3_E_UNSUPPORTED, "context length above 32k not supported by the decode attention kernel");
+    TRYHIP(hipFuncSetAttribute((const void*)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    if ((size_t)d.ctx * 4 + (size_t)PV_ROWS * PV_COLS * 4 + 64 > 150 * 1024) return bail(GL3_E_UNSUPPORTED, "context length above 20k not supported by the decode attention kernel");
     TRY(dmalloc(ctx, &ctx->dyn, 4));
     TRY(dmalloc(ctx, &ctx->argmax, 1));
     if (d.flags & GL3_FLAG_LAYER_TAPS) TRY(dmalloc(ctx, &ctx->taps, (size_t)d.n_layers * d.dim));
@@ -586,7 +594,7 @@ int32_t gl3_profile_decode(gl3_ctx* ctx, int32_t token, int32_t pos, gl3_kernel_
 int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* out_us, uint64_t* bytes_per_launch) {
     if (!ctx || !out_us || iters <= 0) return GL3_E_ARG;
     if (!ctx->finalized) GL3_FAIL(GL3_E_STATE, "profile before gl3_finalize");
-    if (klass < GL3_K_MATVEC_QKV || klass > GL3_K_MATVEC_LOGITS) GL3_FAIL(GL3_E_ARG, "only matvec classes can be profiled");
+    if (klass < GL3_K_MATVEC_QKV || klass > GL3_K_OTHER) GL3_FAIL(GL3_E_ARG, "kernel class cannot be profiled");
     GL3_HIP(hipSetDevice(ctx->d.device));
     const gl3_model_desc& d = ctx->d;
     const int rank = d.tp_rank;
@@ -601,6 +609,8 @@ int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* o
             case GL3_K_MATVEC_WO: launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->qkv, nullptr); break;
             case GL3_K_MATVEC_GATEUP: launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr); break;
             case GL3_K_MATVEC_DOWN: launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->qkv, nullptr); break;
+            case GL3_K_ATTENTION: launch_attention(ctx, l, 1); break;      // scores only (re-run at the current position)
+            case GL3_K_OTHER: launch_attention(ctx, l, 2); break;          // softmax + PV only
             default: launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm, ctx->logits + (size_t)rank * ctx->vocab_l, nullptr); break;
             }
         }
@@ -623,6 +633,7 @@ int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* o
         case GL3_K_MATVEC_WO: *bytes_per_launch = mv_bytes(L.wo); break;
         case GL3_K_MATVEC_GATEUP: *bytes_per_launch = mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4; break;
         case GL3_K_MATVEC_DOWN: *bytes_per_launch = mv_bytes(L.w2); break;
+        case GL3_K_ATTENTION: case GL3_K_OTHER: *bytes_per_launch = 0; break;
         default: *bytes_per_launch = mv_bytes(ctx->wcls) + d.dim * 4; break;
         }
     }

@@ -45,9 +45,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 #ifdef GL3_MV_TIMING
 __device__ long long gl3_mv_stamp[32];
+#define ATT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) gl3_mv_stamp[i] = wall_clock64(); } while (0)
 #define MV_STAMP(i, cond) do { if (blockIdx.x == 0 && (cond)) gl3_mv_stamp[i] = clock64(); } while (0)
 #else
 #define MV_STAMP(i, cond)
+#define ATT_STAMP(i)
 #endif
 
 struct MatvecArgs {
@@ -75,14 +77,26 @@ __device__ __forceinline__ float wave_max(float v) {
 // Strict left-to-right f32 sum of n floats held in LDS, executed redundantly by every lane of the calling
 // wavefront (uniform addresses -> LDS broadcast).  SQ = true sums x*x (InferenceCore.rmsnorm :41).
 template <bool SQ>
+__device__ __forceinline__ float seq_add4(float s, const float4& a) {
+    if (SQ) { s = s + a.x * a.x; s = s + a.y * a.y; s = s + a.z * a.z; s = s + a.w * a.w; }
+    else { s = s + a.x; s = s + a.y; s = s + a.z; s = s + a.w; }
+    return s;
+}
+template <bool SQ>
 __device__ __forceinline__ float seq_sum_lds(const float* v, int n) {
     float s = 0.f;
     int i = 0;
-    for (; i + 4 <= n; i += 4) {
-        const float4 a = *reinterpret_cast<const float4*>(v + i);
-        if (SQ) { s = s + a.x * a.x; s = s + a.y * a.y; s = s + a.z * a.z; s = s + a.w * a.w; }
-        else { s = s + a.x; s = s + a.y; s = s + a.z; s = s + a.w; }
+    if (n >= 16) {                                     // software pipeline: the next 8 elements are in flight
+        float4 a0 = *reinterpret_cast<const float4*>(v), a1 = *reinterpret_cast<const float4*>(v + 4);
+        for (; i + 16 <= n; i += 8) {
+            const float4 b0 = *reinterpret_cast<const float4*>(v + i + 8), b1 = *reinterpret_cast<const float4*>(v + i + 12);
+            s = seq_add4<SQ>(s, a0); s = seq_add4<SQ>(s, a1);
+            a0 = b0; a1 = b1;
+        }
+        s = seq_add4<SQ>(s, a0); s = seq_add4<SQ>(s, a1);
+        i += 8;
     }
+    for (; i + 4 <= n; i += 4) s = seq_add4<SQ>(s, *reinterpret_cast<const float4*>(v + i));
     for (; i < n; ++i) s = SQ ? s + v[i] * v[i] : s + v[i];
     return s;
 }
@@ -320,18 +334,19 @@ __global__ __launch_bounds__(MV_THREADS, 4) void matvec_q8t_kernel(const MatvecA
             for (int m = 0; m < NM; ++m)
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[(size_t)m * a.ng * 64 + g * 64 + lane], 1.0f, acc[m], 0, 0, 0);
         MV_STAMP(17 + 2 * it, lane == 0 && it < 4);
-        if ((lane & 15) == 0) {                       // D[i][j]: row i = 4*(lane>>4) + reg, all 16 columns identical
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = strip * 16 + 4 * (lane >> 4) + r;
-                if (row < a.rows) {
-                    if (EPI == EPI_STORE) a.out[row] = acc[0][r];
-                    if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + acc[0][r] : acc[0][r];
-                    if (EPI == EPI_SWIGLU) {          // InferenceCore.java:155-158, exp in double
-                        float gte = acc[0][r];
-                        gte = gte / (float)(1.0 + exp(-(double)gte));
-                        a.out[row] = gte * acc[NM - 1][r];
-                    }
+        // D[i][j]: row i = 4*(lane>>4) + reg, all 16 columns identical.  Lane l takes row (l & 3) of its own group
+        // when (l & 15) < 4, so the 16 rows of the strip are finished by 16 lanes in parallel (one double exp each).
+        if ((lane & 15) < 4) {
+            const int r = lane & 3;
+            const int row = strip * 16 + 4 * (lane >> 4) + r;
+            if (row < a.rows) {
+                const float v0 = r == 0 ? acc[0][0] : r == 1 ? acc[0][1] : r == 2 ? acc[0][2] : acc[0][3];
+                if (EPI == EPI_STORE) a.out[row] = v0;
+                if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + v0 : v0;
+                if (EPI == EPI_SWIGLU) {                  // InferenceCore.java:155-158, exp in double
+                    const float v1 = r == 0 ? acc[NM - 1][0] : r == 1 ? acc[NM - 1][1] : r == 2 ? acc[NM - 1][2] : acc[NM - 1][3];
+                    const float gte = v0 / (float)(1.0 + exp(-(double)v0));
+                    a.out[row] = gte * v1;
                 }
             }
         }
@@ -403,9 +418,11 @@ constexpr int ATT_TT = 64;   // timesteps per score workgroup
 
 static __global__ void attn_scores_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads;
+    const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads, half = hs >> 1;
     float* q_s = sm;                         // [kvmul][hs]
-    float* kt = q_s + kvmul * hs;            // [ATT_TT][hs + 1]
+    float* kt = q_s + kvmul * hs;            // [ATT_TT][hs + 4]: float4 rows, conflict-free for 16-lane b128 groups
+    float* cr_s = kt + ATT_TT * (hs + 4);    // [hs/2]
+    float* ci_s = cr_s + half;               // [hs/2]
     const int t = threadIdx.x, nthr = blockDim.x;
     const int sp = blockIdx.x, kvh = blockIdx.y;
     const int pos = a.dyn[1];
@@ -413,82 +430,155 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
     if (t0 > pos) return;
     const int t1 = min(pos + 1, t0 + ATT_TT);
     const bool owns_pos = (t1 == pos + 1);
-    const int pitch = hs + 1;
-    // raw q of the group's heads, raw k of this kv head (owner only, into its tile row)
-    for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.qkv[(kvh * kvmul) * hs + i];
+    const int pitch = hs + 4;
     float* krow = kt + (pos - t0) * pitch;
-    if (owns_pos) for (int i = t; i < hs; i += nthr) krow[i] = a.qkv[a.q_dim + kvh * hs + i];
+    // ---- ONE global round trip: raw q of the group's heads, raw k/v of this kv head (owner), the RoPE row of
+    // `pos` and the K tile all go to registers first, then to LDS.
+    const int q4 = hs >> 2;
+    const int nrows_cache = owns_pos ? (t1 - 1 - t0) : (t1 - t0);
+    const int nk4 = nrows_cache * q4;                         // float4s of the K tile that come from the cache
+    constexpr int KMAX = 16;
+    float4 kreg[KMAX];
+    const int per = (nk4 + nthr - 1) / nthr;
+#pragma unroll
+    for (int u = 0; u < KMAX; ++u) {
+        const int i = t + u * nthr;
+        if (u < per && i < nk4) kreg[u] = *reinterpret_cast<const float4*>(a.kcache + (size_t)(t0 + i / q4) * a.kv_dim + kvh * hs + 4 * (i % q4));
+    }
+    for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.qkv[(kvh * kvmul) * hs + i];
+    for (int i = t; i < half; i += nthr) { cr_s[i] = a.rope_cr[(size_t)pos * half + i]; ci_s[i] = a.rope_ci[(size_t)pos * half + i]; }
+    float vraw = 0.f;
+    if (owns_pos) {
+        for (int i = t; i < hs; i += nthr) krow[i] = a.qkv[a.q_dim + kvh * hs + i];
+        if (t < hs) vraw = a.qkv[a.q_dim + a.kv_dim + kvh * hs + t];
+    }
+    if (per > KMAX) {                                         // generic fallback (few threads): straight to LDS
+        for (int i = t; i < nk4; i += nthr) {
+            const float4 v = *reinterpret_cast<const float4*>(a.kcache + (size_t)(t0 + i / q4) * a.kv_dim + kvh * hs + 4 * (i % q4));
+            *reinterpret_cast<float4*>(kt + (i / q4) * pitch + 4 * (i % q4)) = v;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < KMAX; ++u) {
+            const int i = t + u * nthr;
+            if (u < per && i < nk4) *reinterpret_cast<float4*>(kt + (i / q4) * pitch + 4 * (i % q4)) = kreg[u];
+        }
+    }
     __syncthreads();
     if (a.arch == 1) {
         if (t < kvmul) head_rmsnorm_1t(q_s + t * hs, a.qnorm, hs, a.eps);
         if (owns_pos && t == kvmul) head_rmsnorm_1t(krow, a.knorm, hs, a.eps);
         __syncthreads();
     }
-    const float* cr = a.rope_cr + (size_t)pos * (hs >> 1);
-    const float* ci = a.rope_ci + (size_t)pos * (hs >> 1);
-    for (int h = 0; h < kvmul; ++h) rope_head(q_s + h * hs, hs, cr, ci, a.arch, t, nthr);
-    if (owns_pos) rope_head(krow, hs, cr, ci, a.arch, t, nthr);
-    // K tile rows t0 .. t1-1 from the cache (all but the row of `pos`, which is in LDS already)
-    const int nrows_cache = owns_pos ? (t1 - 1 - t0) : (t1 - t0);
-    const int q4 = hs >> 2;
-    for (int i = t; i < nrows_cache * q4; i += nthr) {
-        const int r = i / q4, c = i % q4;
-        const float4 v = *reinterpret_cast<const float4*>(a.kcache + (size_t)(t0 + r) * a.kv_dim + kvh * hs + 4 * c);
-        float* d = kt + r * pitch + 4 * c;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
+    for (int h = 0; h < kvmul; ++h) rope_head(q_s + h * hs, hs, cr_s, ci_s, a.arch, t, nthr);
+    if (owns_pos) rope_head(krow, hs, cr_s, ci_s, a.arch, t, nthr);
     __syncthreads();
-    if (owns_pos) {                              // KV write, InferenceCore.java:92-93
-        for (int i = t; i < hs; i += nthr) {
-            a.kcache[(size_t)pos * a.kv_dim + kvh * hs + i] = krow[i];
-            a.vcache[(size_t)pos * a.kv_dim + kvh * hs + i] = a.qkv[a.q_dim + a.kv_dim + kvh * hs + i];
-        }
+    if (owns_pos && t < hs) {                    // KV write, InferenceCore.java:92-93
+        a.kcache[(size_t)pos * a.kv_dim + kvh * hs + t] = krow[t];
+        a.vcache[(size_t)pos * a.kv_dim + kvh * hs + t] = vraw;
     }
     const int hq = t >> 6, r = t & 63;           // wavefront = query head of the group, lane = timestep
     if (hq < kvmul && t0 + r < t1) {
         const float* q = q_s + hq * hs;
         const float* kk = kt + r * pitch;
-        float score = 0.f;
-        for (int j = 0; j < hs; ++j) score = score + q[j] * kk[j];
+        float score = 0.f;                           // strict j order, mul then add (FloatTensor.scalarDot)
+        float4 qv = *reinterpret_cast<const float4*>(q), kv = *reinterpret_cast<const float4*>(kk);
+        for (int j = 4; j < hs; j += 4) {            // software pipeline: next float4 pair in flight
+            const float4 qn = *reinterpret_cast<const float4*>(q + j), kn = *reinterpret_cast<const float4*>(kk + j);
+            score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
+            qv = qn; kv = kn;
+        }
+        score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
         const float sqrt_hs = (float)sqrt((double)hs);
         a.att[(size_t)(kvh * kvmul + hq) * a.ctx + t0 + r] = score / sqrt_hs;
     }
 }
 
-// Decode attention, part 2: softmax + weighted V sum.   Grid = n_heads x ceil(hs/64), block = 64.
+// Decode attention, part 2: softmax + weighted V sum.   Grid = n_heads x hs/16, block = 256.
 //   FloatTensor.softmaxInPlace :211-219 (max, exp in double, strict sum, divide); saxpyInPlace :221-227 with
-//   t ascending: xb[j] = a_t * v[t][j] + xb[j].  Dynamic LDS: e[ctx].
-static __global__ __launch_bounds__(64) void attn_softmax_pv_kernel(const AttnArgs a) {
+//   t ascending: xb[j] = a_t * v[t][j] + xb[j].
+// A workgroup owns 16 output columns of one head.  All 256 threads put the V slab [n][16] in flight at once while the
+// head's softmax is computed (elementwise parts on all threads, the strict sum on one wavefront); the products
+// a_t * v_tj are rounded on the VALU and added in order on the MFMA pipe (16x16x4, B = 1.0).
+//   Dynamic LDS: e[ctx] | vbuf[PV_ROWS][16]; contexts longer than PV_ROWS are processed in slabs of PV_ROWS rows.
+constexpr int PV_COLS = 16;
+constexpr int PV_ROWS = 1024;
+
+static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float e_s[];
     const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads;
-    const int nj = (hs + 63) / 64;
-    const int h = blockIdx.x / nj, j = (blockIdx.x % nj) * 64 + threadIdx.x;
-    const int lane = threadIdx.x, kvh = h / kvmul;
+    const int nj = hs / PV_COLS;
+    const int h = blockIdx.x / nj, j0 = (blockIdx.x % nj) * PV_COLS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kvh = h / kvmul;
     const int n = a.dyn[1] + 1;
-    const float* sc = a.att + (size_t)h * a.ctx;
-    float mx = -INFINITY;
-    for (int i = lane; i < n; i += 64) { const float s = sc[i]; e_s[i] = s; mx = fmaxf(mx, s); }
-    mx = wave_max(mx);
-    __syncthreads();
-    for (int i = lane; i < n; i += 64) e_s[i] = (float)exp((double)(e_s[i] - mx));
-    __syncthreads();
-    const float sum = seq_sum_lds<false>(e_s, n);
-    __syncthreads();
-    for (int i = lane; i < n; i += 64) e_s[i] = e_s[i] / sum;
-    __syncthreads();
-    if (j < hs) {
-        const float* v = a.vcache + kvh * hs + j;
-        float acc = 0.f;
-        int tt = 0;
-        for (; tt + 8 <= n; tt += 8) {
-            float vv[8];
+    float* vbuf = e_s + ((a.ctx + 3) & ~3);
+    const float* vbase = a.vcache + kvh * hs + j0;
+    constexpr int SU = PV_ROWS * 4 / 256;         // thread = (row t>>2 + 64u, column quad t&3)
+    float4 sreg[SU];
+    auto stage_issue = [&](int r0, int nr) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = v[(size_t)(tt + u) * a.kv_dim];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = e_s[tt + u] * vv[u] + acc;
+        for (int u = 0; u < SU; ++u) {
+            const int row = (t >> 2) + 64 * u;
+            if (row < nr) sreg[u] = *reinterpret_cast<const float4*>(vbase + (size_t)(r0 + row) * a.kv_dim + 4 * (t & 3));
         }
-        for (; tt < n; ++tt) acc = e_s[tt] * v[(size_t)tt * a.kv_dim] + acc;
-        a.xb[h * hs + j] = acc;
+    };
+    auto stage_commit = [&](int nr) {
+#pragma unroll
+        for (int u = 0; u < SU; ++u)
+            if ((t >> 2) + 64 * u < nr) *reinterpret_cast<float4*>(vbuf + 4 * (t + 256 * u)) = sreg[u];
+    };
+    __shared__ float red_s[8];
+    ATT_STAMP(0);
+    stage_issue(0, min(n, PV_ROWS));
+    ATT_STAMP(1);
+    {   // softmax of the head
+        const float* sc = a.att + (size_t)h * a.ctx;
+        float mx = -INFINITY;
+        for (int i = t; i < n; i += 256) { const float s = sc[i]; e_s[i] = s; mx = fmaxf(mx, s); }
+        mx = wave_max(mx);
+        if (lane == 0) red_s[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));
+        ATT_STAMP(2);
+        for (int i = t; i < n; i += 256) e_s[i] = (float)exp((double)(e_s[i] - mx));
+        __syncthreads();
+        ATT_STAMP(3);
+        if (wave == 0) { const float sum = seq_sum_lds<false>(e_s, n); if (lane == 0) red_s[4] = sum; }
+        __syncthreads();
+        ATT_STAMP(4);
+        const float sum = red_s[4];
+        for (int i = t; i < n; i += 256) e_s[i] = e_s[i] / sum;
+    }
+    stage_commit(min(n, PV_ROWS));
+    __syncthreads();
+    ATT_STAMP(5);
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < n; r0 += PV_ROWS) {
+        const int nr = min(PV_ROWS, n - r0);
+        if (r0 > 0) { __syncthreads(); stage_issue(r0, nr); stage_commit(nr); __syncthreads(); }
+        if (wave == 0) {                               // lane l = column l&15, timestep 4g + (l>>4)
+            const int col = lane & 15, k = lane >> 4;
+            const float* ap = e_s + r0;
+            int g = 0;
+            for (; 4 * g + 16 <= nr; g += 4) {          // 4 MFMAs per iteration, operands fetched first
+                float p[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int r = 4 * (g + u) + k; p[u] = ap[r] * vbuf[r * PV_COLS + col]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p[u], 1.0f, acc, 0, 0, 0);
+            }
+            for (; 4 * g < nr; ++g) {
+                const int r = 4 * g + k;
+                const float p = r < nr ? ap[r] * vbuf[r * PV_COLS + col] : 0.f;   // +0 pads the last group
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p, 1.0f, acc, 0, 0, 0);
+            }
+        }
+    }
+    ATT_STAMP(6);
+    // D[row][col]: row = column index of the slab = 4*(lane>>4) + reg; every MFMA column holds the same chain
+    if (wave == 0 && (lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.xb[h * hs + j0 + 4 * (lane >> 4) + r] = acc[r];
     }
 }
 
