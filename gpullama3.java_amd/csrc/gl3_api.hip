@@ -246,6 +246,7 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     if (desc->struct_size != sizeof(gl3_model_desc)) { g_create_err = "gl3_model_desc.struct_size mismatch"; return GL3_E_ARG; }
     gl3_ctx* ctx = new gl3_ctx();
     ctx->d = *desc;
+    ctx->n_seqs = desc->n_seqs < 1 ? 1 : desc->n_seqs;
     const gl3_model_desc& d = ctx->d;
     auto bail = [&](int32_t code, const std::string& msg) { g_create_err = msg.empty() ? ctx->err : msg; gl3_destroy(ctx); return code; };
     const double t0 = now_ms();
@@ -286,7 +287,8 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
         if (d.arch == GL3_ARCH_QWEN3) { TRY(dmalloc(ctx, &L.qnorm, d.head_size)); TRY(dmalloc(ctx, &L.knorm, d.head_size)); }
     }
     TRY(dmalloc(ctx, &ctx->out_norm, d.dim));
-    const size_t kvn = (size_t)d.n_layers * d.ctx * ctx->kv_dim_l;
+    ctx->kv_seq_stride = (size_t)d.n_layers * d.ctx * ctx->kv_dim_l;
+    const size_t kvn = ctx->kv_seq_stride * ctx->n_seqs;
     TRY(dmalloc(ctx, &ctx->kcache, kvn));
     TRY(dmalloc(ctx, &ctx->vcache, kvn));
     TRYHIP(hipMemset(ctx->kcache, 0, kvn * 4));
@@ -562,16 +564,18 @@ int32_t gl3_forward_decode(gl3_ctx* ctx, int32_t token, int32_t pos, float* logi
     return GL3_OK;
 }
 
-int32_t gl3_forward_prefill(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t start_pos) {
+int32_t gl3_forward_prefill_seq(gl3_ctx* ctx, int32_t seq, const int32_t* tokens, int32_t n, int32_t start_pos) {
     if (!ctx) return GL3_E_ARG;
     if (!tokens || n < 0) GL3_FAIL(GL3_E_ARG, "bad token array");
     if (!ctx->finalized) GL3_FAIL(GL3_E_STATE, "forward before gl3_finalize");
+    if (seq < 0 || seq >= ctx->n_seqs) GL3_FAIL(GL3_E_ARG, "sequence id out of range");
     if (start_pos < 0 || start_pos + n > ctx->d.ctx) GL3_FAIL(GL3_E_ARG, "prefill range outside the KV cache");
     if (n == 0) return GL3_OK;
     if (ctx->pf) {
         if (n > ctx->d.max_batch) GL3_FAIL(GL3_E_ARG, "prefill chunk larger than max_batch");
-        return gl3_prefill_run(ctx, tokens, n, start_pos);
+        return gl3_prefill_run(ctx, seq, tokens, n, start_pos);
     }
+    if (seq != 0) GL3_FAIL(GL3_E_UNSUPPORTED, "sequences other than 0 need max_batch > 1");
     // max_batch <= 1: sequential single-token prefill without logits
     // (TornadoVMMasterPlanPrefillDecode.tornadoVMForwardPrefill, J/tornadovm/TornadoVMMasterPlanPrefillDecode.java:116)
     for (int i = 0; i < n; ++i) {
@@ -581,6 +585,26 @@ int32_t gl3_forward_prefill(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int3
         GL3_HIP(hipStreamSynchronize(ctx->stream));
     }
     return GL3_OK;
+}
+
+int32_t gl3_forward_prefill(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t start_pos) {
+    return gl3_forward_prefill_seq(ctx, 0, tokens, n, start_pos);
+}
+
+int32_t gl3_forward_decode_batch(gl3_ctx* ctx, const int32_t* tokens, const int32_t* seq_ids, const int32_t* positions, int32_t n,
+                                 float* logits_out, int32_t* argmax_out) {
+    if (!ctx) return GL3_E_ARG;
+    if (!tokens || !seq_ids || !positions || n <= 0) GL3_FAIL(GL3_E_ARG, "bad batch arrays");
+    if (!ctx->finalized) GL3_FAIL(GL3_E_STATE, "forward before gl3_finalize");
+    if (!ctx->pf) GL3_FAIL(GL3_E_UNSUPPORTED, "batched decode needs max_batch > 1");
+    if (n > ctx->d.max_batch) GL3_FAIL(GL3_E_ARG, "batch larger than max_batch");
+    for (int i = 0; i < n; ++i) {
+        if (tokens[i] < 0 || tokens[i] >= ctx->d.vocab) GL3_FAIL(GL3_E_ARG, "token id out of range");
+        if (seq_ids[i] < 0 || seq_ids[i] >= ctx->n_seqs) GL3_FAIL(GL3_E_ARG, "sequence id out of range");
+        if (positions[i] < 0 || positions[i] >= ctx->d.ctx) GL3_FAIL(GL3_E_ARG, "position outside the KV cache (context length)");
+        for (int j = 0; j < i; ++j) if (seq_ids[j] == seq_ids[i]) GL3_FAIL(GL3_E_ARG, "duplicate sequence id in one batched step");
+    }
+    return gl3_decode_batch_run(ctx, tokens, seq_ids, positions, n, logits_out, argmax_out);
 }
 
 int32_t gl3_profile_decode(gl3_ctx* ctx, int32_t token, int32_t pos, gl3_kernel_times* out) {
@@ -656,14 +680,19 @@ int32_t gl3_get_layer_x(gl3_ctx* ctx, int32_t layer, float* out) {
     return GL3_OK;
 }
 
-int32_t gl3_get_kv(gl3_ctx* ctx, int32_t layer, int32_t pos, float* k_out, float* v_out) {
+int32_t gl3_get_kv_seq(gl3_ctx* ctx, int32_t seq, int32_t layer, int32_t pos, float* k_out, float* v_out) {
     if (!ctx || !k_out || !v_out) return GL3_E_ARG;
-    if (layer < 0 || layer >= ctx->d.n_layers || pos < 0 || pos >= ctx->d.ctx) GL3_FAIL(GL3_E_ARG, "layer/position out of range");
+    if (seq < 0 || seq >= ctx->n_seqs || layer < 0 || layer >= ctx->d.n_layers || pos < 0 || pos >= ctx->d.ctx)
+        GL3_FAIL(GL3_E_ARG, "sequence/layer/position out of range");
     GL3_HIP(hipSetDevice(ctx->d.device));
-    const size_t off = ((size_t)layer * ctx->d.ctx + pos) * ctx->kv_dim_l;
+    const size_t off = (size_t)seq * ctx->kv_seq_stride + ((size_t)layer * ctx->d.ctx + pos) * ctx->kv_dim_l;
     GL3_HIP(hipMemcpy(k_out, ctx->kcache + off, sizeof(float) * ctx->kv_dim_l, hipMemcpyDeviceToHost));
     GL3_HIP(hipMemcpy(v_out, ctx->vcache + off, sizeof(float) * ctx->kv_dim_l, hipMemcpyDeviceToHost));
     return GL3_OK;
+}
+
+int32_t gl3_get_kv(gl3_ctx* ctx, int32_t layer, int32_t pos, float* k_out, float* v_out) {
+    return gl3_get_kv_seq(ctx, 0, layer, pos, k_out, v_out);
 }
 
 int32_t gl3_get_buffer(gl3_ctx* ctx, int32_t which, float* out, uint64_t n) {
@@ -686,7 +715,7 @@ int32_t gl3_get_buffer(gl3_ctx* ctx, int32_t which, float* out, uint64_t n) {
 int32_t gl3_reset_kv(gl3_ctx* ctx) {
     if (!ctx) return GL3_E_ARG;
     GL3_HIP(hipSetDevice(ctx->d.device));
-    const size_t kvn = (size_t)ctx->d.n_layers * ctx->d.ctx * ctx->kv_dim_l;
+    const size_t kvn = ctx->kv_seq_stride * ctx->n_seqs;
     GL3_HIP(hipMemsetAsync(ctx->kcache, 0, kvn * 4, ctx->stream));
     GL3_HIP(hipMemsetAsync(ctx->vcache, 0, kvn * 4, ctx->stream));
     GL3_HIP(hipStreamSynchronize(ctx->stream));

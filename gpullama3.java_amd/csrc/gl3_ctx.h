@@ -58,7 +58,9 @@ struct gl3_ctx {
     float *rope_cr = nullptr, *rope_ci = nullptr;
     uint64_t rope_n = 0;
     // state
-    float *kcache = nullptr, *vcache = nullptr;   // [L][ctx][kv_dim_l]
+    float *kcache = nullptr, *vcache = nullptr;   // [n_seqs][L][ctx][kv_dim_l]
+    int n_seqs = 1;
+    size_t kv_seq_stride = 0;                     // floats per sequence
     float *x = nullptr, *qkv = nullptr, *xb = nullptr, *hb = nullptr, *logits = nullptr, *att = nullptr;
     float* taps = nullptr;                        // [L][dim] when GL3_FLAG_LAYER_TAPS
     int *dyn = nullptr, *argmax = nullptr;        // dyn[0] = token, dyn[1] = position
@@ -110,4 +112,6 @@ struct gl3_ctx {
 // gl3_prefill.hip
 int32_t gl3_prefill_alloc(gl3_ctx* ctx);
 void gl3_prefill_free(gl3_ctx* ctx);
-int32_t gl3_prefill_run(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t start_pos);
+int32_t gl3_prefill_run(gl3_ctx* ctx, int32_t seq, const int32_t* tokens, int32_t n, int32_t start_pos);
+int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t* seq_ids, const int32_t* positions, int32_t n,
+                             float* logits_out, int32_t* argmax_out);

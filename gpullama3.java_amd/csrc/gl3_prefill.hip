@@ -9,6 +9,8 @@
 // (Q8_0FloatTensor.java:90-123), and that is what the GEMM below does on CDNA4's int8 matrix cores:
 //   one v_mfma_i32_32x32x32_i8 = the int32 dot of one Q8_0 block for a 32-row x 32-token tile (exact), then
 //   acc = acc + float(isum) * (wScale * aScale) on the VALU, blocks ascending — the reference's f32 order.
+#include <vector>
+
 #include "gl3_ctx.h"
 #include "gl3_decode_kernels.h"
 
@@ -24,6 +26,10 @@ struct gl3_prefill_state {
     float* AO = nullptr;                // [M][q_dim] attention output
     float* HB = nullptr;                // [M][hidden]
     float* ATT = nullptr;               // [M][n_heads][ctx] scores
+    int32_t* seqpos = nullptr;          // [2][M]: sequence id, position of every token of the step
+    float* LOGITS = nullptr;            // [rows][vocab], grown on demand (batched decode)
+    int logits_rows = 0;
+    int32_t* amax = nullptr;            // [M]
     int maxk = 0;
 };
 
@@ -202,13 +208,15 @@ __global__ __launch_bounds__(256) void pf_gemm_kernel(const GemmArgs a) {
 // RMSNorm, InferenceCore.java:594-600).  Grid = (n_heads + n_kv_heads, ntok), block = 64.
 struct RopeArgs {
     float* QKV; int qkv_stride; float* kcache; float* vcache; const float* cr; const float* ci;
-    const float* qnorm; const float* knorm; int n_heads, n_kv_heads, hs, q_dim, kv_dim, start_pos, arch; float eps;
+    const float* qnorm; const float* knorm; int n_heads, n_kv_heads, hs, q_dim, kv_dim, arch; float eps;
+    const int32_t* seq; const int32_t* pos; size_t seq_stride;   // per-token sequence id / position; floats between sequences' caches
 };
 
 __global__ __launch_bounds__(64) void pf_rope_kv_kernel(const RopeArgs a) {
     __shared__ float v[256];
     const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, hs = a.hs;
-    const int pos = a.start_pos + b;
+    const int pos = a.pos[b];
+    const size_t soff = (size_t)a.seq[b] * a.seq_stride;
     const bool is_k = h >= a.n_heads;
     const int hk = is_k ? h - a.n_heads : h;
     float* src = a.QKV + (size_t)b * a.qkv_stride + (is_k ? a.q_dim + hk * hs : hk * hs);
@@ -225,8 +233,8 @@ __global__ __launch_bounds__(64) void pf_rope_kv_kernel(const RopeArgs a) {
     } else {
         const float* vsrc = a.QKV + (size_t)b * a.qkv_stride + a.q_dim + a.kv_dim + hk * hs;
         for (int i = t; i < hs; i += 64) {
-            a.kcache[(size_t)pos * a.kv_dim + hk * hs + i] = v[i];
-            a.vcache[(size_t)pos * a.kv_dim + hk * hs + i] = vsrc[i];
+            a.kcache[soff + (size_t)pos * a.kv_dim + hk * hs + i] = v[i];
+            a.vcache[soff + (size_t)pos * a.kv_dim + hk * hs + i] = vsrc[i];
         }
     }
 }
@@ -239,7 +247,8 @@ struct PfAttnArgs {
     const float* kcache; const float* vcache;
     float* att;                          // [ntok][n_heads][ctx]
     float* out; int out_stride;          // [ntok][q_dim]
-    int n_heads, n_kv_heads, hs, kv_dim, ctx, start_pos;
+    int n_heads, n_kv_heads, hs, kv_dim, ctx;
+    const int32_t* seq; const int32_t* pos; size_t seq_stride;
 };
 
 __global__ void pf_attn_scores_kernel(const PfAttnArgs a) {
@@ -249,7 +258,8 @@ __global__ void pf_attn_scores_kernel(const PfAttnArgs a) {
     float* kt = q_s + kvmul * hs;
     const int t = threadIdx.x, nthr = blockDim.x;
     const int sp = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
-    const int pos = a.start_pos + b;
+    const int pos = a.pos[b];
+    const float* kc = a.kcache + (size_t)a.seq[b] * a.seq_stride;
     const int t0 = sp * ATT_TT;
     if (t0 > pos) return;
     const int t1 = min(pos + 1, t0 + ATT_TT);
@@ -257,7 +267,7 @@ __global__ void pf_attn_scores_kernel(const PfAttnArgs a) {
     const int q4 = hs >> 2;
     for (int i = t; i < (t1 - t0) * q4; i += nthr) {
         const int r = i / q4, c = i % q4;
-        const float4 v = *reinterpret_cast<const float4*>(a.kcache + (size_t)(t0 + r) * a.kv_dim + kvh * hs + 4 * c);
+        const float4 v = *reinterpret_cast<const float4*>(kc + (size_t)(t0 + r) * a.kv_dim + kvh * hs + 4 * c);
         float* d = kt + r * pitch + 4 * c;
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(64) void pf_attn_softmax_pv_kernel(const PfAttnArgs
     const int nj = (hs + 63) / 64;
     const int h = blockIdx.x / nj, j = (blockIdx.x % nj) * 64 + threadIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x, kvh = h / kvmul;
-    const int n = a.start_pos + b + 1;
+    const int n = a.pos[b] + 1;
     const float* sc = a.att + ((size_t)b * a.n_heads + h) * a.ctx;
     float mx = -INFINITY;
     for (int i = lane; i < n; i += 64) { const float s = sc[i]; e_s[i] = s; mx = fmaxf(mx, s); }
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(64) void pf_attn_softmax_pv_kernel(const PfAttnArgs
     for (int i = lane; i < n; i += 64) e_s[i] = e_s[i] / sum;
     __syncthreads();
     if (j < hs) {
-        const float* v = a.vcache + kvh * hs + j;
+        const float* v = a.vcache + (size_t)a.seq[b] * a.seq_stride + kvh * hs + j;
         float acc = 0.f;
         int tt = 0;
         for (; tt + 8 <= n; tt += 8) {
@@ -305,6 +315,32 @@ __global__ __launch_bounds__(64) void pf_attn_softmax_pv_kernel(const PfAttnArgs
         }
         for (; tt < n; ++tt) acc = e_s[tt] * v[(size_t)tt * a.kv_dim] + acc;
         a.out[(size_t)b * a.out_stride + h * hs + j] = acc;
+    }
+}
+
+// Greedy id per sequence: first index of the maximum of each logits row (FloatTensor.argmax :138-151).
+__global__ __launch_bounds__(1024) void pf_argmax_rows_kernel(const float* __restrict__ logits, int n, int32_t* __restrict__ out) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const float* v = logits + (size_t)blockIdx.x * n;
+    const int t = threadIdx.x;
+    float best = -INFINITY;
+    int idx = 0x7FFFFFFF;
+    for (int i = t; i < n; i += 1024) {
+        const float f = v[i];
+        if (f > best || (f == best && i < idx)) { best = f; idx = i; }
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ob = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(idx, m, 64);
+        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    if ((t & 63) == 0) { bv[t >> 6] = best; bi[t >> 6] = idx; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[blockIdx.x] = idx == 0x7FFFFFFF ? 0 : idx;
     }
 }
 
@@ -325,6 +361,8 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_HIP(hipMalloc((void**)&p->AO, M * ctx->q_dim * 4));
     GL3_HIP(hipMalloc((void**)&p->HB, M * d.hidden * 4));
     GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
+    GL3_HIP(hipMalloc((void**)&p->seqpos, 2 * M * sizeof(int32_t)));
+    GL3_HIP(hipMalloc((void**)&p->amax, M * sizeof(int32_t)));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     return GL3_OK;
@@ -334,7 +372,7 @@ void gl3_prefill_free(gl3_ctx* ctx) {
     gl3_prefill_state* p = ctx->pf;
     if (!p) return;
     auto f = [](void* q) { if (q) hipFree(q); };
-    f(p->tokens); f(p->X); f(p->XQ); f(p->XS); f(p->QKV); f(p->AO); f(p->HB); f(p->ATT);
+    f(p->tokens); f(p->X); f(p->XQ); f(p->XS); f(p->QKV); f(p->AO); f(p->HB); f(p->ATT); f(p->seqpos); f(p->LOGITS); f(p->amax);
     delete p;
     ctx->pf = nullptr;
 }
@@ -350,15 +388,13 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     hipLaunchKernelGGL((pf_gemm_kernel<EPI>), grid, dim3(256), 0, ctx->stream, a);
 }
 
-int32_t gl3_prefill_run(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t start_pos) {
+// All layers for n tokens whose (token, sequence, position) are already on the device.  max_pos = largest position.
+static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos) {
     gl3_prefill_state* p = ctx->pf;
     const gl3_model_desc& d = ctx->d;
-    if (d.tp_size > 1) GL3_FAIL(GL3_E_UNSUPPORTED, "batched prefill under tensor parallelism is not implemented: use max_batch = 1");
-    for (int i = 0; i < n; ++i)
-        if (tokens[i] < 0 || tokens[i] >= d.vocab) GL3_FAIL(GL3_E_ARG, "token id out of range");
-    GL3_HIP(hipSetDevice(d.device));
     hipStream_t s = ctx->stream;
-    GL3_HIP(hipMemcpyAsync(p->tokens, tokens, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    const int32_t* seq = p->seqpos;
+    const int32_t* pos = p->seqpos + p->max_batch;
     const int kvmul = d.n_heads / d.n_kv_heads;
     const int qkv_dim = ctx->q_dim + 2 * ctx->kv_dim;
     const size_t kv_layer = (size_t)d.ctx * ctx->kv_dim;
@@ -372,14 +408,14 @@ int32_t gl3_prefill_run(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t 
         RopeArgs ra{};
         ra.QKV = p->QKV; ra.qkv_stride = qkv_dim; ra.kcache = ctx->kcache + l * kv_layer; ra.vcache = ctx->vcache + l * kv_layer;
         ra.cr = ctx->rope_cr; ra.ci = ctx->rope_ci; ra.qnorm = L.qnorm; ra.knorm = L.knorm; ra.n_heads = d.n_heads;
-        ra.n_kv_heads = d.n_kv_heads; ra.hs = d.head_size; ra.q_dim = ctx->q_dim; ra.kv_dim = ctx->kv_dim; ra.start_pos = start_pos;
-        ra.arch = d.arch; ra.eps = d.rms_eps;
+        ra.n_kv_heads = d.n_kv_heads; ra.hs = d.head_size; ra.q_dim = ctx->q_dim; ra.kv_dim = ctx->kv_dim;
+        ra.arch = d.arch; ra.eps = d.rms_eps; ra.seq = seq; ra.pos = pos; ra.seq_stride = ctx->kv_seq_stride;
         hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(d.n_heads + d.n_kv_heads, n), dim3(64), 0, s, ra);
         PfAttnArgs aa{};
         aa.Q = p->QKV; aa.q_stride = qkv_dim; aa.kcache = ra.kcache; aa.vcache = ra.vcache; aa.att = p->ATT; aa.out = p->AO;
         aa.out_stride = ctx->q_dim; aa.n_heads = d.n_heads; aa.n_kv_heads = d.n_kv_heads; aa.hs = d.head_size; aa.kv_dim = ctx->kv_dim;
-        aa.ctx = d.ctx; aa.start_pos = start_pos;
-        const int nsplit = (start_pos + n + ATT_TT - 1) / ATT_TT;
+        aa.ctx = d.ctx; aa.seq = seq; aa.pos = pos; aa.seq_stride = ctx->kv_seq_stride;
+        const int nsplit = (max_pos + 1 + ATT_TT - 1) / ATT_TT;
         const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
         hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, d.n_kv_heads, n), dim3(64 * kvmul), sm1, s, aa);
         hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(d.n_heads * ((d.head_size + 63) / 64), n), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
@@ -393,8 +429,64 @@ int32_t gl3_prefill_run(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t 
                            p->XQ, p->XS, p->maxk);
         launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, p->X, d.dim);
     }
+    GL3_HIP(hipGetLastError());
+    return GL3_OK;
+}
+
+static int32_t pf_stage_tokens(gl3_ctx* ctx, const int32_t* tokens, const int32_t* seqs, const int32_t* poss, int n) {
+    gl3_prefill_state* p = ctx->pf;
+    GL3_HIP(hipMemcpyAsync(p->tokens, tokens, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    GL3_HIP(hipMemcpyAsync(p->seqpos, seqs, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    GL3_HIP(hipMemcpyAsync(p->seqpos + p->max_batch, poss, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    return GL3_OK;
+}
+
+int32_t gl3_prefill_run(gl3_ctx* ctx, int32_t seq, const int32_t* tokens, int32_t n, int32_t start_pos) {
+    gl3_prefill_state* p = ctx->pf;
+    const gl3_model_desc& d = ctx->d;
+    if (d.tp_size > 1) GL3_FAIL(GL3_E_UNSUPPORTED, "batched prefill under tensor parallelism is not implemented: use max_batch = 1");
+    for (int i = 0; i < n; ++i)
+        if (tokens[i] < 0 || tokens[i] >= d.vocab) GL3_FAIL(GL3_E_ARG, "token id out of range");
+    GL3_HIP(hipSetDevice(d.device));
+    std::vector<int32_t> seqs(n, seq), poss(n);
+    for (int i = 0; i < n; ++i) poss[i] = start_pos + i;
+    int32_t r = pf_stage_tokens(ctx, tokens, seqs.data(), poss.data(), n);
+    if (r != GL3_OK) return r;
+    if ((r = pf_layers(ctx, n, start_pos + n - 1)) != GL3_OK) return r;
     // keep the decode path's x in step with the last prefilled token (parity tap gl3_get_x)
-    GL3_HIP(hipMemcpyAsync(ctx->x, p->X + (size_t)(n - 1) * d.dim, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, s));
+    GL3_HIP(hipMemcpyAsync(ctx->x, p->X + (size_t)(n - 1) * d.dim, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, ctx->stream));
+    GL3_HIP(hipStreamSynchronize(ctx->stream));
+    return GL3_OK;
+}
+
+// One decode step of n independent sequences = the prefill machinery over (token, sequence, position) triples +
+// final RMSNorm + vocab projection for every row (the n matvecs become one GEMM over the shared weights).
+int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t* seq_ids, const int32_t* positions, int32_t n,
+                             float* logits_out, int32_t* argmax_out) {
+    gl3_prefill_state* p = ctx->pf;
+    const gl3_model_desc& d = ctx->d;
+    if (d.tp_size > 1) GL3_FAIL(GL3_E_UNSUPPORTED, "batched decode under tensor parallelism is not implemented");
+    GL3_HIP(hipSetDevice(d.device));
+    if (p->logits_rows < n) {
+        if (p->LOGITS) hipFree(p->LOGITS);
+        p->LOGITS = nullptr; p->logits_rows = 0;
+        GL3_HIP(hipMalloc((void**)&p->LOGITS, (size_t)n * d.vocab * 4));
+        p->logits_rows = n;
+    }
+    int max_pos = 0;
+    for (int i = 0; i < n; ++i) max_pos = positions[i] > max_pos ? positions[i] : max_pos;
+    int32_t r = pf_stage_tokens(ctx, tokens, seq_ids, positions, n);
+    if (r != GL3_OK) return r;
+    if ((r = pf_layers(ctx, n, max_pos)) != GL3_OK) return r;
+    hipStream_t s = ctx->stream;
+    const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
+    hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq, s, p->X, d.dim, d.dim, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk);
+    launch_gemm<EPI_STORE>(ctx, ctx->wcls, nullptr, n, p->LOGITS, d.vocab);
+    if (argmax_out) {
+        hipLaunchKernelGGL(pf_argmax_rows_kernel, dim3(n), dim3(1024), 0, s, p->LOGITS, d.vocab, p->amax);
+        GL3_HIP(hipMemcpyAsync(argmax_out, p->amax, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    }
+    if (logits_out) GL3_HIP(hipMemcpyAsync(logits_out, p->LOGITS, (size_t)n * d.vocab * 4, hipMemcpyDeviceToHost, s));
     GL3_HIP(hipGetLastError());
     GL3_HIP(hipStreamSynchronize(s));
     return GL3_OK;

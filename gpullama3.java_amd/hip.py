@@ -29,7 +29,7 @@ class ModelDesc(C.Structure):
                 ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("head_size", C.c_int32),
                 ("vocab", C.c_int32), ("ctx", C.c_int32), ("rms_eps", C.c_float), ("weight_type", C.c_int32),
                 ("max_batch", C.c_int32), ("device", C.c_int32), ("tp_rank", C.c_int32), ("tp_size", C.c_int32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("n_seqs", C.c_int32)]
 
 
 class KernelTimes(C.Structure):
@@ -49,6 +49,9 @@ _SIGS = {  # symbol -> (restype, argtypes): exactly the declarations of include/
     "gl3_finalize": (C.c_int32, [C.c_void_p]),
     "gl3_forward_decode": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gl3_forward_prefill": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "gl3_forward_prefill_seq": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
+    "gl3_forward_decode_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gl3_get_kv_seq": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gl3_get_x": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "gl3_get_layer_x": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "gl3_get_kv": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

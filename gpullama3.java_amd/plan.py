@@ -29,7 +29,7 @@ def _p(a: np.ndarray):
 
 class HipMasterPlan:
     def __init__(self, model, prefill_batch_size: int = 1, device: int = 0, tp_rank: int = 0, tp_size: int = 1,
-                 flags: int = 0, unique_id: bytes | None = None, local_group=None):
+                 flags: int = 0, unique_id: bytes | None = None, local_group=None, n_seqs: int = 1):
         """model: synth.SynthModel-like — cfg, tensors {gguf name: (raw uint8, ggml_type, rows, cols)}, rope (cr, ci)."""
         L = hip.lib()
         c = model.cfg
@@ -37,7 +37,7 @@ class HipMasterPlan:
         self._ctx = C.c_void_p()
         d = hip.ModelDesc(C.sizeof(hip.ModelDesc), c.arch, c.dim, c.hidden, c.n_layers, c.n_heads, c.n_kv_heads,
                           c.head_size, c.vocab, c.ctx, c.rms_eps, model.wtype, prefill_batch_size, device, tp_rank,
-                          tp_size, flags)
+                          tp_size, flags, n_seqs)
         hip.check(L.gl3_create(C.byref(d), C.byref(self._ctx)))
         self.tp_size, self.tp_rank = tp_size, tp_rank
         self.max_batch = prefill_batch_size
@@ -89,6 +89,29 @@ class HipMasterPlan:
         """TornadoVMMasterPlanBatchPrefillDecode.tornadoVMForwardBatchPrefill(): one chunk, logits skipped."""
         t = np.ascontiguousarray(tokens, np.int32)
         hip.check(hip.lib().gl3_forward_prefill(self._ctx, _p(t), t.size, start_pos), self._ctx)
+
+    def prefill_seq(self, seq: int, tokens, start_pos: int = 0):
+        """Prefill sequence `seq` (its own KV cache) in chunks of max_batch."""
+        tokens = list(tokens)
+        b = max(1, self.max_batch)
+        for off in range(0, len(tokens), b):
+            t = np.ascontiguousarray(tokens[off:off + b], np.int32)
+            hip.check(hip.lib().gl3_forward_prefill_seq(self._ctx, seq, _p(t), t.size, start_pos + off), self._ctx)
+
+    def forward_decode_batch(self, tokens, seq_ids, positions, want_logits: bool = True):
+        """Static batched decode: one step for n independent sequences -> (logits [n][vocab] or None, greedy ids [n])."""
+        t = np.ascontiguousarray(tokens, np.int32); s = np.ascontiguousarray(seq_ids, np.int32); p = np.ascontiguousarray(positions, np.int32)
+        n = t.size
+        logits = np.empty((n, self.cfg.vocab), np.float32) if want_logits else None
+        ids = np.empty(n, np.int32)
+        hip.check(hip.lib().gl3_forward_decode_batch(self._ctx, _p(t), _p(s), _p(p), n, _p(logits) if want_logits else None, _p(ids)), self._ctx)
+        return logits, ids
+
+    def kv_seq(self, seq: int, layer: int, pos: int):
+        n = self.cfg.kv_dim // self.tp_size
+        k, v = np.empty(n, np.float32), np.empty(n, np.float32)
+        hip.check(hip.lib().gl3_get_kv_seq(self._ctx, seq, layer, pos, _p(k), _p(v)), self._ctx)
+        return k, v
 
     def freeTornadoExecutionPlan(self):
         if getattr(self, "_ctx", None) is not None and self._ctx:

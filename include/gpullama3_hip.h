@@ -108,6 +108,7 @@ typedef struct {
     int32_t tp_rank;        /* tensor-parallel rank of this process (0 when tp_size == 1) */
     int32_t tp_size;        /* tensor-parallel degree: heads / hidden units / vocab rows are split tp_size ways */
     uint32_t flags;         /* GL3_FLAG_* */
+    int32_t n_seqs;         /* independent sequences with their own KV cache (static batched decode); 0 or 1 = one */
 } gl3_model_desc;
 
 /* Per-kernel-class device time of one instrumented decode step (HIP events around every launch). */
@@ -161,10 +162,21 @@ GL3_API int32_t gl3_forward_decode(gl3_ctx* ctx, int32_t token, int32_t position
  * n <= max_batch. */
 GL3_API int32_t gl3_forward_prefill(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t start_pos);
 
+/* Same for sequence `seq` (0 <= seq < n_seqs); gl3_forward_prefill is seq = 0. */
+GL3_API int32_t gl3_forward_prefill_seq(gl3_ctx* ctx, int32_t seq, const int32_t* tokens, int32_t n, int32_t start_pos);
+
+/* Static batched decode (BASELINE.json config 5; announced for the reference as PR #129, README.md:74): one decode
+ * step for n independent sequences: token tokens[i] of sequence seq_ids[i] at position positions[i].  The n matvecs
+ * become one int8-MFMA GEMM over the shared weights (weights are streamed once per step).  n <= max_batch, distinct
+ * seq_ids.  logits_out: f32[n][vocab] or NULL; argmax_out: int32[n] (greedy id per sequence, sampled on the device) or NULL. */
+GL3_API int32_t gl3_forward_decode_batch(gl3_ctx* ctx, const int32_t* tokens, const int32_t* seq_ids, const int32_t* positions,
+                                         int32_t n, float* logits_out, int32_t* argmax_out);
+
 /* Parity taps. */
 GL3_API int32_t gl3_get_x(gl3_ctx* ctx, float* out /* f32[dim] */);
 GL3_API int32_t gl3_get_layer_x(gl3_ctx* ctx, int32_t layer, float* out /* f32[dim], needs GL3_FLAG_LAYER_TAPS */);
 GL3_API int32_t gl3_get_kv(gl3_ctx* ctx, int32_t layer, int32_t position, float* k_out, float* v_out /* f32[kvDim/tp] */);
+GL3_API int32_t gl3_get_kv_seq(gl3_ctx* ctx, int32_t seq, int32_t layer, int32_t position, float* k_out, float* v_out);
 
 /* Debug/parity tap: copy a scratch buffer of the LAST executed layer to the host.
  * which: 0 = raw q|k|v of the qkv projection, 1 = attention output xb, 2 = hb (SwiGLU output), 3 = logits. */

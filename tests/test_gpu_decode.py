@@ -137,3 +137,37 @@ def test_batched_prefill_is_bit_identical_to_the_cpu_path(pkg, orc, planmod, cfg
     with pytest.raises(hip.Gl3Error):
         plan.tornadoVMForwardBatchPrefill(toks[:batch + 1] if batch + 1 <= len(toks) else list(toks) * 300, 0)   # chunk > max_batch
     plan.freeTornadoExecutionPlan()
+
+
+@pytest.mark.parametrize("cfg,nseq", [("tiny-qwen3", 5), ("mid-llama", 3)])
+def test_static_batched_decode_matches_independent_cpu_runs(pkg, orc, planmod, cfg, nseq):
+    """BASELINE config 5 shape of work: n independent sequences (own KV caches, different prompt lengths) advance one
+    token per step through ONE batched GEMM pass; every sequence's logits must equal its own CPU run bit for bit."""
+    plan_mod, hip = planmod
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], seed=44)
+    plan = plan_mod.HipMasterPlan(m, prefill_batch_size=16, n_seqs=nseq)
+    oracles = [orc.COracle(m) for _ in range(nseq)]
+    rng = np.random.default_rng(3)
+    lens = [3 + 2 * i for i in range(nseq)]
+    prompts = [rng.integers(0, m.cfg.vocab, n).tolist() for n in lens]
+    for s in range(nseq):
+        plan.prefill_seq(s, prompts[s], 0)
+        oracles[s].prefill(prompts[s], 0)
+    cur = [int(rng.integers(0, m.cfg.vocab)) for _ in range(nseq)]
+    pos = list(lens)
+    for step in range(4):
+        order = list(range(nseq))
+        if step % 2:
+            order.reverse()                      # batch row order is arbitrary
+        logits, ids = plan.forward_decode_batch([cur[s] for s in order], order, [pos[s] for s in order])
+        for row, s in enumerate(order):
+            ref = oracles[s].forward(cur[s], pos[s])
+            assert np.array_equal(logits[row], ref), (step, s)
+            assert ids[row] == orc.argmax(ref)
+            cur[s], pos[s] = int(ids[row]), pos[s] + 1          # greedy continuation per sequence
+    k, v = plan.kv_seq(nseq - 1, 0, lens[-1])
+    ko, vo = oracles[-1].kv(0, lens[-1])
+    assert np.array_equal(k, ko) and np.array_equal(v, vo)
+    with pytest.raises(hip.Gl3Error):
+        plan.forward_decode_batch([1, 2], [0, 0], [pos[0], pos[0]])       # duplicate sequence id
+    plan.freeTornadoExecutionPlan()
