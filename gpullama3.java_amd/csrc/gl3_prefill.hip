@@ -104,9 +104,7 @@ __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restr
 
 // ---------------------------------------------------------------------------------------------------
 // Batched Q8_0 matmul: out[b][n] = sum_blocks float(isum) * (wScale * aScale), blocks ascending
-// (FloatTensor.matmul(context, ...) :102-111 with dotQ8Activation).  Workgroup = 4 wavefronts = 32 weight rows x
-// 256 tokens; wavefront = 32 rows x 64 tokens = two 32x32 int8 MFMA tiles per Q8_0 block.
-// A operand (weights) and its 16 per-lane scales come straight from the Q8T tiles (L2), B operand from XQ.
+// (FloatTensor.matmul(context, ...) :102-111 with dotQ8Activation).
 struct GemmArgs {
     const uint8_t* w; const uint8_t* w2;  // Q8T matrices (w2: up projection for the SwiGLU epilogue)
     int rows, ng, nb;                     // valid rows, tile groups per strip, real blocks per row (k/32)
@@ -115,90 +113,176 @@ struct GemmArgs {
     float* out; int out_stride;           // EPI_STORE / EPI_SWIGLU: out[b*stride + row]; EPI_RESID: out +=
 };
 
-template <int EPI>
-__global__ __launch_bounds__(256) void pf_gemm_kernel(const GemmArgs a) {
-    constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tl = lane & 31, hi = lane >> 5;
-    const int rg = blockIdx.y;                         // 32-row group
-    const int tok0 = blockIdx.x * 256 + wave * 64;     // this wavefront's 64 tokens
-    if (tok0 >= a.ntok) return;
-    // A-fragment addressing: weight row rg*32 + tl, 16-byte half `hi` of block blk
-    const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
-    const uint8_t* wrow[NM];
-    const uint8_t* wsc[NM][4];
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
-        const uint8_t* base = (m == 0 ? a.w : a.w2) + (size_t)(rg * 2) * strip_bytes;
-        wrow[m] = base + (size_t)(tl >> 4) * strip_bytes + (hi ? 1152 : 128) + 16 * (tl & 15);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)       // scales of rows 8q + 4hi + (0..3): 4 consecutive f16 in the tile's scale area
-            wsc[m][q] = base + (size_t)(q >> 1) * strip_bytes + 2 * (8 * (q & 1) + 4 * hi);
-    }
-    int tok[2];
-    const uint8_t* xq[2];
-    const float* xs[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        tok[tt] = min(a.ntok - 1, tok0 + 32 * tt + tl);
-        xq[tt] = a.XQ + (size_t)tok[tt] * a.maxk + 16 * hi;
-        xs[tt] = a.XS + (size_t)tok[tt] * (a.maxk >> 5);
-    }
-    float acc[NM][2][16];
-#pragma unroll
-    for (int m = 0; m < NM; ++m)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][tt][r] = 0.f;
+// LDS-tiled version: workgroup = 128 weight rows (64 gate + 64 up rows for the SwiGLU epilogue) x 128 tokens, 4
+// wavefronts in a 2 x 2 grid, each owning 64 rows x 64 tokens = four 32x32 int8 MFMA tiles.  K advances 4 blocks
+// (= one Q8T tile per 16-row strip) per stage; the next stage's operands travel HBM/L2 -> registers while the current
+// stage is consumed from LDS (double buffer).  LDS image per stage (36 KB):
+//   Aq[blk][half][128 rows][16 B] | As[blk][128 rows] f32 | Bq[blk][half][128 tokens][16 B] | Bs[blk][128 tokens] f32
+// so an MFMA fragment is one conflict-free ds_read_b128 and the 16 weight scales of a lane are four broadcast b128 reads.
+constexpr int GM_ROWS = 128, GM_TOK = 128, GM_KB = 4;
+constexpr int GM_STAGE_BYTES = GM_KB * 2 * GM_ROWS * 16 + GM_KB * GM_ROWS * 4 + GM_KB * 2 * GM_TOK * 16 + GM_KB * GM_TOK * 4;
 
-    for (int blk = 0; blk < a.nb; ++blk) {
-        const size_t toff = (size_t)(blk >> 2) * TILE_BYTES;
-        const int lsel = 16 * (blk & 3);
-        v4i_t bf[2];
-        float xsc[2];
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int RPM = GM_ROWS / NM;                  // output rows per matrix covered by this workgroup
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tl = lane & 31, hi = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;           // wavefront grid: rows wr*64.., tokens wc*64..
+    const int row0 = blockIdx.y * RPM;                 // first output row (per matrix)
+    const int tok0 = blockIdx.x * GM_TOK;
+    const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
+    const int nkb = a.ng;                              // K stages = tile groups per strip
+    const int nstrips = (a.rows + 15) >> 4;
+
+    // ---- global -> register staging of one K stage
+    // A: 8 strips x one tile (64 x f16 scales, 64 x 16 B lo, 64 x 16 B hi).  Thread t: lo/hi pieces t and t + 256 of the
+    // 512 (strip, lane-in-tile) pairs; scales: threads 0..63 take 8 f16 = (strip t>>3, lanes 8*(t&7)..+7).
+    v4i_t ra_lo[2], ra_hi[2], ra_sc, rb[4];
+    float4 rb_s;
+    auto gload = [&](int kb) {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            bf[tt] = *reinterpret_cast<const v4i_t*>(xq[tt] + 32 * blk);
-            xsc[tt] = xs[tt][blk];
+        for (int i = 0; i < 2; ++i) {
+            const int pr = t + 256 * i, sl = pr >> 6, lt = pr & 63;          // local strip 0..7, lane in tile
+            const int m = NM == 2 ? (sl >> 2) : 0;
+            const int strip = min(nstrips - 1, (row0 >> 4) + (NM == 2 ? (sl & 3) : sl));
+            const uint8_t* tile = (m == 0 ? a.w : a.w2) + (size_t)strip * strip_bytes + (size_t)kb * TILE_BYTES;
+            ra_lo[i] = *reinterpret_cast<const v4i_t*>(tile + 128 + 16 * lt);
+            ra_hi[i] = *reinterpret_cast<const v4i_t*>(tile + 1152 + 16 * lt);
+        }
+        if (t < 64) {
+            const int sl = t >> 3;
+            const int m = NM == 2 ? (sl >> 2) : 0;
+            const int strip = min(nstrips - 1, (row0 >> 4) + (NM == 2 ? (sl & 3) : sl));
+            const uint8_t* tile = (m == 0 ? a.w : a.w2) + (size_t)strip * strip_bytes + (size_t)kb * TILE_BYTES;
+            ra_sc = *reinterpret_cast<const v4i_t*>(tile + 16 * (t & 7));
+        }
+        // B: 128 tokens x 128 B of int8 (4 blocks) -> 1024 16-byte pieces, 4 per thread: piece = t + 256*i ->
+        // token = piece >> 3, 16-byte chunk c = piece & 7 (block c>>1, half c&1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = t + 256 * i, tk = min(a.ntok - 1, tok0 + (pc >> 3)), c = pc & 7;
+            rb[i] = *reinterpret_cast<const v4i_t*>(a.XQ + (size_t)tk * a.maxk + (size_t)kb * 128 + 16 * c);
+        }
+        if (t < GM_TOK) {
+            const int tk = min(a.ntok - 1, tok0 + t);
+            rb_s = *reinterpret_cast<const float4*>(a.XS + (size_t)tk * (a.maxk >> 5) + kb * 4);
+            // ragged K (k % 128 != 0): the padded blocks carry zero weights; zero their activation scale too
+            if (kb * 4 + 1 >= a.nb) rb_s.y = 0.f;
+            if (kb * 4 + 2 >= a.nb) rb_s.z = 0.f;
+            if (kb * 4 + 3 >= a.nb) rb_s.w = 0.f;
+        }
+    };
+    auto lstore = [&](int stage) {
+        uint8_t* base = smem + (size_t)stage * GM_STAGE_BYTES;
+        uint8_t* Aq = base;
+        float* As = reinterpret_cast<float*>(base + GM_KB * 2 * GM_ROWS * 16);
+        uint8_t* Bq = base + GM_KB * 2 * GM_ROWS * 16 + GM_KB * GM_ROWS * 4;
+        float* Bs = reinterpret_cast<float*>(Bq + GM_KB * 2 * GM_TOK * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pr = t + 256 * i, sl = pr >> 6, lt = pr & 63;
+            const int row = sl * 16 + (lt & 15), blk = lt >> 4;
+            *reinterpret_cast<v4i_t*>(Aq + ((size_t)(blk * 2 + 0) * GM_ROWS + row) * 16) = ra_lo[i];
+            *reinterpret_cast<v4i_t*>(Aq + ((size_t)(blk * 2 + 1) * GM_ROWS + row) * 16) = ra_hi[i];
+        }
+        if (t < 64) {
+            const int sl = t >> 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int lt = 8 * (t & 7) + j;
+                const uint32_t w = (uint32_t)ra_sc[j >> 1];
+                As[(lt >> 4) * GM_ROWS + sl * 16 + (lt & 15)] = h2f((uint16_t)((j & 1) ? (w >> 16) : (w & 0xFFFF)));
+            }
         }
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            const v4i_t af = *reinterpret_cast<const v4i_t*>(wrow[m] + toff + 16 * lsel);
-            float wsf[16];
+        for (int i = 0; i < 4; ++i) {
+            const int pc = t + 256 * i, tk = pc >> 3, c = pc & 7;
+            *reinterpret_cast<v4i_t*>(Bq + ((size_t)c * GM_TOK + tk) * 16) = rb[i];       // c = blk*2 + half
+        }
+        if (t < GM_TOK) { Bs[0 * GM_TOK + t] = rb_s.x; Bs[1 * GM_TOK + t] = rb_s.y; Bs[2 * GM_TOK + t] = rb_s.z; Bs[3 * GM_TOK + t] = rb_s.w; }
+    };
+
+    // wavefront's fragments: NM == 1: row frags rf = 0,1 at rows wr*64 + 32*rf; NM == 2: matrix m at local rows m*64 + wr*32
+    float acc[2][2][16];                               // [row frag or matrix][token frag][16]
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint2 s4 = *reinterpret_cast<const uint2*>(wsc[m][q] + toff + 2 * lsel);
-                wsf[4 * q + 0] = h2f((uint16_t)(s4.x & 0xFFFF)); wsf[4 * q + 1] = h2f((uint16_t)(s4.x >> 16));
-                wsf[4 * q + 2] = h2f((uint16_t)(s4.y & 0xFFFF)); wsf[4 * q + 3] = h2f((uint16_t)(s4.y >> 16));
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        if (kb + 1 < nkb) gload(kb + 1);
+        const uint8_t* base = smem + (size_t)(kb & 1) * GM_STAGE_BYTES;
+        const uint8_t* Aq = base;
+        const float* As = reinterpret_cast<const float*>(base + GM_KB * 2 * GM_ROWS * 16);
+        const uint8_t* Bq = base + GM_KB * 2 * GM_ROWS * 16 + GM_KB * GM_ROWS * 4;
+        const float* Bs = reinterpret_cast<const float*>(Bq + GM_KB * 2 * GM_TOK * 16);
+#pragma unroll 1
+        for (int blk = 0; blk < GM_KB; ++blk) {
+            v4i_t bf[2];
+            float xsc[2];
+#pragma unroll
+            for (int tf = 0; tf < 2; ++tf) {
+                const int tk = wc * 64 + tf * 32 + tl;
+                bf[tf] = *reinterpret_cast<const v4i_t*>(Bq + ((size_t)(blk * 2 + hi) * GM_TOK + tk) * 16);
+                xsc[tf] = Bs[blk * GM_TOK + tk];
             }
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                v16i_t c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[tt], c, 0, 0, 0);
+            for (int rf = 0; rf < 2; ++rf) {
+                const int lrow = NM == 2 ? rf * 64 + wr * 32 : wr * 64 + rf * 32;      // local row of this frag
+                const v4i_t af = *reinterpret_cast<const v4i_t*>(Aq + ((size_t)(blk * 2 + hi) * GM_ROWS + lrow + tl) * 16);
+                float wsf[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)          // result += isum * (wScale * aScale)
-                    acc[m][tt][r] = acc[m][tt][r] + (float)c[r] * (wsf[r] * xsc[tt]);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(As + blk * GM_ROWS + lrow + 8 * q + 4 * hi);
+                    wsf[4 * q] = w4.x; wsf[4 * q + 1] = w4.y; wsf[4 * q + 2] = w4.z; wsf[4 * q + 3] = w4.w;
+                }
+#pragma unroll
+                for (int tf = 0; tf < 2; ++tf) {
+                    v16i_t c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    c = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[tf], c, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)      // result += isum * (wScale * aScale), blocks ascending
+                        acc[rf][tf][r] = acc[rf][tf][r] + (float)c[r] * (wsf[r] * xsc[tf]);
+                }
             }
         }
+        if (kb + 1 < nkb) {
+            lstore((kb + 1) & 1);
+        }
+        __syncthreads();
     }
-    // C layout: token = lane & 31 (column), weight row = (r & 3) + 8 * (r >> 2) + 4 * hi
+    // ---- epilogue.  C layout: token = lane & 31 (column), weight row = (r & 3) + 8 * (r >> 2) + 4 * hi
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const int b = tok0 + 32 * tt + tl;
+    for (int tf = 0; tf < 2; ++tf) {
+        const int b = tok0 + wc * 64 + tf * 32 + tl;
         if (b >= a.ntok) continue;
+        if (EPI == EPI_SWIGLU) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (row >= a.rows) continue;
-            float* o = a.out + (size_t)b * a.out_stride + row;
-            if (EPI == EPI_STORE) *o = acc[0][tt][r];
-            if (EPI == EPI_RESID) *o = *o + acc[0][tt][r];
-            if (EPI == EPI_SWIGLU) {
-                float g = acc[0][tt][r];
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row >= a.rows) continue;
+                float g = acc[0][tf][r];
                 g = g / (float)(1.0 + exp(-(double)g));
-                *o = g * acc[NM - 1][tt][r];
+                a.out[(size_t)b * a.out_stride + row] = g * acc[1][tf][r];
             }
+        } else {
+#pragma unroll
+            for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + wr * 64 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row >= a.rows) continue;
+                    float* o = a.out + (size_t)b * a.out_stride + row;
+                    if (EPI == EPI_STORE) *o = acc[rf][tf][r];
+                    else *o = *o + acc[rf][tf][r];
+                }
         }
     }
 }
@@ -353,6 +437,7 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     const size_t M = d.max_batch;
     p->maxk = d.hidden > ctx->q_dim ? d.hidden : ctx->q_dim;
     if (d.dim > p->maxk) p->maxk = d.dim;
+    p->maxk = (p->maxk + 127) & ~127;
     GL3_HIP(hipMalloc((void**)&p->tokens, M * sizeof(int32_t)));
     GL3_HIP(hipMalloc((void**)&p->X, M * d.dim * 4));
     GL3_HIP(hipMalloc((void**)&p->XQ, M * p->maxk));
@@ -363,6 +448,9 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
     GL3_HIP(hipMalloc((void**)&p->seqpos, 2 * M * sizeof(int32_t)));
     GL3_HIP(hipMalloc((void**)&p->amax, M * sizeof(int32_t)));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GM_STAGE_BYTES));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GM_STAGE_BYTES));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GM_STAGE_BYTES));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     return GL3_OK;
@@ -383,9 +471,9 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     GemmArgs a{};
     a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.ng = w.ng; a.nb = w.k / 32;
     a.XQ = p->XQ; a.XS = p->XS; a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride;
-    // Q8T strips hold 16 rows; a 32-row group needs an even number of strips (padded rows are zero weights)
-    dim3 grid((ntok + 255) / 256, (w.nstrips + 1) / 2);
-    hipLaunchKernelGGL((pf_gemm_kernel<EPI>), grid, dim3(256), 0, ctx->stream, a);
+    constexpr int RPM = GM_ROWS / (EPI == EPI_SWIGLU ? 2 : 1);
+    dim3 grid((ntok + GM_TOK - 1) / GM_TOK, (w.rows + RPM - 1) / RPM);
+    hipLaunchKernelGGL((pf_gemm_kernel<EPI>), grid, dim3(256), 2 * GM_STAGE_BYTES, ctx->stream, a);
 }
 
 // All layers for n tokens whose (token, sequence, position) are already on the device.  max_pos = largest position.

@@ -1,0 +1,20 @@
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+pkg = ge.load_package()
+from importlib import import_module
+plan_mod = import_module(ge.PKG_NAME + ".plan")
+name = sys.argv[1] if len(sys.argv) > 1 else "llama-3-8b"
+nl = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+base = pkg.synth.CONFIGS[name]
+cfg = pkg.synth.ModelConfig(**{**base.__dict__, "n_layers": nl, "vocab": 4096, "ctx": 648})
+m = pkg.synth.make_torch(cfg, seed=1, device="cuda")
+plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=512)
+toks = pkg.javarand.bench_tokens(cfg.vocab, 512)
+plan.prefill(toks, 0)
+t0 = time.perf_counter()
+for _ in range(3):
+    plan.prefill(toks, 0)
+dt = (time.perf_counter() - t0) / 3
+print("pp512 %d layers: %.2f ms -> %.0f tok/s (x%d layers = %.1f ms / 32 layers)" % (nl, dt * 1e3, 512 / dt, nl, dt * 1e3 * 32 / nl))
