@@ -119,17 +119,27 @@ struct GemmArgs {
 // stage is consumed from LDS (double buffer).  LDS image per stage (36 KB):
 //   Aq[blk][half][128 rows][16 B] | As[blk][128 rows] f32 | Bq[blk][half][128 tokens][16 B] | Bs[blk][128 tokens] f32
 // so an MFMA fragment is one conflict-free ds_read_b128 and the 16 weight scales of a lane are four broadcast b128 reads.
-constexpr int GM_ROWS = 128, GM_TOK = 128, GM_KB = 4;
-constexpr int GM_STAGE_BYTES = GM_KB * 2 * GM_ROWS * 16 + GM_KB * GM_ROWS * 4 + GM_KB * 2 * GM_TOK * 16 + GM_KB * GM_TOK * 4;
+// RF = 32-row fragments per wavefront (2: 128-row workgroup tile for the wide matrices; 1: 64-row tile so that the
+// 4096-row wo / down projections still launch >= 256 workgroups at 512 tokens).  The SwiGLU epilogue always runs
+// RF = 1 over two matrices.
+constexpr int GM_TOK = 128, GM_KB = 4;
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__host__ __device__ constexpr int gm_stage_bytes(int arows) {
+    return GM_KB * 2 * arows * 16 + GM_KB * arows * 4 + GM_KB * 2 * GM_TOK * 16 + GM_KB * GM_TOK * 4;
+}
 
-template <int EPI>
+template <int EPI, int RF>
 __global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
-    constexpr int RPM = GM_ROWS / NM;                  // output rows per matrix covered by this workgroup
+    static_assert(NM * RF <= 2, "accumulator budget");
+    constexpr int AROWS = NM * RF * 64;                // weight rows staged per K stage (both matrices together)
+    constexpr int RPM = AROWS / NM;                    // output rows per matrix covered by this workgroup
+    constexpr int STAGE = gm_stage_bytes(AROWS);
+    constexpr int NAP = AROWS / 64;                    // (strip, lane) pairs per thread
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tl = lane & 31, hi = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;           // wavefront grid: rows wr*64.., tokens wc*64..
+    const int wr = wave >> 1, wc = wave & 1;           // wavefront grid: row half wr, tokens wc*64..
     const int row0 = blockIdx.y * RPM;                 // first output row (per matrix)
     const int tok0 = blockIdx.x * GM_TOK;
     const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
@@ -137,27 +147,24 @@ __global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
     const int nstrips = (a.rows + 15) >> 4;
 
     // ---- global -> register staging of one K stage
-    // A: 8 strips x one tile (64 x f16 scales, 64 x 16 B lo, 64 x 16 B hi).  Thread t: lo/hi pieces t and t + 256 of the
-    // 512 (strip, lane-in-tile) pairs; scales: threads 0..63 take 8 f16 = (strip t>>3, lanes 8*(t&7)..+7).
-    v4i_t ra_lo[2], ra_hi[2], ra_sc, rb[4];
+    // A: AROWS/16 strips x one tile (64 x f16 scales, 64 x 16 B lo, 64 x 16 B hi).  Thread t: lo/hi pieces
+    // t + 256 i of the (strip, lane-in-tile) pairs; scales: threads < AROWS/2 take 8 f16 = (strip t>>3, lanes 8*(t&7)..+7)
+    v4i_t ra_lo[NAP], ra_hi[NAP], ra_sc, rb[4];
     float4 rb_s;
+    auto tile_of = [&](int sl, int kb) -> const uint8_t* {   // sl: local strip 0..AROWS/16-1
+        const int m = NM == 2 ? (sl >> 2) : 0;
+        const int strip = min(nstrips - 1, (row0 >> 4) + (NM == 2 ? (sl & 3) : sl));
+        return (m == 0 ? a.w : a.w2) + (size_t)strip * strip_bytes + (size_t)kb * TILE_BYTES;
+    };
     auto gload = [&](int kb) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pr = t + 256 * i, sl = pr >> 6, lt = pr & 63;          // local strip 0..7, lane in tile
-            const int m = NM == 2 ? (sl >> 2) : 0;
-            const int strip = min(nstrips - 1, (row0 >> 4) + (NM == 2 ? (sl & 3) : sl));
-            const uint8_t* tile = (m == 0 ? a.w : a.w2) + (size_t)strip * strip_bytes + (size_t)kb * TILE_BYTES;
+        for (int i = 0; i < NAP; ++i) {
+            const int pr = t + 256 * i, lt = pr & 63;
+            const uint8_t* tile = tile_of(pr >> 6, kb);
             ra_lo[i] = *reinterpret_cast<const v4i_t*>(tile + 128 + 16 * lt);
             ra_hi[i] = *reinterpret_cast<const v4i_t*>(tile + 1152 + 16 * lt);
         }
-        if (t < 64) {
-            const int sl = t >> 3;
-            const int m = NM == 2 ? (sl >> 2) : 0;
-            const int strip = min(nstrips - 1, (row0 >> 4) + (NM == 2 ? (sl & 3) : sl));
-            const uint8_t* tile = (m == 0 ? a.w : a.w2) + (size_t)strip * strip_bytes + (size_t)kb * TILE_BYTES;
-            ra_sc = *reinterpret_cast<const v4i_t*>(tile + 16 * (t & 7));
-        }
+        if (t < AROWS / 2) ra_sc = *reinterpret_cast<const v4i_t*>(tile_of(t >> 3, kb) + 16 * (t & 7));
         // B: 128 tokens x 128 B of int8 (4 blocks) -> 1024 16-byte pieces, 4 per thread: piece = t + 256*i ->
         // token = piece >> 3, 16-byte chunk c = piece & 7 (block c>>1, half c&1)
 #pragma unroll
@@ -175,87 +182,103 @@ __global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
         }
     };
     auto lstore = [&](int stage) {
-        uint8_t* base = smem + (size_t)stage * GM_STAGE_BYTES;
+        uint8_t* base = smem + (size_t)stage * STAGE;
         uint8_t* Aq = base;
-        float* As = reinterpret_cast<float*>(base + GM_KB * 2 * GM_ROWS * 16);
-        uint8_t* Bq = base + GM_KB * 2 * GM_ROWS * 16 + GM_KB * GM_ROWS * 4;
+        float* As = reinterpret_cast<float*>(base + GM_KB * 2 * AROWS * 16);
+        uint8_t* Bq = base + GM_KB * 2 * AROWS * 16 + GM_KB * AROWS * 4;
         float* Bs = reinterpret_cast<float*>(Bq + GM_KB * 2 * GM_TOK * 16);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NAP; ++i) {
             const int pr = t + 256 * i, sl = pr >> 6, lt = pr & 63;
             const int row = sl * 16 + (lt & 15), blk = lt >> 4;
-            *reinterpret_cast<v4i_t*>(Aq + ((size_t)(blk * 2 + 0) * GM_ROWS + row) * 16) = ra_lo[i];
-            *reinterpret_cast<v4i_t*>(Aq + ((size_t)(blk * 2 + 1) * GM_ROWS + row) * 16) = ra_hi[i];
+            *reinterpret_cast<v4i_t*>(Aq + ((size_t)(blk * 2 + 0) * AROWS + row) * 16) = ra_lo[i];
+            *reinterpret_cast<v4i_t*>(Aq + ((size_t)(blk * 2 + 1) * AROWS + row) * 16) = ra_hi[i];
         }
-        if (t < 64) {
+        if (t < AROWS / 2) {
             const int sl = t >> 3;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int lt = 8 * (t & 7) + j;
                 const uint32_t w = (uint32_t)ra_sc[j >> 1];
-                As[(lt >> 4) * GM_ROWS + sl * 16 + (lt & 15)] = h2f((uint16_t)((j & 1) ? (w >> 16) : (w & 0xFFFF)));
+                As[(lt >> 4) * AROWS + sl * 16 + (lt & 15)] = h2f((uint16_t)((j & 1) ? (w >> 16) : (w & 0xFFFF)));
             }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pc = t + 256 * i, tk = pc >> 3, c = pc & 7;
-            *reinterpret_cast<v4i_t*>(Bq + ((size_t)c * GM_TOK + tk) * 16) = rb[i];       // c = blk*2 + half
+            *reinterpret_cast<v4i_t*>(Bq + ((size_t)c * GM_TOK + (tk ^ c)) * 16) = rb[i]; // c = blk*2 + half; xor: bank spread
         }
         if (t < GM_TOK) { Bs[0 * GM_TOK + t] = rb_s.x; Bs[1 * GM_TOK + t] = rb_s.y; Bs[2 * GM_TOK + t] = rb_s.z; Bs[3 * GM_TOK + t] = rb_s.w; }
     };
 
-    // wavefront's fragments: NM == 1: row frags rf = 0,1 at rows wr*64 + 32*rf; NM == 2: matrix m at local rows m*64 + wr*32
-    float acc[2][2][16];                               // [row frag or matrix][token frag][16]
+    // accumulators: [fragment f][token frag][8 x 2]; fragment f = matrix (SwiGLU) or row fragment
+    constexpr int NF = NM * RF;
+    v2f_t acc[NF][2][8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NF; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 8; ++r) acc[i][j][r] = v2f_t{0.f, 0.f};
 
+    v16i_t cbias;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cbias[r] = 0x4B400000;
     gload(0);
     lstore(0);
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         if (kb + 1 < nkb) gload(kb + 1);
-        const uint8_t* base = smem + (size_t)(kb & 1) * GM_STAGE_BYTES;
+        const uint8_t* base = smem + (size_t)(kb & 1) * STAGE;
         const uint8_t* Aq = base;
-        const float* As = reinterpret_cast<const float*>(base + GM_KB * 2 * GM_ROWS * 16);
-        const uint8_t* Bq = base + GM_KB * 2 * GM_ROWS * 16 + GM_KB * GM_ROWS * 4;
+        const float* As = reinterpret_cast<const float*>(base + GM_KB * 2 * AROWS * 16);
+        const uint8_t* Bq = base + GM_KB * 2 * AROWS * 16 + GM_KB * AROWS * 4;
         const float* Bs = reinterpret_cast<const float*>(Bq + GM_KB * 2 * GM_TOK * 16);
 #pragma unroll 1
         for (int blk = 0; blk < GM_KB; ++blk) {
             v4i_t bf[2];
-            float xsc[2];
+            v2f_t xsc[2];
 #pragma unroll
             for (int tf = 0; tf < 2; ++tf) {
                 const int tk = wc * 64 + tf * 32 + tl;
-                bf[tf] = *reinterpret_cast<const v4i_t*>(Bq + ((size_t)(blk * 2 + hi) * GM_TOK + tk) * 16);
-                xsc[tf] = Bs[blk * GM_TOK + tk];
+                bf[tf] = *reinterpret_cast<const v4i_t*>(Bq + ((size_t)(blk * 2 + hi) * GM_TOK + (tk ^ (blk * 2 + hi))) * 16);
+                const float x = Bs[blk * GM_TOK + tk];
+                xsc[tf] = v2f_t{x, x};
             }
+            // The int32 block sums come out of the MFMA already biased by 0x4B400000: reinterpreted as f32 that is
+            // 12582912 + isum exactly (|isum| <= 32*127*127 < 2^22), so (float)isum = bits - 12582912.0f is one packed
+            // subtract per two values instead of two v_cvt_f32_i32.
 #pragma unroll
-            for (int rf = 0; rf < 2; ++rf) {
-                const int lrow = NM == 2 ? rf * 64 + wr * 32 : wr * 64 + rf * 32;      // local row of this frag
-                const v4i_t af = *reinterpret_cast<const v4i_t*>(Aq + ((size_t)(blk * 2 + hi) * GM_ROWS + lrow + tl) * 16);
-                float wsf[16];
+            for (int f = 0; f < NF; ++f) {
+                const int lrow = NM == 2 ? f * 64 + wr * 32 : wr * (32 * RF) + f * 32;     // local row of this fragment
+                v4i_t af[NF];
+                v2f_t wsf[NF][8];
+                af[f] = *reinterpret_cast<const v4i_t*>(Aq + ((size_t)(blk * 2 + hi) * AROWS + lrow + tl) * 16);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(As + blk * GM_ROWS + lrow + 8 * q + 4 * hi);
-                    wsf[4 * q] = w4.x; wsf[4 * q + 1] = w4.y; wsf[4 * q + 2] = w4.z; wsf[4 * q + 3] = w4.w;
+                    const float4 w4 = *reinterpret_cast<const float4*>(As + blk * AROWS + lrow + 8 * q + 4 * hi);
+                    wsf[f][2 * q] = v2f_t{w4.x, w4.y};
+                    wsf[f][2 * q + 1] = v2f_t{w4.z, w4.w};
                 }
+                v16i_t c[NF][2];
+#pragma unroll
+                for (int tf = 0; tf < 2; ++tf) c[f][tf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[f], bf[tf], cbias, 0, 0, 0);
 #pragma unroll
                 for (int tf = 0; tf < 2; ++tf) {
-                    v16i_t c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    c = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[tf], c, 0, 0, 0);
+                    v2f_t cf[8], pr[8];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)      // result += isum * (wScale * aScale), blocks ascending
-                        acc[rf][tf][r] = acc[rf][tf][r] + (float)c[r] * (wsf[r] * xsc[tf]);
+                    for (int r = 0; r < 8; ++r)
+                        cf[r] = v2f_t{__int_as_float(c[f][tf][2 * r]), __int_as_float(c[f][tf][2 * r + 1])} - v2f_t{12582912.f, 12582912.f};
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) pr[r] = wsf[f][r] * xsc[tf];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) cf[r] = cf[r] * pr[r];       // isum * (wScale * aScale)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[f][tf][r] = acc[f][tf][r] + cf[r];   // result +=, blocks ascending
                 }
             }
         }
-        if (kb + 1 < nkb) {
-            lstore((kb + 1) & 1);
-        }
+        if (kb + 1 < nkb) lstore((kb + 1) & 1);
         __syncthreads();
     }
     // ---- epilogue.  C layout: token = lane & 31 (column), weight row = (r & 3) + 8 * (r >> 2) + 4 * hi
@@ -268,20 +291,20 @@ __global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (row >= a.rows) continue;
-                float g = acc[0][tf][r];
+                float g = acc[0][tf][r >> 1][r & 1];
                 g = g / (float)(1.0 + exp(-(double)g));
-                a.out[(size_t)b * a.out_stride + row] = g * acc[1][tf][r];
+                a.out[(size_t)b * a.out_stride + row] = g * acc[NF - 1][tf][r >> 1][r & 1];
             }
         } else {
 #pragma unroll
-            for (int rf = 0; rf < 2; ++rf)
+            for (int f = 0; f < NF; ++f)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + wr * 64 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int row = row0 + wr * (32 * RF) + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (row >= a.rows) continue;
                     float* o = a.out + (size_t)b * a.out_stride + row;
-                    if (EPI == EPI_STORE) *o = acc[rf][tf][r];
-                    else *o = *o + acc[rf][tf][r];
+                    if (EPI == EPI_STORE) *o = acc[f][tf][r >> 1][r & 1];
+                    else *o = *o + acc[f][tf][r >> 1][r & 1];
                 }
         }
     }
@@ -448,9 +471,11 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
     GL3_HIP(hipMalloc((void**)&p->seqpos, 2 * M * sizeof(int32_t)));
     GL3_HIP(hipMalloc((void**)&p->amax, M * sizeof(int32_t)));
-    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GM_STAGE_BYTES));
-    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GM_STAGE_BYTES));
-    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GM_STAGE_BYTES));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_STORE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_STORE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_RESID, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_RESID, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_SWIGLU, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     return GL3_OK;
@@ -471,9 +496,15 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     GemmArgs a{};
     a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.ng = w.ng; a.nb = w.k / 32;
     a.XQ = p->XQ; a.XS = p->XS; a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride;
-    constexpr int RPM = GM_ROWS / (EPI == EPI_SWIGLU ? 2 : 1);
-    dim3 grid((ntok + GM_TOK - 1) / GM_TOK, (w.rows + RPM - 1) / RPM);
-    hipLaunchKernelGGL((pf_gemm_kernel<EPI>), grid, dim3(256), 2 * GM_STAGE_BYTES, ctx->stream, a);
+    // 128-row tiles only when they still give >= 2 workgroups per CU; otherwise 64-row tiles
+    const int ntt = (ntok + GM_TOK - 1) / GM_TOK;
+    if (EPI != EPI_SWIGLU && (size_t)ntt * ((w.rows + 127) / 128) >= 512) {
+        constexpr int RF = EPI == EPI_SWIGLU ? 1 : 2;
+        hipLaunchKernelGGL((pf_gemm_kernel<EPI, RF>), dim3(ntt, (w.rows + 127) / 128), dim3(256), 2 * gm_stage_bytes(128), ctx->stream, a);
+    } else {
+        constexpr int AROWS = EPI == EPI_SWIGLU ? 128 : 64;
+        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1>), dim3(ntt, (w.rows + 63) / 64), dim3(256), 2 * gm_stage_bytes(AROWS), ctx->stream, a);
+    }
 }
 
 // All layers for n tokens whose (token, sequence, position) are already on the device.  max_pos = largest position.
