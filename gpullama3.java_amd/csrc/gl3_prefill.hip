@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "gl3_ctx.h"
+#include <type_traits>
 #include "gl3_decode_kernels.h"
 
 using namespace gl3;
@@ -124,6 +125,7 @@ struct GemmArgs {
 // RF = 1 over two matrices.
 constexpr int GM_TOK = 128, GM_KB = 4;
 typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
 __host__ __device__ constexpr int gm_stage_bytes(int arows) {
     return GM_KB * 2 * arows * 16 + GM_KB * arows * 4 + GM_KB * 2 * GM_TOK * 16 + GM_KB * GM_TOK * 4;
 }
@@ -425,6 +427,175 @@ __global__ __launch_bounds__(64) void pf_attn_softmax_pv_kernel(const PfAttnArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Prefill of ONE sequence (token b sits at position pos0 + b): the K / V tiles are shared by a tile of PA_TB tokens
+// instead of being re-read for every token.  Per-element arithmetic and order are those of the per-token kernels above.
+//
+// Scores: grid = (64-timestep K tiles, n_kv_heads, token tiles), block = 64 x kvMul (kvMul <= 4).  Thread (head hq,
+// timestep r) keeps its K row in registers and walks the PA_TB query rows of its head (four chains in flight).
+template <int I, int N, int STEP, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + STEP, N, STEP>(f);
+    }
+}
+// two score chains advance 16 elements: score = score + q[j] * k[j], j ascending (no FMA)
+__device__ __forceinline__ void score_step16(float& s0, float& s1, const v16f_t& qa, const v16f_t& qb, const float4* k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s0 = s0 + qa[4 * i] * k[i].x;     s1 = s1 + qb[4 * i] * k[i].x;
+        s0 = s0 + qa[4 * i + 1] * k[i].y; s1 = s1 + qb[4 * i + 1] * k[i].y;
+        s0 = s0 + qa[4 * i + 2] * k[i].z; s1 = s1 + qb[4 * i + 2] * k[i].z;
+        s0 = s0 + qa[4 * i + 3] * k[i].w; s1 = s1 + qb[4 * i + 3] * k[i].w;
+    }
+}
+constexpr int PA_TB = 16;
+template <int HS>
+__global__ __launch_bounds__(256) void pf_scores_tiled_kernel(const float* __restrict__ Q, int q_stride, const float* __restrict__ kc,
+                                                              float* __restrict__ att, int n_heads, int kvmul, int kv_dim, int ctx,
+                                                              int pos0, int ntok) {
+    extern __shared__ __attribute__((aligned(16))) float kt[];       // [64][PITCH]
+    constexpr int PITCH = HS + 4, H4 = HS / 4;
+    const int t = threadIdx.x, nthr = blockDim.x;
+    const int t0 = blockIdx.x * 64, kvh = blockIdx.y, b0 = blockIdx.z * PA_TB;
+    const int nb = min(PA_TB, ntok - b0);
+    const int tmax = pos0 + b0 + nb - 1;              // last timestep any token of this tile attends to
+    if (tmax < t0) return;
+    const int t1 = min(tmax + 1, t0 + 64);
+    for (int i = t; i < (t1 - t0) * H4; i += nthr) {
+        const int r = i / H4, c = i % H4;
+        *reinterpret_cast<float4*>(kt + r * PITCH + 4 * c) =
+            *reinterpret_cast<const float4*>(kc + (size_t)(t0 + r) * kv_dim + kvh * HS + 4 * c);
+    }
+    __syncthreads();
+    const int hq = __builtin_amdgcn_readfirstlane(t >> 6), r = t & 63;
+    float4 kr[H4];
+#pragma unroll
+    for (int c = 0; c < H4; ++c) kr[c] = *reinterpret_cast<const float4*>(kt + min(r, t1 - t0 - 1) * PITCH + 4 * c);
+    const float sqrt_hs = (float)sqrt((double)HS);
+    const int head = kvh * kvmul + hq;
+    for (int tb = 0; tb < nb; tb += 2) {
+        // the two query rows are wavefront-uniform: scalar loads (8 floats per row per step, double-buffered), SGPR
+        // operands in the multiplies.  Explicit s_load: the compiler would hoist every load and spill SGPRs.
+        const float* q0 = Q + (size_t)(b0 + tb) * q_stride + (size_t)head * HS;
+        const float* q1 = Q + (size_t)(b0 + min(tb + 1, nb - 1)) * q_stride + (size_t)head * HS;
+        float s0 = 0.f, s1 = 0.f;
+        if constexpr (HS >= 64) {
+            v16f_t a0, a1, c0, c1;                    // 16 q values per row per step (64 SGPRs for the double buffer)
+            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
+            static_for<0, H4 / 4, 2>([&](auto ic) {
+                constexpr int c4 = decltype(ic)::value;
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(s0), "+v"(s1));   // s0/s1 pin the VALU chain between the asm statements
+                asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4" : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1), "n"((c4 + 1) * 64));
+                score_step16(s0, s1, a0, a1, &kr[4 * c4]);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c0), "+s"(c1), "+v"(s0), "+v"(s1));
+                if constexpr (c4 + 2 < H4 / 4)
+                    asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1), "n"((c4 + 2) * 64));
+                score_step16(s0, s1, c0, c1, &kr[4 * c4 + 4]);
+            });
+        } else {
+            v16f_t a0, a1, c0, c1;
+            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
+            asm volatile("s_load_dwordx16 %0, %2, 64\n\ts_load_dwordx16 %1, %3, 64" : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(c0), "+s"(c1), "+v"(s0), "+v"(s1));
+            score_step16(s0, s1, a0, a1, &kr[0]);
+            score_step16(s0, s1, c0, c1, &kr[4]);
+        }
+        const int b = b0 + tb;
+        if (t0 + r < t1) {
+            if (t0 + r <= pos0 + b) att[((size_t)b * n_heads + head) * ctx + t0 + r] = s0 / sqrt_hs;
+            if (tb + 1 < nb && t0 + r <= pos0 + b + 1) att[((size_t)(b + 1) * n_heads + head) * ctx + t0 + r] = s1 / sqrt_hs;
+        }
+    }
+}
+
+// Softmax of every (token, head) score row, in place: one wavefront per row, wpw rows per workgroup.
+// max -> exp in double -> sequential f32 sum -> divide (InferenceCore.java softmax via FloatTensor.softmaxInPlace).
+__global__ __launch_bounds__(256) void pf_softmax_kernel(const PfAttnArgs a, int ntok, int wpw, int npad) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pair = blockIdx.x * wpw + w;
+    const bool live = w < wpw && pair < ntok * a.n_heads;
+    const int b = live ? pair / a.n_heads : 0;
+    const int n = live ? a.pos[b] + 1 : 0;
+    float* sc = a.att + (size_t)(live ? pair : 0) * a.ctx;
+    float* e_s = sm + (size_t)(w < wpw ? w : 0) * npad;
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) { const float v = sc[i]; e_s[i] = v; mx = fmaxf(mx, v); }
+    mx = wave_max(mx);
+    for (int i = lane; i < n; i += 64) e_s[i] = (float)exp((double)(e_s[i] - mx));   // lane-private slots so far
+    __syncthreads();
+    const float sum = seq_sum_lds<false>(e_s, n);
+    for (int i = lane; i < n; i += 64) sc[i] = e_s[i] / sum;
+}
+
+// Weighted V sum: grid = (n_heads, token tiles), block 256.  V tiles of 64 timesteps are staged in LDS once per
+// workgroup; wavefront w carries tokens 4w..4w+3 of the tile, lane j the output columns j (+64): acc = a_t * v + acc,
+// t ascending.  The softmax weights are wavefront-uniform loads.
+template <int NCOL>
+__global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, int seq, int pos0, int ntok) {
+    extern __shared__ __attribute__((aligned(16))) float vt[];        // [64][hs]
+    const int hs = a.hs, h4 = hs >> 2, kvmul = a.n_heads / a.n_kv_heads;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int h = blockIdx.x, kvh = h / kvmul, b0 = blockIdx.y * PA_TB;
+    const int nb = min(PA_TB, ntok - b0);
+    const int tmax = pos0 + b0 + nb - 1;
+    const float* vc = a.vcache + (size_t)seq * a.seq_stride;
+    float* as = vt + 64 * hs;                                         // [PA_TB][64] softmax weights of the current tile
+    int posu[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) posu[u] = 4 * w + u < nb ? pos0 + b0 + 4 * w + u : -1;   // -1: no timestep qualifies
+    const int wmax = 4 * w < nb ? pos0 + b0 + min(4 * w + 3, nb - 1) : -1;
+    float acc[4][NCOL];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) acc[u][c] = 0.f;
+    for (int t0 = 0; t0 <= tmax; t0 += 64) {
+        const int tt = min(64, tmax + 1 - t0);
+        __syncthreads();
+        for (int i = t; i < tt * h4; i += 256) {
+            const int r = i / h4, c = i % h4;
+            *reinterpret_cast<float4*>(vt + r * hs + 4 * c) =
+                *reinterpret_cast<const float4*>(vc + (size_t)(t0 + r) * a.kv_dim + kvh * hs + 4 * c);
+        }
+        for (int i = t; i < PA_TB * 64; i += 256) {                   // entries past a token's position are never used
+            const int tb = i >> 6, r = i & 63;
+            as[i] = (tb < nb && t0 + r <= pos0 + b0 + tb) ? a.att[((size_t)(b0 + tb) * a.n_heads + h) * a.ctx + t0 + r] : 0.f;
+        }
+        __syncthreads();
+        const int ttw = min(tt, wmax + 1 - t0);                       // this wavefront's tokens stop at wmax
+        for (int r = 0; r < ttw; r += 4) {
+            float4 a4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] = *reinterpret_cast<const float4*>(as + (4 * w + u) * 64 + r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[NCOL];
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c) v[c] = (lane + 64 * c < hs) ? vt[min(r + i, 63) * hs + lane + 64 * c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (t0 + r + i <= posu[u]) {                      // wavefront-uniform
+                        const float at = i == 0 ? a4[u].x : i == 1 ? a4[u].y : i == 2 ? a4[u].z : a4[u].w;
+#pragma unroll
+                        for (int c = 0; c < NCOL; ++c) acc[u][c] = at * v[c] + acc[u][c];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int tb = 4 * w + u;
+        if (tb >= nb) continue;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c)
+            if (lane + 64 * c < hs) a.out[(size_t)(b0 + tb) * a.out_stride + h * hs + lane + 64 * c] = acc[u][c];
+    }
+}
+
 // Greedy id per sequence: first index of the maximum of each logits row (FloatTensor.argmax :138-151).
 __global__ __launch_bounds__(1024) void pf_argmax_rows_kernel(const float* __restrict__ logits, int n, int32_t* __restrict__ out) {
     __shared__ float bv[16];
@@ -508,7 +679,8 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
 }
 
 // All layers for n tokens whose (token, sequence, position) are already on the device.  max_pos = largest position.
-static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos) {
+// one_seq >= 0: all n tokens belong to that sequence at consecutive positions ending at max_pos (prefill).
+static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
     gl3_prefill_state* p = ctx->pf;
     const gl3_model_desc& d = ctx->d;
     hipStream_t s = ctx->stream;
@@ -535,9 +707,29 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos) {
         aa.out_stride = ctx->q_dim; aa.n_heads = d.n_heads; aa.n_kv_heads = d.n_kv_heads; aa.hs = d.head_size; aa.kv_dim = ctx->kv_dim;
         aa.ctx = d.ctx; aa.seq = seq; aa.pos = pos; aa.seq_stride = ctx->kv_seq_stride;
         const int nsplit = (max_pos + 1 + ATT_TT - 1) / ATT_TT;
-        const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
-        hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, d.n_kv_heads, n), dim3(64 * kvmul), sm1, s, aa);
-        hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(d.n_heads * ((d.head_size + 63) / 64), n), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
+        const int hs = d.head_size;
+        const bool tiled = one_seq >= 0 && kvmul <= 4 && (hs == 32 || hs == 64 || hs == 128) && (size_t)(max_pos + 1) * 4 <= 60 * 1024;
+        if (tiled) {
+            const int pos0 = max_pos + 1 - n, ntt = (n + PA_TB - 1) / PA_TB;
+            const size_t sms = (size_t)64 * (hs + 4) * 4;
+            const dim3 g1(nsplit, d.n_kv_heads, ntt), b1(64 * kvmul);
+            const float* kc1 = aa.kcache + (size_t)one_seq * ctx->kv_seq_stride;
+#define GL3_SCORES(HS_) hipLaunchKernelGGL((pf_scores_tiled_kernel<HS_>), g1, b1, sms, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n)
+            if (hs == 128) GL3_SCORES(128);
+            else if (hs == 64) GL3_SCORES(64);
+            else GL3_SCORES(32);
+#undef GL3_SCORES
+            const int npad = (max_pos + 1 + 63) & ~63;
+            int wpw = (int)((60 * 1024) / ((size_t)npad * 4));
+            wpw = wpw > 4 ? 4 : wpw;
+            hipLaunchKernelGGL(pf_softmax_kernel, dim3((n * d.n_heads + wpw - 1) / wpw), dim3(256), (size_t)wpw * npad * 4, s, aa, n, wpw, npad);
+            if (hs > 64) hipLaunchKernelGGL((pf_pv_tiled_kernel<2>), dim3(d.n_heads, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
+            else hipLaunchKernelGGL((pf_pv_tiled_kernel<1>), dim3(d.n_heads, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
+        } else {
+            const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
+            hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, d.n_kv_heads, n), dim3(64 * kvmul), sm1, s, aa);
+            hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(d.n_heads * ((d.head_size + 63) / 64), n), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
+        }
         hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->AO, ctx->q_dim, ctx->q_dim, (const float*)nullptr,
                            0.f, p->XQ, p->XS, p->maxk);
         launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, p->X, d.dim);
@@ -571,7 +763,7 @@ int32_t gl3_prefill_run(gl3_ctx* ctx, int32_t seq, const int32_t* tokens, int32_
     for (int i = 0; i < n; ++i) poss[i] = start_pos + i;
     int32_t r = pf_stage_tokens(ctx, tokens, seqs.data(), poss.data(), n);
     if (r != GL3_OK) return r;
-    if ((r = pf_layers(ctx, n, start_pos + n - 1)) != GL3_OK) return r;
+    if ((r = pf_layers(ctx, n, start_pos + n - 1, seq)) != GL3_OK) return r;
     // keep the decode path's x in step with the last prefilled token (parity tap gl3_get_x)
     GL3_HIP(hipMemcpyAsync(ctx->x, p->X + (size_t)(n - 1) * d.dim, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, ctx->stream));
     GL3_HIP(hipStreamSynchronize(ctx->stream));
@@ -596,7 +788,7 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
     for (int i = 0; i < n; ++i) max_pos = positions[i] > max_pos ? positions[i] : max_pos;
     int32_t r = pf_stage_tokens(ctx, tokens, seq_ids, positions, n);
     if (r != GL3_OK) return r;
-    if ((r = pf_layers(ctx, n, max_pos)) != GL3_OK) return r;
+    if ((r = pf_layers(ctx, n, max_pos, -1)) != GL3_OK) return r;
     hipStream_t s = ctx->stream;
     const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
     hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq, s, p->X, d.dim, d.dim, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk);
