@@ -130,18 +130,24 @@ __host__ __device__ constexpr int gm_stage_bytes(int arows) {
     return GM_KB * 2 * arows * 16 + GM_KB * arows * 4 + GM_KB * 2 * GM_TOK * 16 + GM_KB * GM_TOK * 4;
 }
 
-template <int EPI, int RF>
-__global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
+// NW = wavefronts per workgroup: 4 (2 x 2, two token fragments each) or 8 (2 x 4, one token fragment each; used for the
+// 4096-row matrices where only one workgroup fits a CU, so that every SIMD still interleaves two wavefronts).
+template <int EPI, int RF, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
     static_assert(NM * RF <= 2, "accumulator budget");
+    static_assert(NW == 4 || (NW == 8 && NM * RF == 1), "8-wavefront layout is for the single-fragment variant");
+    constexpr int NT = 64 * NW, TF = 8 / NW;          // threads; 32-token fragments per wavefront
     constexpr int AROWS = NM * RF * 64;                // weight rows staged per K stage (both matrices together)
     constexpr int RPM = AROWS / NM;                    // output rows per matrix covered by this workgroup
     constexpr int STAGE = gm_stage_bytes(AROWS);
-    constexpr int NAP = AROWS / 64;                    // (strip, lane) pairs per thread
+    constexpr int NAP = (AROWS * 4 + NT - 1) / NT;     // (strip, lane) pairs per thread
+    constexpr int NBP = 1024 / NT;                     // 16-byte activation pieces per thread
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tl = lane & 31, hi = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;           // wavefront grid: row half wr, tokens wc*64..
+    const int wr = NW == 4 ? wave >> 1 : wave >> 2;    // wavefront grid: row half wr,
+    const int wc = NW == 4 ? wave & 1 : wave & 3;      // tokens wc * 32 * TF ..
     const int row0 = blockIdx.y * RPM;                 // first output row (per matrix)
     const int tok0 = blockIdx.x * GM_TOK;
     const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
     // ---- global -> register staging of one K stage
     // A: AROWS/16 strips x one tile (64 x f16 scales, 64 x 16 B lo, 64 x 16 B hi).  Thread t: lo/hi pieces
     // t + 256 i of the (strip, lane-in-tile) pairs; scales: threads < AROWS/2 take 8 f16 = (strip t>>3, lanes 8*(t&7)..+7)
-    v4i_t ra_lo[NAP], ra_hi[NAP], ra_sc, rb[4];
+    v4i_t ra_lo[NAP], ra_hi[NAP], ra_sc, rb[NBP];
     float4 rb_s;
     auto tile_of = [&](int sl, int kb) -> const uint8_t* {   // sl: local strip 0..AROWS/16-1
         const int m = NM == 2 ? (sl >> 2) : 0;
@@ -161,29 +167,27 @@ __global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
     auto gload = [&](int kb) {
 #pragma unroll
         for (int i = 0; i < NAP; ++i) {
-            const int pr = t + 256 * i, lt = pr & 63;
-            const uint8_t* tile = tile_of(pr >> 6, kb);
-            ra_lo[i] = *reinterpret_cast<const v4i_t*>(tile + 128 + 16 * lt);
-            ra_hi[i] = *reinterpret_cast<const v4i_t*>(tile + 1152 + 16 * lt);
+            const int pr = t + NT * i, lt = pr & 63;
+            if (pr < AROWS * 4) {
+                const uint8_t* tile = tile_of(pr >> 6, kb);
+                ra_lo[i] = *reinterpret_cast<const v4i_t*>(tile + 128 + 16 * lt);
+                ra_hi[i] = *reinterpret_cast<const v4i_t*>(tile + 1152 + 16 * lt);
+            }
         }
         if (t < AROWS / 2) ra_sc = *reinterpret_cast<const v4i_t*>(tile_of(t >> 3, kb) + 16 * (t & 7));
         // B: 128 tokens x 128 B of int8 (4 blocks) -> 1024 16-byte pieces, 4 per thread: piece = t + 256*i ->
         // token = piece >> 3, 16-byte chunk c = piece & 7 (block c>>1, half c&1)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pc = t + 256 * i, tk = min(a.ntok - 1, tok0 + (pc >> 3)), c = pc & 7;
+        for (int i = 0; i < NBP; ++i) {
+            const int pc = t + NT * i, tk = min(a.ntok - 1, tok0 + (pc >> 3)), c = pc & 7;
             rb[i] = *reinterpret_cast<const v4i_t*>(a.XQ + (size_t)tk * a.maxk + (size_t)kb * 128 + 16 * c);
         }
         if (t < GM_TOK) {
             const int tk = min(a.ntok - 1, tok0 + t);
             rb_s = *reinterpret_cast<const float4*>(a.XS + (size_t)tk * (a.maxk >> 5) + kb * 4);
-            // ragged K (k % 128 != 0): the padded blocks carry zero weights; zero their activation scale too
-            if (kb * 4 + 1 >= a.nb) rb_s.y = 0.f;
-            if (kb * 4 + 2 >= a.nb) rb_s.z = 0.f;
-            if (kb * 4 + 3 >= a.nb) rb_s.w = 0.f;
         }
     };
-    auto lstore = [&](int stage) {
+    auto lstore = [&](int stage, int kbs) {        // kbs = K stage held in the staging registers
         uint8_t* base = smem + (size_t)stage * STAGE;
         uint8_t* Aq = base;
         float* As = reinterpret_cast<float*>(base + GM_KB * 2 * AROWS * 16);
@@ -191,10 +195,12 @@ __global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
         float* Bs = reinterpret_cast<float*>(Bq + GM_KB * 2 * GM_TOK * 16);
 #pragma unroll
         for (int i = 0; i < NAP; ++i) {
-            const int pr = t + 256 * i, sl = pr >> 6, lt = pr & 63;
+            const int pr = t + NT * i, sl = pr >> 6, lt = pr & 63;
             const int row = sl * 16 + (lt & 15), blk = lt >> 4;
-            *reinterpret_cast<v4i_t*>(Aq + ((size_t)(blk * 2 + 0) * AROWS + row) * 16) = ra_lo[i];
-            *reinterpret_cast<v4i_t*>(Aq + ((size_t)(blk * 2 + 1) * AROWS + row) * 16) = ra_hi[i];
+            if (pr < AROWS * 4) {
+                *reinterpret_cast<v4i_t*>(Aq + ((size_t)(blk * 2 + 0) * AROWS + row) * 16) = ra_lo[i];
+                *reinterpret_cast<v4i_t*>(Aq + ((size_t)(blk * 2 + 1) * AROWS + row) * 16) = ra_hi[i];
+            }
         }
         if (t < AROWS / 2) {
             const int sl = t >> 3;
@@ -206,28 +212,38 @@ __global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pc = t + 256 * i, tk = pc >> 3, c = pc & 7;
+        for (int i = 0; i < NBP; ++i) {
+            const int pc = t + NT * i, tk = pc >> 3, c = pc & 7;
             *reinterpret_cast<v4i_t*>(Bq + ((size_t)c * GM_TOK + (tk ^ c)) * 16) = rb[i]; // c = blk*2 + half; xor: bank spread
         }
-        if (t < GM_TOK) { Bs[0 * GM_TOK + t] = rb_s.x; Bs[1 * GM_TOK + t] = rb_s.y; Bs[2 * GM_TOK + t] = rb_s.z; Bs[3 * GM_TOK + t] = rb_s.w; }
+        if (t < GM_TOK) {
+            // ragged K (k % 128 != 0): the padded blocks carry zero weights; zero their activation scale too.  (Done
+            // here, not at load time, so that the global loads stay in flight across the compute phase.)
+            Bs[0 * GM_TOK + t] = rb_s.x;
+            Bs[1 * GM_TOK + t] = kbs * 4 + 1 < a.nb ? rb_s.y : 0.f;
+            Bs[2 * GM_TOK + t] = kbs * 4 + 2 < a.nb ? rb_s.z : 0.f;
+            Bs[3 * GM_TOK + t] = kbs * 4 + 3 < a.nb ? rb_s.w : 0.f;
+        }
     };
 
     // accumulators: [fragment f][token frag][8 x 2]; fragment f = matrix (SwiGLU) or row fragment
     constexpr int NF = NM * RF;
-    v2f_t acc[NF][2][8];
+    v2f_t acc[NF][TF][8];
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TF; ++j)
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[i][j][r] = v2f_t{0.f, 0.f};
 
+#ifdef GL3_GEMM_TIMING
+    const unsigned long long tk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     v16i_t cbias;
 #pragma unroll
     for (int r = 0; r < 16; ++r) cbias[r] = 0x4B400000;
     gload(0);
-    lstore(0);
+    lstore(0, 0);
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         if (kb + 1 < nkb) gload(kb + 1);
@@ -236,57 +252,88 @@ __global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
         const float* As = reinterpret_cast<const float*>(base + GM_KB * 2 * AROWS * 16);
         const uint8_t* Bq = base + GM_KB * 2 * AROWS * 16 + GM_KB * AROWS * 4;
         const float* Bs = reinterpret_cast<const float*>(Bq + GM_KB * 2 * GM_TOK * 16);
-#pragma unroll 1
-        for (int blk = 0; blk < GM_KB; ++blk) {
-            v4i_t bf[2];
-            v2f_t xsc[2];
+        // operand fragments of one Q8_0 block for this wavefront
+        struct Frag { v4i_t bf[TF]; v2f_t xsc[TF]; v4i_t af[NF]; v2f_t wsf[NF][8]; };
+        auto fload_a = [&](Frag& fr, int blk, int f) {
+            const int lrow = NM == 2 ? f * 64 + wr * 32 : wr * (32 * RF) + f * 32;     // local row of this fragment
+            fr.af[f] = *reinterpret_cast<const v4i_t*>(Aq + ((size_t)(blk * 2 + hi) * AROWS + lrow + tl) * 16);
 #pragma unroll
-            for (int tf = 0; tf < 2; ++tf) {
-                const int tk = wc * 64 + tf * 32 + tl;
-                bf[tf] = *reinterpret_cast<const v4i_t*>(Bq + ((size_t)(blk * 2 + hi) * GM_TOK + (tk ^ (blk * 2 + hi))) * 16);
-                const float x = Bs[blk * GM_TOK + tk];
-                xsc[tf] = v2f_t{x, x};
+            for (int q = 0; q < 4; ++q) {
+                const float4 w4 = *reinterpret_cast<const float4*>(As + blk * AROWS + lrow + 8 * q + 4 * hi);
+                fr.wsf[f][2 * q] = v2f_t{w4.x, w4.y};
+                fr.wsf[f][2 * q + 1] = v2f_t{w4.z, w4.w};
             }
-            // The int32 block sums come out of the MFMA already biased by 0x4B400000: reinterpreted as f32 that is
-            // 12582912 + isum exactly (|isum| <= 32*127*127 < 2^22), so (float)isum = bits - 12582912.0f is one packed
-            // subtract per two values instead of two v_cvt_f32_i32.
+        };
+        auto fload = [&](Frag& fr, int blk, bool with_a) {
+#pragma unroll
+            for (int tf = 0; tf < TF; ++tf) {
+                const int tk = wc * (32 * TF) + tf * 32 + tl;
+                fr.bf[tf] = *reinterpret_cast<const v4i_t*>(Bq + ((size_t)(blk * 2 + hi) * GM_TOK + (tk ^ (blk * 2 + hi))) * 16);
+                const float x = Bs[blk * GM_TOK + tk];
+                fr.xsc[tf] = v2f_t{x, x};
+            }
+            if (with_a) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) fload_a(fr, blk, f);
+            }
+        };
+        // The int32 block sums come out of the MFMA already biased by 0x4B400000: reinterpreted as f32 that is
+        // 12582912 + isum exactly (|isum| <= 32*127*127 < 2^22), so (float)isum = bits - 12582912.0f is one packed
+        // subtract per two values instead of two v_cvt_f32_i32.
+        auto fcompute = [&](Frag& fr, int blk, bool load_a) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const int lrow = NM == 2 ? f * 64 + wr * 32 : wr * (32 * RF) + f * 32;     // local row of this fragment
-                v4i_t af[NF];
-                v2f_t wsf[NF][8];
-                af[f] = *reinterpret_cast<const v4i_t*>(Aq + ((size_t)(blk * 2 + hi) * AROWS + lrow + tl) * 16);
+                if (load_a) fload_a(fr, blk, f);
+                v16i_t c[TF];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(As + blk * AROWS + lrow + 8 * q + 4 * hi);
-                    wsf[f][2 * q] = v2f_t{w4.x, w4.y};
-                    wsf[f][2 * q + 1] = v2f_t{w4.z, w4.w};
-                }
-                v16i_t c[NF][2];
+                for (int tf = 0; tf < TF; ++tf) c[tf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr.af[f], fr.bf[tf], cbias, 0, 0, 0);
 #pragma unroll
-                for (int tf = 0; tf < 2; ++tf) c[f][tf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[f], bf[tf], cbias, 0, 0, 0);
-#pragma unroll
-                for (int tf = 0; tf < 2; ++tf) {
+                for (int tf = 0; tf < TF; ++tf) {
                     v2f_t cf[8], pr[8];
 #pragma unroll
                     for (int r = 0; r < 8; ++r)
-                        cf[r] = v2f_t{__int_as_float(c[f][tf][2 * r]), __int_as_float(c[f][tf][2 * r + 1])} - v2f_t{12582912.f, 12582912.f};
+                        cf[r] = v2f_t{__int_as_float(c[tf][2 * r]), __int_as_float(c[tf][2 * r + 1])} - v2f_t{12582912.f, 12582912.f};
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) pr[r] = wsf[f][r] * xsc[tf];
+                    for (int r = 0; r < 8; ++r) pr[r] = fr.wsf[f][r] * fr.xsc[tf];
 #pragma unroll
                     for (int r = 0; r < 8; ++r) cf[r] = cf[r] * pr[r];       // isum * (wScale * aScale)
 #pragma unroll
                     for (int r = 0; r < 8; ++r) acc[f][tf][r] = acc[f][tf][r] + cf[r];   // result +=, blocks ascending
                 }
             }
+        };
+        if constexpr (NF == 1) {
+            // one wavefront per SIMD in the narrow-matrix launches: fetch block b+1's fragments while block b computes
+            Frag fa, fb;
+            fload(fa, 0, true);
+#pragma unroll 1
+            for (int blk = 0; blk < GM_KB; blk += 2) {
+                fload(fb, blk + 1, true);
+                fcompute(fa, 0, false);
+                if (blk + 2 < GM_KB) fload(fa, blk + 2, true);
+                fcompute(fb, 0, false);
+            }
+        } else {
+#pragma unroll 1
+            for (int blk = 0; blk < GM_KB; ++blk) {
+                Frag fr;
+                fload(fr, blk, false);
+                fcompute(fr, blk, true);
+            }
         }
-        if (kb + 1 < nkb) lstore((kb + 1) & 1);
+        if (kb + 1 < nkb) lstore((kb + 1) & 1, kb + 1);
         __syncthreads();
     }
+#ifdef GL3_GEMM_TIMING
+    if (t == 0 && (blockIdx.y % 97) == 0 && blockIdx.x == 0) {
+        const unsigned long long tk1 = __builtin_readcyclecounter(), rt1 = __builtin_amdgcn_s_memrealtime();
+        printf("gemm epi=%d wg=(%d,%d) nkb=%d ticks=%llu realtime=%llu start_rt=%llu\n", EPI, blockIdx.x, blockIdx.y, nkb, tk1 - tk0, rt1 - rt0, rt0);
+    }
+#endif
     // ---- epilogue.  C layout: token = lane & 31 (column), weight row = (r & 3) + 8 * (r >> 2) + 4 * hi
 #pragma unroll
-    for (int tf = 0; tf < 2; ++tf) {
-        const int b = tok0 + wc * 64 + tf * 32 + tl;
+    for (int tf = 0; tf < TF; ++tf) {
+        const int b = tok0 + wc * (32 * TF) + tf * 32 + tl;
         if (b >= a.ntok) continue;
         if (EPI == EPI_SWIGLU) {
 #pragma unroll
@@ -299,15 +346,29 @@ __global__ __launch_bounds__(256, 2) void pf_gemm_kernel(const GemmArgs a) {
             }
         } else {
 #pragma unroll
-            for (int f = 0; f < NF; ++f)
+            for (int f = 0; f < NF; ++f) {
+                // rows (r & 3) + 8 * (r >> 2) + 4 * hi: four runs of four consecutive rows -> float4 accesses
+                float* o = a.out + (size_t)b * a.out_stride + row0 + wr * (32 * RF) + f * 32 + 4 * hi;
+                const int rbase = row0 + wr * (32 * RF) + f * 32 + 4 * hi;
+                float4 old[4];
+                if (EPI == EPI_RESID) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + wr * (32 * RF) + f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (row >= a.rows) continue;
-                    float* o = a.out + (size_t)b * a.out_stride + row;
-                    if (EPI == EPI_STORE) *o = acc[f][tf][r >> 1][r & 1];
-                    else *o = *o + acc[f][tf][r >> 1][r & 1];
+                    for (int q = 0; q < 4; ++q)
+                        if (rbase + 8 * q + 3 < a.rows) old[q] = *reinterpret_cast<const float4*>(o + 8 * q);
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = {acc[f][tf][2 * q][0], acc[f][tf][2 * q][1], acc[f][tf][2 * q + 1][0], acc[f][tf][2 * q + 1][1]};
+                    if (rbase + 8 * q + 3 < a.rows) {
+                        if (EPI == EPI_RESID) { v.x = old[q].x + v.x; v.y = old[q].y + v.y; v.z = old[q].z + v.z; v.w = old[q].w + v.w; }
+                        *reinterpret_cast<float4*>(o + 8 * q) = v;
+                    } else {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+                        for (int i = 0; i < 4; ++i)
+                            if (rbase + 8 * q + i < a.rows) o[8 * q + i] = EPI == EPI_RESID ? o[8 * q + i] + vv[i] : vv[i];
+                    }
+                }
+            }
         }
     }
 }
@@ -642,11 +703,11 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
     GL3_HIP(hipMalloc((void**)&p->seqpos, 2 * M * sizeof(int32_t)));
     GL3_HIP(hipMalloc((void**)&p->amax, M * sizeof(int32_t)));
-    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_STORE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)));
-    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_STORE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)));
-    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_RESID, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)));
-    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_RESID, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)));
-    GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<EPI_SWIGLU, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)));
+#define GL3_GEMM_LDS(...) GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)))
+    GL3_GEMM_LDS(EPI_STORE, 1, 4); GL3_GEMM_LDS(EPI_STORE, 2, 4); GL3_GEMM_LDS(EPI_STORE, 1, 8);
+    GL3_GEMM_LDS(EPI_RESID, 1, 4); GL3_GEMM_LDS(EPI_RESID, 2, 4); GL3_GEMM_LDS(EPI_RESID, 1, 8);
+    GL3_GEMM_LDS(EPI_SWIGLU, 1, 4);
+#undef GL3_GEMM_LDS
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     return GL3_OK;
@@ -667,14 +728,17 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     GemmArgs a{};
     a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.ng = w.ng; a.nb = w.k / 32;
     a.XQ = p->XQ; a.XS = p->XS; a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride;
-    // 128-row tiles only when they still give >= 2 workgroups per CU; otherwise 64-row tiles
+    // 128-row tiles only when they still give >= 2 workgroups per CU; otherwise 64-row tiles, and 8 wavefronts per
+    // workgroup when even those leave a single workgroup per CU
     const int ntt = (ntok + GM_TOK - 1) / GM_TOK;
-    if (EPI != EPI_SWIGLU && (size_t)ntt * ((w.rows + 127) / 128) >= 512) {
-        constexpr int RF = EPI == EPI_SWIGLU ? 1 : 2;
-        hipLaunchKernelGGL((pf_gemm_kernel<EPI, RF>), dim3(ntt, (w.rows + 127) / 128), dim3(256), 2 * gm_stage_bytes(128), ctx->stream, a);
+    if constexpr (EPI == EPI_SWIGLU) {
+        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 4>), dim3(ntt, (w.rows + 63) / 64), dim3(256), 2 * gm_stage_bytes(128), ctx->stream, a);
+    } else if ((size_t)ntt * ((w.rows + 127) / 128) >= 512) {
+        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 2, 4>), dim3(ntt, (w.rows + 127) / 128), dim3(256), 2 * gm_stage_bytes(128), ctx->stream, a);
+    } else if ((size_t)ntt * ((w.rows + 63) / 64) > 256) {
+        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 4>), dim3(ntt, (w.rows + 63) / 64), dim3(256), 2 * gm_stage_bytes(64), ctx->stream, a);
     } else {
-        constexpr int AROWS = EPI == EPI_SWIGLU ? 128 : 64;
-        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1>), dim3(ntt, (w.rows + 63) / 64), dim3(256), 2 * gm_stage_bytes(AROWS), ctx->stream, a);
+        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 8>), dim3(ntt, (w.rows + 63) / 64), dim3(512), 2 * gm_stage_bytes(64), ctx->stream, a);
     }
 }
 
