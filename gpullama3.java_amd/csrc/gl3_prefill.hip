@@ -627,22 +627,41 @@ __global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, in
         }
         __syncthreads();
         const int ttw = min(tt, wmax + 1 - t0);                       // this wavefront's tokens stop at wmax
-        for (int r = 0; r < ttw; r += 4) {
+        // timesteps every one of the four tokens attends to (t <= position of the first token): no conditions
+        const int rfull = (4 * w + 3 < nb) ? max(0, min(tt, posu[0] + 1 - t0)) & ~3 : 0;
+        auto vload = [&](int r, float (&v)[NCOL]) {
+            if (NCOL == 2) {                                          // lane owns columns 2*lane, 2*lane + 1
+                const float2 v2 = (2 * lane < hs) ? *reinterpret_cast<const float2*>(vt + r * hs + 2 * lane) : make_float2(0.f, 0.f);
+                v[0] = v2.x; v[NCOL - 1] = v2.y;
+            } else {
+                v[0] = lane < hs ? vt[r * hs + lane] : 0.f;
+            }
+        };
+        for (int r = 0; r < rfull; r += 4) {
             float4 a4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) a4[u] = *reinterpret_cast<const float4*>(as + (4 * w + u) * 64 + r);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float v[NCOL];
-#pragma unroll
-                for (int c = 0; c < NCOL; ++c) v[c] = (lane + 64 * c < hs) ? vt[min(r + i, 63) * hs + lane + 64 * c] : 0.f;
+                vload(r + i, v);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (t0 + r + i <= posu[u]) {                      // wavefront-uniform
-                        const float at = i == 0 ? a4[u].x : i == 1 ? a4[u].y : i == 2 ? a4[u].z : a4[u].w;
+                    const float at = i == 0 ? a4[u].x : i == 1 ? a4[u].y : i == 2 ? a4[u].z : a4[u].w;
 #pragma unroll
-                        for (int c = 0; c < NCOL; ++c) acc[u][c] = at * v[c] + acc[u][c];
-                    }
+                    for (int c = 0; c < NCOL; ++c) acc[u][c] = at * v[c] + acc[u][c];
+                }
+            }
+        }
+        for (int r = rfull; r < ttw; ++r) {                           // the diagonal: per-token conditions (uniform)
+            float v[NCOL];
+            vload(r, v);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (t0 + r <= posu[u]) {
+                    const float at = as[(4 * w + u) * 64 + r];
+#pragma unroll
+                    for (int c = 0; c < NCOL; ++c) acc[u][c] = at * v[c] + acc[u][c];
                 }
             }
         }
@@ -652,8 +671,10 @@ __global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, in
         const int tb = 4 * w + u;
         if (tb >= nb) continue;
 #pragma unroll
-        for (int c = 0; c < NCOL; ++c)
-            if (lane + 64 * c < hs) a.out[(size_t)(b0 + tb) * a.out_stride + h * hs + lane + 64 * c] = acc[u][c];
+        for (int c = 0; c < NCOL; ++c) {
+            const int j = NCOL == 2 ? 2 * lane + c : lane;
+            if (j < hs) a.out[(size_t)(b0 + tb) * a.out_stride + h * hs + j] = acc[u][c];
+        }
     }
 }
 
