@@ -18,6 +18,7 @@
 
 #include "gl3_ctx.h"
 #include "gl3_decode_kernels.h"
+#include "gl3_rowlane_kernels.h"
 
 using namespace gl3;
 
@@ -55,6 +56,27 @@ static hipError_t allow_big_lds() {
 // rows_valid / out / resid_in may address a slice (tensor parallel row split); w holds exactly that slice.
 static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const Q8Mat* w2, const float* x,
                           const float* norm_w, float* out, const float* resid_in) {
+    if (w.fmt != GL3_TYPE_Q8_0) {      // F16 / Q4_0: element-wise chains, one output row per lane (gl3_rowlane_kernels.h)
+        hipStream_t s = ctx->stream;
+        if (pro == PRO_RMS) {
+            const size_t sm = (size_t)(w.k + 32) * 4 + ss_scratch_bytes(w.k) + 64;
+            hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3(1), dim3(256), sm, s, x, w.k, norm_w, ctx->d.rms_eps, ctx->xn);
+            x = ctx->xn;
+        }
+        RlArgs a{};
+        a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.k = w.k; a.x = x; a.out = out; a.resid_in = resid_in;
+        const dim3 grid((w.rows + 255) / 256);
+        const size_t sm = (size_t)w.k * 4;
+#define GL3_RL(WT_) \
+        do { \
+            if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_rl_kernel<WT_, EPI_STORE>), grid, dim3(256), sm, s, a); \
+            else if (epi == EPI_RESID) hipLaunchKernelGGL((matvec_rl_kernel<WT_, EPI_RESID>), grid, dim3(256), sm, s, a); \
+            else hipLaunchKernelGGL((matvec_rl_kernel<WT_, EPI_SWIGLU>), grid, dim3(256), sm, s, a); \
+        } while (0)
+        if (w.fmt == GL3_TYPE_F16) GL3_RL(WT_F16); else GL3_RL(WT_Q4_0);
+#undef GL3_RL
+        return;
+    }
     static const bool nt = env_flag("GL3_NT", true);
     static const int max_wgs = getenv("GL3_WGS") ? atoi(getenv("GL3_WGS")) : 512;   // 2 resident workgroups per CU
     MatvecArgs a{};
@@ -154,7 +176,9 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
     int32_t r;
 
     pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
-    hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn, ctx->x);
+    if (ctx->emb.fmt == GL3_TYPE_Q8_0) hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn, ctx->x);
+    else if (ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_rl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn, ctx->x);
+    else hipLaunchKernelGGL((embed_rl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn, ctx->x);
     pr.end();
 
     for (int l = 0; l < d.n_layers; ++l) {
@@ -207,8 +231,9 @@ static int32_t dmalloc(gl3_ctx* ctx, T** p, size_t n) {
 }
 
 static int32_t alloc_mat(gl3_ctx* ctx, Q8Mat& m, int rows, int k) {
-    m.rows = rows; m.k = k; m.ng = ((k / 32) + 3) / 4; m.nstrips = (rows + 15) / 16;
+    m.rows = rows; m.k = k; m.ng = ((k / 32) + 3) / 4; m.nstrips = (rows + 15) / 16; m.fmt = ctx->d.weight_type;
     GL3_HIP(hipMalloc((void**)&m.w, m.bytes()));
+    if (m.fmt != GL3_TYPE_Q8_0) GL3_HIP(hipMemset(m.w, 0, m.bytes()));      // padded rows of the last 64-row group
     return GL3_OK;
 }
 
@@ -251,7 +276,10 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     auto bail = [&](int32_t code, const std::string& msg) { g_create_err = msg.empty() ? ctx->err : msg; gl3_destroy(ctx); return code; };
     const double t0 = now_ms();
     if (d.arch != GL3_ARCH_LLAMA && d.arch != GL3_ARCH_QWEN3) return bail(GL3_E_UNSUPPORTED, "unsupported architecture");
-    if (d.weight_type != GL3_TYPE_Q8_0) return bail(GL3_E_UNSUPPORTED, "only Q8_0 weights are implemented in this build");
+    if (d.weight_type != GL3_TYPE_Q8_0 && d.weight_type != GL3_TYPE_F16 && d.weight_type != GL3_TYPE_Q4_0)
+        return bail(GL3_E_UNSUPPORTED, "matrix weight type must be Q8_0, F16 or Q4_0");
+    if (d.weight_type != GL3_TYPE_Q8_0 && d.tp_size > 1 && (d.vocab / d.tp_size) % 64)
+        return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0 tensor parallel needs vocab/tp_size to be a multiple of 64");
     if (d.dim <= 0 || d.dim % 32 || d.hidden % 32 || d.n_layers <= 0 || d.n_heads <= 0 || d.n_kv_heads <= 0 ||
         d.n_heads % d.n_kv_heads || d.vocab <= 0 || d.ctx <= 0)
         return bail(GL3_E_ARG, "bad model dimensions");
@@ -294,6 +322,7 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP(hipMemset(ctx->kcache, 0, kvn * 4));
     TRYHIP(hipMemset(ctx->vcache, 0, kvn * 4));
     TRY(dmalloc(ctx, &ctx->x, d.dim));
+    TRY(dmalloc(ctx, &ctx->xn, d.dim));
     TRY(dmalloc(ctx, &ctx->qkv, ctx->q_dim_l + 2 * ctx->kv_dim_l));
     TRY(dmalloc(ctx, &ctx->xb, ctx->q_dim));
     TRY(dmalloc(ctx, &ctx->hb, d.hidden));
@@ -302,6 +331,11 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP((allow_big_lds<PRO_RMS, EPI_STORE>()));
     TRYHIP((allow_big_lds<PRO_QUANT, EPI_RESID>()));
     TRYHIP((allow_big_lds<PRO_RMS, EPI_SWIGLU>()));
+#define GL3_RL_LDS(...) TRYHIP(hipFuncSetAttribute((const void*)matvec_rl_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
+    GL3_RL_LDS(WT_F16, EPI_STORE); GL3_RL_LDS(WT_F16, EPI_RESID); GL3_RL_LDS(WT_F16, EPI_SWIGLU);
+    GL3_RL_LDS(WT_Q4_0, EPI_STORE); GL3_RL_LDS(WT_Q4_0, EPI_RESID); GL3_RL_LDS(WT_Q4_0, EPI_SWIGLU);
+#undef GL3_RL_LDS
+    TRYHIP(hipFuncSetAttribute((const void*)rmsnorm_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     TRYHIP(hipFuncSetAttribute((const void*)attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     TRYHIP(hipFuncSetAttribute((const void*)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     if ((size_t)d.ctx * 4 + (size_t)PV_ROWS * PV_COLS * 4 + 64 > 150 * 1024) return bail(GL3_E_UNSUPPORTED, "context length above 20k not supported by the decode attention kernel");
@@ -311,7 +345,8 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP(hipHostMalloc((void**)&ctx->h_dyn, 4 * sizeof(int)));
     TRYHIP(hipHostMalloc((void**)&ctx->h_logits, (size_t)d.vocab * 4));
     TRYHIP(hipHostMalloc((void**)&ctx->h_argmax, sizeof(int)));
-    if (d.max_batch > 1) TRY(gl3_prefill_alloc(ctx));
+    // the batched (int8 MFMA) prefill exists for Q8_0 only; F16 / Q4_0 prefill token by token
+    if (d.max_batch > 1 && d.weight_type == GL3_TYPE_Q8_0) TRY(gl3_prefill_alloc(ctx));
     TRYHIP(hipDeviceSynchronize());
 #undef TRY
 #undef TRYHIP
@@ -336,7 +371,7 @@ void gl3_destroy(gl3_ctx* ctx) {
         f(L.wqkv.w); f(L.wo.w); f(L.w1.w); f(L.w3.w); f(L.w2.w);
         f(L.attn_norm); f(L.ffn_norm); f(L.qnorm); f(L.knorm);
     }
-    f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->x); f(ctx->qkv);
+    f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->x); f(ctx->xn); f(ctx->qkv);
     f(ctx->xb); f(ctx->hb); f(ctx->logits); f(ctx->att); f(ctx->dyn); f(ctx->argmax); f(ctx->taps); f(ctx->staging);
     if (ctx->h_dyn) hipHostFree(ctx->h_dyn);
     if (ctx->h_logits) hipHostFree(ctx->h_logits);
@@ -357,15 +392,27 @@ static int32_t stage(gl3_ctx* ctx, const void* host, size_t bytes) {
     return GL3_OK;
 }
 
-// src: full [rows_full x k_full] GGUF Q8_0 tensor on the host; keeps rows [r0, r0+sub_rows), placed at row
-// dst_row0 (multiple of 16) of m.  Only the kept rows are staged (tensor-parallel ranks upload 1/tp of the bytes).
+// src: full [rows_full x k_full] GGUF tensor on the host (Q8_0 / F16 / Q4_0 row-major blocks); keeps rows
+// [r0, r0+sub_rows), placed at row dst_row0 of m.  Only the kept rows are staged (tensor-parallel ranks upload 1/tp of
+// the bytes).
 static int32_t upload_q8(gl3_ctx* ctx, Q8Mat& m, int dst_row0, int sub_rows, const void* host, uint64_t bytes, int rows_full,
                          int k_full, long r0) {
     const int nb_full = k_full / 32;
     if (k_full != m.k) GL3_FAIL(GL3_E_ARG, "tensor inner dimension mismatch");
-    if (bytes != (uint64_t)rows_full * nb_full * 34) GL3_FAIL(GL3_E_ARG, "tensor byte size does not match its shape");
+    const size_t row_bytes = m.fmt == GL3_TYPE_Q8_0 ? (size_t)nb_full * 34 : m.fmt == GL3_TYPE_F16 ? (size_t)k_full * 2 : (size_t)nb_full * 18;
+    if (bytes != (uint64_t)rows_full * row_bytes) GL3_FAIL(GL3_E_ARG, "tensor byte size does not match its shape");
+    const uint8_t* h = (const uint8_t*)host + (size_t)r0 * row_bytes;
+    if (m.fmt != GL3_TYPE_Q8_0) {
+        int32_t r = stage(ctx, h, (size_t)sub_rows * row_bytes);
+        if (r != GL3_OK) return r;
+        const long total = (long)sub_rows * (m.fmt == GL3_TYPE_F16 ? k_full / 8 : nb_full);
+        const dim3 grid((unsigned)((total + 255) / 256));
+        if (m.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((repack_rl_kernel<WT_F16>), grid, dim3(256), 0, ctx->stream, ctx->staging, m.w, sub_rows, k_full, dst_row0);
+        else hipLaunchKernelGGL((repack_rl_kernel<WT_Q4_0>), grid, dim3(256), 0, ctx->stream, ctx->staging, m.w, sub_rows, k_full, dst_row0);
+        GL3_HIP(hipStreamSynchronize(ctx->stream));
+        return GL3_OK;
+    }
     if (dst_row0 % 16) GL3_FAIL(GL3_E_UNSUPPORTED, "sub-matrix row offset must be a multiple of 16");
-    const uint8_t* h = (const uint8_t*)host + (size_t)r0 * nb_full * 34;
     int32_t r = stage(ctx, h, (size_t)sub_rows * nb_full * 34);
     if (r != GL3_OK) return r;
     const long total = (long)((sub_rows + 15) & ~15) * m.ng * 4;
@@ -516,7 +563,8 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
         ctx->wcls = ctx->emb;
         ctx->wcls.rows = ctx->vocab_l;
         ctx->wcls.nstrips = (ctx->vocab_l + 15) / 16;
-        ctx->wcls.w = ctx->emb.w + (size_t)(d.tp_rank * ctx->vocab_l / 16) * ctx->emb.ng * TILE_BYTES;
+        if (ctx->emb.fmt == GL3_TYPE_Q8_0) ctx->wcls.w = ctx->emb.w + (size_t)(d.tp_rank * ctx->vocab_l / 16) * ctx->emb.ng * TILE_BYTES;
+        else ctx->wcls.w = ctx->emb.w + (size_t)(d.tp_rank * ctx->vocab_l / 64) * ctx->emb.rl_group_bytes();
         ctx->wcls_owned = false;
     }
     if (ctx->staging) { hipFree(ctx->staging); ctx->staging = nullptr; ctx->staging_bytes = 0; }
@@ -596,7 +644,7 @@ int32_t gl3_forward_decode_batch(gl3_ctx* ctx, const int32_t* tokens, const int3
     if (!ctx) return GL3_E_ARG;
     if (!tokens || !seq_ids || !positions || n <= 0) GL3_FAIL(GL3_E_ARG, "bad batch arrays");
     if (!ctx->finalized) GL3_FAIL(GL3_E_STATE, "forward before gl3_finalize");
-    if (!ctx->pf) GL3_FAIL(GL3_E_UNSUPPORTED, "batched decode needs max_batch > 1");
+    if (!ctx->pf) GL3_FAIL(GL3_E_UNSUPPORTED, "batched decode needs max_batch > 1 and Q8_0 weights");
     if (n > ctx->d.max_batch) GL3_FAIL(GL3_E_ARG, "batch larger than max_batch");
     for (int i = 0; i < n; ++i) {
         if (tokens[i] < 0 || tokens[i] >= ctx->d.vocab) GL3_FAIL(GL3_E_ARG, "token id out of range");

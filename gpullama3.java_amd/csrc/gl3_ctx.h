@@ -12,13 +12,20 @@
 
 #include "../../include/gpullama3_hip.h"
 
-struct Q8Mat {               // one repacked (Q8T) matrix, see gl3_decode_kernels.h
+struct Q8Mat {               // one repacked matrix: Q8T tiles (gl3_decode_kernels.h) or F16 / Q4_0 row-lane (gl3_rowlane_kernels.h)
     uint8_t* w = nullptr;
     int rows = 0, k = 0;
-    int ng = 0;              // tile groups per strip = ceil(k/32 / 4)
-    int nstrips = 0;         // ceil(rows / 16)
-    size_t bytes() const { return (size_t)(nstrips + (nstrips & 1)) * ng * 2176; }   // even #strips: the prefill GEMM reads 32-row groups
-    size_t algo_bytes() const { return (size_t)rows * (k / 32) * 34; }   // GGUF bytes (no padding)
+    int ng = 0;              // Q8T: tile groups per strip = ceil(k/32 / 4)
+    int nstrips = 0;         // Q8T: ceil(rows / 16)
+    int fmt = 8;             // GL3_TYPE_* of the source tensor (8 = Q8_0, 1 = F16, 2 = Q4_0)
+    size_t rl_group_bytes() const { return fmt == 1 ? (size_t)(k / 8) * 1024 : (size_t)(k / 32) * 1152; }
+    size_t bytes() const {
+        if (fmt != 8) return (size_t)((rows + 63) / 64) * rl_group_bytes();
+        return (size_t)(nstrips + (nstrips & 1)) * ng * 2176;            // even #strips: the prefill GEMM reads 32-row groups
+    }
+    size_t algo_bytes() const {                                          // GGUF bytes (no padding)
+        return fmt == 8 ? (size_t)rows * (k / 32) * 34 : fmt == 1 ? (size_t)rows * k * 2 : (size_t)rows * (k / 32) * 18;
+    }
 };
 
 struct gl3_layer {
@@ -62,6 +69,7 @@ struct gl3_ctx {
     int n_seqs = 1;
     size_t kv_seq_stride = 0;                     // floats per sequence
     float *x = nullptr, *qkv = nullptr, *xb = nullptr, *hb = nullptr, *logits = nullptr, *att = nullptr;
+    float* xn = nullptr;                          // RMS-normalised activation (F16 / Q4_0 path only)
     float* taps = nullptr;                        // [L][dim] when GL3_FLAG_LAYER_TAPS
     int *dyn = nullptr, *argmax = nullptr;        // dyn[0] = token, dyn[1] = position
     int* h_dyn = nullptr;                         // pinned

@@ -28,11 +28,12 @@ def planmod():
     return import_module(ge.PKG_NAME + ".plan"), import_module(ge.PKG_NAME + ".hip")
 
 
-@pytest.mark.parametrize("fx,cfg,seed", [("tiny_llama_q8_0", "tiny-llama", 7), ("tiny_qwen3_q8_0", "tiny-qwen3", 5)])
-def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed):
+@pytest.mark.parametrize("fx,cfg,seed,wtype", [("tiny_llama_q8_0", "tiny-llama", 7, 8), ("tiny_qwen3_q8_0", "tiny-qwen3", 5, 8),
+                                               ("tiny_llama_f16", "tiny-llama", 7, 1), ("tiny_llama_tied_q4_0", "tiny-llama-tied", 11, 2)])
+def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed, wtype):
     plan_mod, hip = planmod
     g = np.load(os.path.join(GOLD, fx + ".npz"))
-    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], seed=seed)
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=seed)
     plan = plan_mod.HipMasterPlan(m, flags=hip.FLAG_LAYER_TAPS)
     toks = g["tokens"]
     n_prompt = len(g["prompt"])
@@ -63,6 +64,32 @@ def test_decode_matches_c_oracle_live(pkg, orc, planmod, cfg):
         for l in range(m.cfg.n_layers):
             assert np.array_equal(plan.layer_x(l), lx[l])
         assert plan.forward_decode_argmax(t, pos) == orc.argmax(ref)     # device argmax = first index of the max
+    plan.freeTornadoExecutionPlan()
+
+
+@pytest.mark.parametrize("cfg,wtype", [("mid-llama", 1), ("mid-qwen3", 2), ("tiny-llama-tied", 1), ("mid-llama", 2)])
+def test_f16_and_q4_0_decode_match_c_oracle_live(pkg, orc, planmod, cfg, wtype):
+    """F16 (FP16FloatTensor scalar dot) and Q4_0 (getFloat + scalarDot) weights — element-wise f32
+    chains, no activation quantisation.  Logits, per-layer x and device argmax bit-identical to the oracle; prefill of
+    these types runs token by token (tornadoVMForwardPrefill semantics) and must leave the same KV cache."""
+    plan_mod, hip = planmod
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=17)
+    plan = plan_mod.HipMasterPlan(m, prefill_batch_size=16, flags=hip.FLAG_LAYER_TAPS)
+    o = orc.COracle(m)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 14)
+    plan.prefill(toks[:6], 0)
+    o.prefill(toks[:6], 0)
+    for pos in range(6, 14):
+        ref, lx = o.forward(toks[pos], pos, layer_x=True)
+        got = plan.tornadoVMForwardDecode(toks[pos], pos)
+        assert np.array_equal(got, ref), (pos, rel(got, ref))
+        for l in range(m.cfg.n_layers):
+            assert np.array_equal(plan.layer_x(l), lx[l])
+        assert plan.forward_decode_argmax(toks[pos], pos) == orc.argmax(ref)
+    for l in range(m.cfg.n_layers):
+        k, v = plan.kv(l, 3)
+        ko, vo = o.kv(l, 3)
+        assert np.array_equal(k, ko) and np.array_equal(v, vo)
     plan.freeTornadoExecutionPlan()
 
 
@@ -103,10 +130,16 @@ def test_error_behaviour(pkg, planmod):
     with pytest.raises(hip.Gl3Error):
         plan.layer_x(0)                                       # taps not enabled
     plan.freeTornadoExecutionPlan()
-    m4 = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], wtype=2, seed=7)
+    m4 = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], wtype=0, seed=7)
     with pytest.raises(hip.Gl3Error) as e:
-        plan_mod.HipMasterPlan(m4)                            # Q4_0: GL3_E_UNSUPPORTED in this build
+        plan_mod.HipMasterPlan(m4)                            # F32 matrices: GL3_E_UNSUPPORTED (Q8_0 / F16 / Q4_0 only)
     assert e.value.code == -2
+    m5 = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], wtype=2, seed=7)
+    plan = plan_mod.HipMasterPlan(m5, prefill_batch_size=8, n_seqs=2)
+    with pytest.raises(hip.Gl3Error) as e:                    # static batched decode is a Q8_0 (int8 MFMA) feature
+        plan.forward_decode_batch([1, 2], [0, 1], [0, 0])
+    assert e.value.code == -2
+    plan.freeTornadoExecutionPlan()
 
 
 @pytest.mark.parametrize("cfg,batch,chunks", [("tiny-llama", 8, [8, 8, 5]), ("mid-llama", 64, [40, 64, 3]), ("mid-qwen3", 32, [30, 7]),
