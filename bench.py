@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pp", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--wtype", default="q8_0", choices=["q8_0", "f16", "q4_0"], help="ggml type of the matrices (default: the headline Q8_0)")
     args = ap.parse_args()
 
     import numpy as np
@@ -81,10 +82,13 @@ def main():
         obj = [plan_mod.make_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(obj, src=0)
         uid = obj[0]
+    wtype = {"q8_0": synth.GGML_Q8_0, "f16": synth.GGML_F16, "q4_0": synth.GGML_Q4_0}[args.wtype]
+    WT = args.wtype.upper()
+    bpe = {"q8_0": 34 / 32, "f16": 2.0, "q4_0": 18 / 32}[args.wtype]          # weight bytes per element
     if keep_host:
-        model = synth.make_torch(cfg, seed=args.seed, device=dev)
+        model = synth.make_torch(cfg, wtype=wtype, seed=args.seed, device=dev)
     else:
-        model = synth.StreamModel(cfg, synth.GGML_Q8_0, synth.iter_torch(cfg, seed=args.seed, device=dev))
+        model = synth.StreamModel(cfg, wtype, synth.iter_torch(cfg, wtype=wtype, seed=args.seed, device=dev))
     plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(model, prefill_batch_size=args.batch, device=local_rank,
                                                            tp_rank=rank, tp_size=world, unique_id=uid)
     torch.cuda.empty_cache()
@@ -157,7 +161,9 @@ def main():
         kclass[name] = dict(avg_us=round(r["avg_us"], 3), bytes_per_launch=r["bytes_per_launch"], gbs=round(r["gbs"], 1),
                             frac_of_hbm_peak=round(r["gbs"] / HBM_PEAK_GBS, 4))
     dom = kclass["matvec_gateup"]
-    roofline = dict(bound="hbm", kernel="matvec_q8t_kernel<PRO_RMS,EPI_SWIGLU> (fused RMSNorm + gate/up Q8_0 matvec + SwiGLU, %dx%d x2)" % (cfg.hidden // world, cfg.dim),
+    kname = "matvec_q8t_kernel<PRO_RMS,EPI_SWIGLU> (fused RMSNorm + gate/up Q8_0 matvec + SwiGLU, %dx%d x2)" if args.wtype == "q8_0" else \
+        "rmsnorm_f32_kernel + matvec_rl_kernel<" + WT + ",EPI_SWIGLU> (gate/up element-wise-chain matvec + SwiGLU, %dx%d x2)"
+    roofline = dict(bound="hbm", kernel=kname % (cfg.hidden // world, cfg.dim),
                     achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(dom["gbs"] / HBM_PEAK_GBS, 4),
                     traffic=None, avg_us=dom["avg_us"], bytes_per_launch=dom["bytes_per_launch"],
                     method="HIP event pair around 20 sweeps x %d layers of back-to-back launches on the plan's stream" % cfg.n_layers)
@@ -169,7 +175,7 @@ def main():
         import glob
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_summary.csv")))[-1]
         for r in csv.reader(open(f)):
-            if "matvec_q8t_kernel<0, 2" in r[0] and world == 1 and args.model == "llama-3-8b":
+            if "matvec_q8t_kernel<0, 2" in r[0] and world == 1 and args.model == "llama-3-8b" and args.wtype == "q8_0":
                 roofline["traffic"] = int(r[-1])
                 roofline["traffic_source"] = os.path.relpath(f, ROOT) + " (FETCH_SIZE, separate rocprofv3 --pmc pass)"
     except Exception:
@@ -179,7 +185,7 @@ def main():
     L, kvd = cfg.n_layers, cfg.kv_dim
     mat_elems = L * (cfg.q_dim * cfg.dim + 2 * kvd * cfg.dim + cfg.dim * cfg.q_dim + 3 * cfg.hidden * cfg.dim) + cfg.vocab * cfg.dim
     avg_pos = (args.n_gen - 1) / 2.0
-    token_bytes = mat_elems * 34 // 32 + (2 * L + 1) * cfg.dim * 4 + cfg.dim // 32 * 34 + 2 * L * kvd * 4 * (avg_pos + 1) \
+    token_bytes = int(mat_elems * bpe) + (2 * L + 1) * cfg.dim * 4 + int(cfg.dim * bpe) + 2 * L * kvd * 4 * (avg_pos + 1) \
         + 2 * L * kvd * 4 + cfg.vocab * 4
     token_gbs = token_bytes * tg_tok_s / 1e9
 
@@ -211,13 +217,14 @@ def main():
         mean = np.mean([args.n_gen / s for s in tg_samples])
         sd = float(np.std([args.n_gen / s for s in tg_samples], ddof=1)) if len(tg_samples) > 1 else 0.0
         out = {
-            "metric": "tg128 tok/s (llama-bench), Llama-3-8B Q8_0" if args.model == "llama-3-8b" else "tg%d tok/s, %s Q8_0" % (args.n_gen, args.model),
+            "metric": "tg128 tok/s (llama-bench), Llama-3-8B Q8_0" if (args.model == "llama-3-8b" and args.wtype == "q8_0" and args.n_gen == 128)
+                      else "tg%d tok/s, %s %s" % (args.n_gen, args.model, WT),
             "value": round(tg_tok_s, 3), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(tg_total / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "i8", "data": "synthetic",
-            "config": {"workload": "%s Q8_0 random-weight GGUF-layout model, tg%d at depth 0 (one step = %d decode tokens, logits D2H "
+            "scaling": "strong", "vs_baseline": None, "dtype": "i8" if args.wtype == "q8_0" else "f32", "data": "synthetic",
+            "config": {"workload": "%s %s random-weight GGUF-layout model, tg%d at depth 0 (one step = %d decode tokens, logits D2H "
                                    "inside the timed region); pp%d -b %d reported beside it" %
-                                   (cfg.name, args.n_gen, args.n_gen, args.n_prompt, args.batch),
+                                   (cfg.name, WT, args.n_gen, args.n_gen, args.n_prompt, args.batch),
                        "parallelism": "tp%d" % world if world > 1 else "single GPU", "ctx": cfg.ctx, "tokens": "java.util.Random(42)"},
             "tg_tok_s_mean": round(float(mean), 3), "tg_tok_s_stddev": round(sd, 3),
             "pp": pp,

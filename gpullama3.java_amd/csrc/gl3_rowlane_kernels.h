@@ -194,7 +194,7 @@ static __global__ __launch_bounds__(256) void matvec_rl_kernel(const RlArgs a) {
     const int row = g * 64 + lane;
     if (row >= a.rows) return;
     if (EPI == EPI_STORE) a.out[row] = res[0];
-    else if (EPI == EPI_RESID) a.out[row] = a.resid_in[row] + res[0];
+    else if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + res[0] : res[0];
     else {
         float gte = res[0];
         gte = gte / (float)(1.0 + exp(-(double)gte));            // InferenceCore.java:155-158
