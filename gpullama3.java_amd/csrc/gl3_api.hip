@@ -65,13 +65,13 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
         }
         RlArgs a{};
         a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.k = w.k; a.x = x; a.out = out; a.resid_in = resid_in;
-        const dim3 grid((w.rows + 255) / 256);
-        const size_t sm = (size_t)w.k * 4;
+        const dim3 grid((w.rows + 63) / 64);
+        const size_t sm = rl_smem_bytes(w.k, epi);
 #define GL3_RL(WT_) \
         do { \
-            if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_rl_kernel<WT_, EPI_STORE>), grid, dim3(256), sm, s, a); \
-            else if (epi == EPI_RESID) hipLaunchKernelGGL((matvec_rl_kernel<WT_, EPI_RESID>), grid, dim3(256), sm, s, a); \
-            else hipLaunchKernelGGL((matvec_rl_kernel<WT_, EPI_SWIGLU>), grid, dim3(256), sm, s, a); \
+            if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_rl_kernel<WT_, EPI_STORE>), grid, dim3(RL_THREADS), sm, s, a); \
+            else if (epi == EPI_RESID) hipLaunchKernelGGL((matvec_rl_kernel<WT_, EPI_RESID>), grid, dim3(RL_THREADS), sm, s, a); \
+            else hipLaunchKernelGGL((matvec_rl_kernel<WT_, EPI_SWIGLU>), grid, dim3(RL_THREADS), sm, s, a); \
         } while (0)
         if (w.fmt == GL3_TYPE_F16) GL3_RL(WT_F16); else GL3_RL(WT_Q4_0);
 #undef GL3_RL
@@ -278,6 +278,10 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     if (d.arch != GL3_ARCH_LLAMA && d.arch != GL3_ARCH_QWEN3) return bail(GL3_E_UNSUPPORTED, "unsupported architecture");
     if (d.weight_type != GL3_TYPE_Q8_0 && d.weight_type != GL3_TYPE_F16 && d.weight_type != GL3_TYPE_Q4_0)
         return bail(GL3_E_UNSUPPORTED, "matrix weight type must be Q8_0, F16 or Q4_0");
+    if (d.weight_type != GL3_TYPE_Q8_0 && (d.dim % 64 || d.hidden % 64 || (d.n_heads * d.head_size) % 64))
+        return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0 matrices need inner dimensions that are multiples of 64");
+    if (d.weight_type != GL3_TYPE_Q8_0 && rl_smem_bytes(d.hidden > d.dim ? d.hidden : d.dim, EPI_STORE) > 150 * 1024)
+        return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0: activation vector does not fit in LDS");
     if (d.weight_type != GL3_TYPE_Q8_0 && d.tp_size > 1 && (d.vocab / d.tp_size) % 64)
         return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0 tensor parallel needs vocab/tp_size to be a multiple of 64");
     if (d.dim <= 0 || d.dim % 32 || d.hidden % 32 || d.n_layers <= 0 || d.n_heads <= 0 || d.n_kv_heads <= 0 ||

@@ -11,8 +11,8 @@
 //   F16  "RL": [row group g = row/64][chunk c = 8 elements][lane = row%64][16 B]              (1024 B per (g, c))
 //   Q4_0 "RL": [row group g][block b][64 x f16 d (128 B)][lane][16 B of nibbles (1024 B)]     (1152 B per (g, b))
 // The activation vector (already RMS-normalised by rmsnorm_f32_kernel when the reference normalises first) sits in LDS
-// and is read as wavefront-uniform float4 broadcasts.  The kernels are latency-bound by the chain itself
-// (K dependent adds per row); they exist for parity on §8 rows a5 / a6, the HBM-roofline target is the Q8_0 path.
+// and is read as wavefront-uniform float4 broadcasts.  The products are computed in parallel by producer wavefronts;
+// the kernels stay bound by the K dependent adds of the chain itself (about 5-6 cycles per element per row).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -101,96 +101,144 @@ struct RlArgs {
     float* out; const float* resid_in;      // EPI_RESID: out[i] = resid_in[i] + result
 };
 
-// Workgroup = 4 wavefronts = 4 row groups; the activation is staged in LDS once per workgroup.
+// Workgroup = one 64-row group, 9 wavefronts in two roles (as in matvec_q8t_kernel, register pressure = max of the roles):
+//   producers (waves 1-8): lane = (row, 8 consecutive elements of the current 64-element tile): one 16-byte (F16) or
+//       8-byte (Q4_0) weight load, kept RL_D tiles ahead in registers, p = w * x (Q4_0: ((q - 8) * d) * x) written to a
+//       double-buffered LDS tile P[row][64] (pitch 68: conflict-free 16-byte rows);
+//   chain (wave 0, raised priority): lane = row, result += p in element order — the only serial part of the reference's dot product —
+//       and the epilogue.
+// One workgroup barrier per tile: producers fill tile i+1 while the chain consumes tile i.
+constexpr int RL_T = 64, RL_PITCH = 68, RL_NP = 8, RL_THREADS = 64 * (RL_NP + 1), RL_D = 8;
+
+__host__ __device__ inline size_t rl_smem_bytes(int k, int epi) {
+    return ((size_t)k + (size_t)2 * (epi == EPI_SWIGLU ? 2 : 1) * 64 * RL_PITCH) * 4;
+}
+
 template <int WT, int EPI>
-static __global__ __launch_bounds__(256) void matvec_rl_kernel(const RlArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];   // [k]
+static __global__ __launch_bounds__(RL_THREADS) void matvec_rl_kernel(const RlArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [k] | P[2][NM][64][RL_PITCH]
     constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int i = t; i < (a.k >> 2); i += 256) *reinterpret_cast<float4*>(xs + 4 * i) = *reinterpret_cast<const float4*>(a.x + 4 * i);
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    const int t = threadIdx.x, lane = t & 63;
+    // wavefront 0 (the oldest: wins issue arbitration on its SIMD) runs the chain; producers are role-waves 0..7
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6) - 1;
+#ifdef GL3_RL_TIMING
+    const unsigned long long tstart = __builtin_readcyclecounter();
+#endif
+    float* P = xs + a.k;
+    for (int i = t; i < (a.k >> 2); i += RL_THREADS) *reinterpret_cast<float4*>(xs + 4 * i) = *reinterpret_cast<const float4*>(a.x + 4 * i);
     __syncthreads();
-    const int g = blockIdx.x * 4 + wave;
-    if (g * 64 >= a.rows) return;
+    const int g = blockIdx.x, ntiles = a.k / RL_T;
     const size_t gbytes = rl_group_bytes(WT, a.k);
-    const uint8_t* wp[NM];
-    wp[0] = a.w + (size_t)g * gbytes;
-    if (NM == 2) wp[NM - 1] = a.w2 + (size_t)g * gbytes;
+
+    if (wave >= 0) {
+        // ------------------------------------------------------------------ producers
+        const uint8_t* wp[NM];
+        wp[0] = a.w + (size_t)g * gbytes;
+        if (NM == 2) wp[NM - 1] = a.w2 + (size_t)g * gbytes;
+        // Q4_0 unit: block-in-tile bt, nibble half h, byte quarter q8 -> elements 32*bt + 16*h + 8*q8 + i
+        const int bt = wave >> 2, h = (wave >> 1) & 1, q8 = wave & 1;
+        v4i raw16[NM][RL_D];      // F16: 8 halfs
+        v2i raw8[NM][RL_D];       // Q4_0: 8 bytes of nibbles
+        uint16_t dsc[NM][RL_D];   // Q4_0: block scale
+        auto load = [&](int m, int u, int tile) {
+            if (WT == WT_F16) {
+                raw16[m][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(wp[m] + (size_t)(tile * 8 + wave) * 1024 + lane * 16));
+            } else {
+                const uint8_t* pb = wp[m] + (size_t)(tile * 2 + bt) * 1152;
+                raw8[m][u] = *reinterpret_cast<const v2i*>(pb + 128 + lane * 16 + 8 * q8);
+                dsc[m][u] = *reinterpret_cast<const uint16_t*>(pb + 2 * lane);
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < RL_D; ++u)
+            if (u < ntiles)
+#pragma unroll
+                for (int m = 0; m < NM; ++m) load(m, u, u);
+        for (int base = 0; base < ntiles; base += RL_D) {
+#pragma unroll
+            for (int u = 0; u < RL_D; ++u) {
+                const int tile = base + u;
+                if (tile < ntiles) {
+                    const int e0 = WT == WT_F16 ? wave * 8 : 32 * bt + 16 * h + 8 * q8;     // first element within the tile
+                    const float4 x0 = *reinterpret_cast<const float4*>(xs + tile * RL_T + e0);
+                    const float4 x1 = *reinterpret_cast<const float4*>(xs + tile * RL_T + e0 + 4);
+                    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        float pv[8];
+                        if (WT == WT_F16) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const uint32_t word = (uint32_t)raw16[m][u][i >> 1];
+                                pv[i] = h2f((uint16_t)((i & 1) ? word >> 16 : word & 0xFFFF)) * xv[i];
+                            }
+                        } else {
+                            const float d = h2f(dsc[m][u]);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const uint32_t word = (uint32_t)raw8[m][u][i >> 2];
+                                const int q = (int)((word >> (8 * (i & 3) + 4 * h)) & 0xF);
+                                pv[i] = ((float)(q - 8) * d) * xv[i];
+                            }
+                        }
+                        float* dst = P + ((size_t)((tile & 1) * NM + m) * 64 + lane) * RL_PITCH + e0;
+                        *reinterpret_cast<float4*>(dst) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                        *reinterpret_cast<float4*>(dst + 4) = make_float4(pv[4], pv[5], pv[6], pv[7]);
+                        if (tile + RL_D < ntiles) load(m, u, tile + RL_D);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    // ---------------------------------------------------------------------- chain wavefront (lane = row)
+    __builtin_amdgcn_s_setprio(3);
     float res[NM];
 #pragma unroll
     for (int m = 0; m < NM; ++m) res[m] = 0.f;
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    if (WT == WT_F16) {
-        const int nch = a.k >> 3;
-        constexpr int U = 4;                                     // chunks in flight
-        int c = 0;
-        for (; c + U <= nch; c += U) {
-            v4i wv[NM][U];
+#ifdef GL3_RL_TIMING
+    unsigned long long ts[4] = {0, 0, 0, 0};
+#endif
+    for (int tile = 0; tile < ntiles; ++tile) {
+#ifdef GL3_RL_TIMING
+        if (tile == 8) ts[0] = __builtin_readcyclecounter();
+#endif
+        __syncthreads();
+#ifdef GL3_RL_TIMING
+        if (tile == 8) ts[1] = __builtin_readcyclecounter();
+        if (tile == 0) ts[3] = __builtin_readcyclecounter();
+#endif
+        float4 pv[NM][RL_T / 4];
 #pragma unroll
-            for (int m = 0; m < NM; ++m)
+        for (int m = 0; m < NM; ++m)
 #pragma unroll
-                for (int u = 0; u < U; ++u) wv[m][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(wp[m] + (size_t)(c + u) * 1024 + lane * 16));
+            for (int c = 0; c < RL_T / 4; ++c)
+                pv[m][c] = *reinterpret_cast<const float4*>(P + ((size_t)((tile & 1) * NM + m) * 64 + lane) * RL_PITCH + 4 * c);
+        // a dependent f32 add issues every ~8 cycles: the two chains of the SwiGLU pair alternate instruction by instruction
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float4 x0 = *reinterpret_cast<const float4*>(xs + 8 * (c + u)), x1 = *reinterpret_cast<const float4*>(xs + 8 * (c + u) + 4);
-                const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        for (int c = 0; c < RL_T / 4; ++c) {
 #pragma unroll
-                for (int m = 0; m < NM; ++m)
+            for (int m = 0; m < NM; ++m) res[m] = res[m] + pv[m][c].x;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const uint32_t word = (uint32_t)wv[m][u][i >> 1];
-                        res[m] = res[m] + h2f((uint16_t)((i & 1) ? word >> 16 : word & 0xFFFF)) * xv[i];
-                    }
-            }
+            for (int m = 0; m < NM; ++m) res[m] = res[m] + pv[m][c].y;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) res[m] = res[m] + pv[m][c].z;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) res[m] = res[m] + pv[m][c].w;
         }
-        for (; c < nch; ++c)
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const v4i wv = *reinterpret_cast<const v4i*>(wp[m] + (size_t)c * 1024 + lane * 16);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const uint32_t word = (uint32_t)wv[i >> 1];
-                    res[m] = res[m] + h2f((uint16_t)((i & 1) ? word >> 16 : word & 0xFFFF)) * xs[8 * c + i];
-                }
-            }
-    } else {
-        const int nb = a.k >> 5;
-        constexpr int U = 2;                                     // blocks in flight
-        auto block = [&](int m, int b, const v4i& qv, uint16_t dh) {
-            const float d = h2f(dh);
-            const float* xb = xs + 32 * b;
-#pragma unroll
-            for (int half = 0; half < 2; ++half)                 // elements 0..15 = low nibbles, 16..31 = high nibbles
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint32_t word = (uint32_t)qv[j >> 2];
-                    const int q = (int)((word >> (8 * (j & 3) + 4 * half)) & 0xF);
-                    res[m] = res[m] + ((float)(q - 8) * d) * xb[16 * half + j];
-                }
-        };
-        int b = 0;
-        for (; b + U <= nb; b += U) {
-            v4i qv[NM][U];
-            uint16_t dh[NM][U];
-#pragma unroll
-            for (int m = 0; m < NM; ++m)
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint8_t* p = wp[m] + (size_t)(b + u) * 1152;
-                    dh[m][u] = *reinterpret_cast<const uint16_t*>(p + 2 * lane);
-                    qv[m][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p + 128 + lane * 16));
-                }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int m = 0; m < NM; ++m) block(m, b + u, qv[m][u], dh[m][u]);
-        }
-        for (; b < nb; ++b)
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const uint8_t* p = wp[m] + (size_t)b * 1152;
-                block(m, b, *reinterpret_cast<const v4i*>(p + 128 + lane * 16), *reinterpret_cast<const uint16_t*>(p + 2 * lane));
-            }
+#ifdef GL3_RL_TIMING
+        if (tile == 8) { asm volatile("" :: "v"(res[0])); ts[2] = __builtin_readcyclecounter(); }
+        if (tile == 9 && lane == 0 && blockIdx.x == 0) printf("rl chain k=%d NM=%d: barrier wait %llu, reads+adds %llu, tile period %llu\n", a.k, NM, ts[1] - ts[0], ts[2] - ts[1], __builtin_readcyclecounter() - ts[2] + ts[2] - ts[0]);
+#endif
     }
+    __syncthreads();
+#ifdef GL3_RL_TIMING
+    if (lane == 0 && blockIdx.x == 0) printf("rl total k=%d NM=%d: first tile ready at %llu, tile8 start %llu, end %llu\n", a.k, NM, ts[3] - tstart, ts[0] - tstart, __builtin_readcyclecounter() - tstart);
+#endif
     const int row = g * 64 + lane;
     if (row >= a.rows) return;
     if (EPI == EPI_STORE) a.out[row] = res[0];
