@@ -42,8 +42,8 @@ static size_t matvec_smem(int pro, int epi, const Q8Mat& w) {
 
 template <int PRO, int EPI>
 static void launch_matvec_t(const MatvecArgs& a, int wgs, size_t smem, hipStream_t s, bool nt) {
-    if (nt) hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, true>), dim3(wgs), dim3(MV_THREADS), smem, s, a);
-    else hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, false>), dim3(wgs), dim3(MV_THREADS), smem, s, a);
+    if (nt) hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, true>), dim3(wgs), dim3(mv_threads(4)), smem, s, a);
+    else hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, false>), dim3(wgs), dim3(mv_threads(4)), smem, s, a);
 }
 
 template <int PRO, int EPI>
@@ -85,7 +85,12 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
     const int wgs = w.nstrips < max_wgs ? w.nstrips : max_wgs;
     const size_t smem = matvec_smem(pro, epi, w);
     if (pro == PRO_RMS && epi == EPI_STORE) launch_matvec_t<PRO_RMS, EPI_STORE>(a, wgs, smem, ctx->stream, nt);
-    else if (pro == PRO_QUANT && epi == EPI_RESID) launch_matvec_t<PRO_QUANT, EPI_RESID>(a, wgs, smem, ctx->stream, nt);
+    else if (pro == PRO_QUANT && epi == EPI_RESID) {
+        static const int wide_max = getenv("GL3_WIDE_STRIPS") ? atoi(getenv("GL3_WIDE_STRIPS")) : 256;
+        if (w.nstrips <= wide_max && nt)      // one workgroup per CU: 8 producer wavefronts
+            hipLaunchKernelGGL((matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 8>), dim3(wgs), dim3(mv_threads(8)), smem, ctx->stream, a);
+        else launch_matvec_t<PRO_QUANT, EPI_RESID>(a, wgs, smem, ctx->stream, nt);
+    }
     else launch_matvec_t<PRO_RMS, EPI_SWIGLU>(a, wgs, smem, ctx->stream, nt);
 }
 
@@ -335,6 +340,7 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP((allow_big_lds<PRO_RMS, EPI_STORE>()));
     TRYHIP((allow_big_lds<PRO_QUANT, EPI_RESID>()));
     TRYHIP((allow_big_lds<PRO_RMS, EPI_SWIGLU>()));
+    TRYHIP(hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
 #define GL3_RL_LDS(...) TRYHIP(hipFuncSetAttribute((const void*)matvec_rl_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
     GL3_RL_LDS(WT_F16, EPI_STORE); GL3_RL_LDS(WT_F16, EPI_RESID); GL3_RL_LDS(WT_F16, EPI_SWIGLU);
     GL3_RL_LDS(WT_Q4_0, EPI_STORE); GL3_RL_LDS(WT_Q4_0, EPI_RESID); GL3_RL_LDS(WT_Q4_0, EPI_SWIGLU);

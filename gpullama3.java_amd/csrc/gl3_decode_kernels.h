@@ -34,9 +34,10 @@
 namespace gl3 {
 
 constexpr int TILE_BYTES = 2176;       // 64 Q8_0 blocks
-constexpr int MV_PRODUCERS = 4;        // wavefronts streaming weights
 constexpr int MV_AUX = 4;               // wavefronts running the prologue; the first one then runs the ordered sums
-constexpr int MV_THREADS = 64 * (MV_PRODUCERS + MV_AUX);
+// NPW = wavefronts streaming weights: 4, or 8 for matrices with <= 256 strips (wo / down), where only one workgroup
+// lands on a CU and four wavefronts cannot keep enough bytes in flight (each alternates issue -> wait -> dot).
+__host__ __device__ constexpr int mv_threads(int npw) { return 64 * (npw + MV_AUX); }
 
 enum { PRO_RMS = 0, PRO_QUANT = 1 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2 };
@@ -156,8 +157,9 @@ __device__ __forceinline__ uint16_t ld2(const uint8_t* p) {
 //       the epilogue while the producers already stream the next strip.
 // Register pressure is the maximum of the roles, not their sum (wave-uniform branches).
 //   LDS: xq[ng*128] | xs[ng*4] f32 | xf[k + 32] f32 (PRO_RMS) | pbuf[2][NM][ng*64] f32 | red[4] | sync[4]
-template <int PRO, int EPI, bool NT>
-__global__ __launch_bounds__(MV_THREADS, 4) void matvec_q8t_kernel(const MatvecArgs a) {
+template <int PRO, int EPI, bool NT, int NPW = 4>
+__global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_kernel(const MatvecArgs a) {
+    constexpr int MV_PRODUCERS = NPW;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int CH = (NM == 1) ? 8 : 4;             // tiles in flight per producer wave
