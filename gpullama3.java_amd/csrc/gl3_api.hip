@@ -154,7 +154,7 @@ static int32_t all_gather(gl3_ctx* ctx, int which, int count_per_rank, Prof& pr)
     return GL3_OK;
 }
 
-static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores, 2 softmax+pv */) {
+static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores, 2 softmax+pv */, bool short_ctx = false) {
     const gl3_model_desc& d = ctx->d;
     gl3_layer& L = ctx->layers[l];
     const size_t kv_layer = (size_t)d.ctx * ctx->kv_dim_l;
@@ -169,11 +169,16 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
     const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 4) + d.head_size) * 4;
     const int pv_rows = d.ctx < PV_ROWS ? d.ctx : PV_ROWS;
     const size_t sm2 = ((size_t)((d.ctx + 3) & ~3) + (size_t)pv_rows * PV_COLS) * 4;
+    if (which == 0 && short_ctx && ctx->fused_attn_ok) {      // positions < AF_MAXN: one launch
+        hipLaunchKernelGGL(attn_fused_kernel, dim3(ctx->kv_heads_l), dim3(128 * kvmul), attn_fused_smem(d.head_size, kvmul), ctx->stream, aa);
+        return;
+    }
     if (which != 2) hipLaunchKernelGGL(attn_scores_kernel, dim3(ctx->n_tsplit, ctx->kv_heads_l), dim3(64 * kvmul), sm1, ctx->stream, aa);
     if (which != 1) hipLaunchKernelGGL(attn_softmax_pv_kernel, dim3(ctx->heads_l * (d.head_size / PV_COLS)), dim3(256), sm2, ctx->stream, aa);
 }
 
-static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* kt) {
+// short_ctx: the position is known (by the host) to be < AF_MAXN
+static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* kt, bool short_ctx) {
     const gl3_model_desc& d = ctx->d;
     hipStream_t s = ctx->stream;
     Prof pr{ctx, kt};
@@ -193,7 +198,7 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         pr.end();
 
         pr.begin(GL3_K_ATTENTION, 0);
-        launch_attention(ctx, l, 0);
+        launch_attention(ctx, l, 0, short_ctx);
         pr.end();
         if ((r = all_gather(ctx, GB_XB, ctx->q_dim_l, pr)) != GL3_OK) return r;
 
@@ -340,6 +345,14 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP((allow_big_lds<PRO_RMS, EPI_STORE>()));
     TRYHIP((allow_big_lds<PRO_QUANT, EPI_RESID>()));
     TRYHIP((allow_big_lds<PRO_RMS, EPI_SWIGLU>()));
+    {
+        const int kvmul = d.n_heads / d.n_kv_heads;
+        // measured: wins for head_size 64 (Llama-3.2-1B tg128 +4 %), loses for 128 (K/V tiles of 128 KB per workgroup)
+        const int hs_max = getenv("GL3_FUSED_ATTN_HS") ? atoi(getenv("GL3_FUSED_ATTN_HS")) : 64;
+        ctx->fused_attn_ok = kvmul <= 4 && d.head_size <= hs_max && d.head_size <= 128 && d.head_size % 4 == 0 && attn_fused_smem(d.head_size, kvmul) <= 150 * 1024 &&
+                             !env_flag("GL3_NO_FUSED_ATTN", false);
+        if (ctx->fused_attn_ok) TRYHIP(hipFuncSetAttribute((const void*)attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    }
     TRYHIP(hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
 #define GL3_RL_LDS(...) TRYHIP(hipFuncSetAttribute((const void*)matvec_rl_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
     GL3_RL_LDS(WT_F16, EPI_STORE); GL3_RL_LDS(WT_F16, EPI_RESID); GL3_RL_LDS(WT_F16, EPI_SWIGLU);
@@ -370,6 +383,8 @@ void gl3_destroy(gl3_ctx* ctx) {
     hipSetDevice(ctx->d.device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx->graph_exec_s) hipGraphExecDestroy(ctx->graph_exec_s);
+    if (ctx->graph_s) hipGraphDestroy(ctx->graph_s);
     if (ctx->graph) hipGraphDestroy(ctx->graph);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     gl3_prefill_free(ctx);
@@ -545,9 +560,9 @@ int32_t gl3_tp_init(gl3_ctx* ctx, const void* unique_id, uint64_t bytes) {
     return GL3_OK;
 }
 
-static int32_t capture(gl3_ctx* ctx, bool want_logits, hipGraph_t* g, hipGraphExec_t* ge) {
+static int32_t capture(gl3_ctx* ctx, bool want_logits, bool short_ctx, hipGraph_t* g, hipGraphExec_t* ge) {
     GL3_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    int32_t r = enqueue_decode(ctx, want_logits, nullptr);
+    int32_t r = enqueue_decode(ctx, want_logits, nullptr, short_ctx);
     hipError_t e = hipStreamEndCapture(ctx->stream, g);
     if (r != GL3_OK) return r;
     GL3_HIP(e);
@@ -581,9 +596,10 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
     ctx->finalized = true;
     if (!(d.flags & GL3_FLAG_NO_GRAPH) && !env_flag("GL3_NO_GRAPH", false) && !ctx->lgrp) {
         const double t0 = now_ms();
-        int32_t r = capture(ctx, true, &ctx->graph, &ctx->graph_exec);
+        int32_t r = capture(ctx, true, false, &ctx->graph, &ctx->graph_exec);
+        if (r == GL3_OK && ctx->fused_attn_ok) r = capture(ctx, true, true, &ctx->graph_s, &ctx->graph_exec_s);
         if (r != GL3_OK) {   // e.g. a collective that cannot be captured: run eagerly instead
-            ctx->graph_exec = nullptr;
+            ctx->graph_exec = nullptr; ctx->graph_exec_s = nullptr;
             (void)hipGetLastError();
             fprintf(stderr, "[gl3] hipGraph capture failed (%s); falling back to eager launches\n", ctx->err.c_str());
         }
@@ -609,8 +625,9 @@ int32_t gl3_forward_decode(gl3_ctx* ctx, int32_t token, int32_t pos, float* logi
     int32_t r = set_dyn(ctx, token, pos);
     if (r != GL3_OK) return r;
     const bool want_logits = logits_out || argmax_out;
-    if (ctx->graph_exec && want_logits) GL3_HIP(hipGraphLaunch(ctx->graph_exec, ctx->stream));
-    else if ((r = enqueue_decode(ctx, want_logits, nullptr)) != GL3_OK) return r;
+    const bool short_ctx = ctx->fused_attn_ok && pos < AF_MAXN;
+    if (ctx->graph_exec && want_logits) GL3_HIP(hipGraphLaunch(short_ctx && ctx->graph_exec_s ? ctx->graph_exec_s : ctx->graph_exec, ctx->stream));
+    else if ((r = enqueue_decode(ctx, want_logits, nullptr, short_ctx)) != GL3_OK) return r;
     if (argmax_out) {
         hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->logits, ctx->d.vocab, ctx->argmax);
         GL3_HIP(hipMemcpyAsync(ctx->h_argmax, ctx->argmax, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -639,7 +656,7 @@ int32_t gl3_forward_prefill_seq(gl3_ctx* ctx, int32_t seq, const int32_t* tokens
     for (int i = 0; i < n; ++i) {
         int32_t r = set_dyn(ctx, tokens[i], start_pos + i);
         if (r != GL3_OK) return r;
-        if ((r = enqueue_decode(ctx, false, nullptr)) != GL3_OK) return r;
+        if ((r = enqueue_decode(ctx, false, nullptr, ctx->fused_attn_ok && start_pos + i < AF_MAXN)) != GL3_OK) return r;
         GL3_HIP(hipStreamSynchronize(ctx->stream));
     }
     return GL3_OK;
@@ -670,7 +687,7 @@ int32_t gl3_profile_decode(gl3_ctx* ctx, int32_t token, int32_t pos, gl3_kernel_
     memset(out, 0, sizeof(*out));
     int32_t r = set_dyn(ctx, token, pos);
     if (r != GL3_OK) return r;
-    return enqueue_decode(ctx, true, out);
+    return enqueue_decode(ctx, true, out, ctx->fused_attn_ok && pos < AF_MAXN);
 }
 
 int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* out_us, uint64_t* bytes_per_launch) {

@@ -84,6 +84,9 @@ struct gl3_ctx {
     bool finalized = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;          // decode step incl. logits
+    hipGraph_t graph_s = nullptr;
+    hipGraphExec_t graph_exec_s = nullptr;        // same step with the fused short-context attention (pos < AF_MAXN)
+    bool fused_attn_ok = false;                   // shape admits attn_fused_kernel
     ncclComm_t comm = nullptr;
     gl3_local_group* lgrp = nullptr;
     bool use_rccl = false;                        // tensor-parallel gathers are active (RCCL or local group)

@@ -496,6 +496,158 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Short-context decode attention in ONE launch (positions < AF_MAXN): RoPE + KV write + scores + softmax + weighted V
+// sum for one kv head and its kvMul query heads.  Same arithmetic and order as the two kernels above/below; what it
+// saves is a launch and three dependent global round trips (scores -> HBM -> softmax, V after the softmax), which is
+// most of the time at tg128 depth 0.  Grid = n_kv_heads, block = 128 x kvMul (kvMul <= 4): wavefront = (query head,
+// score tile); after the scores one wavefront per query head does softmax and the V sum.
+//   LDS: q[kvMul][hs] | K[AF_MAXN][hs+4] | V[AF_MAXN][hs] | e[kvMul][AF_MAXN] | rope row
+constexpr int AF_MAXN = 128;
+__host__ __device__ inline size_t attn_fused_smem(int hs, int kvmul) {
+    return ((size_t)kvmul * hs + (size_t)AF_MAXN * (hs + 4) + (size_t)AF_MAXN * hs + (size_t)kvmul * AF_MAXN + hs) * 4;
+}
+
+static __global__ __launch_bounds__(512) void attn_fused_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads, half = hs >> 1, pitch = hs + 4, q4 = hs >> 2;
+    float* q_s = sm;
+    float* kt = q_s + kvmul * hs;
+    float* vt = kt + AF_MAXN * pitch;
+    float* e_s = vt + AF_MAXN * hs;
+    float* cr_s = e_s + kvmul * AF_MAXN;
+    float* ci_s = cr_s + half;
+    const int t = threadIdx.x, nthr = blockDim.x, kvh = blockIdx.x;
+    const int pos = a.dyn[1], n = pos + 1;
+    // ---- one global round trip: cached K / V rows, raw q / k / v of this token, the RoPE row
+    const int nk4 = pos * q4;
+    constexpr int KMAX = 8;
+    float4 kreg[KMAX], vreg[KMAX];
+    const int per = (nk4 + nthr - 1) / nthr;
+    if (per <= KMAX) {
+#pragma unroll
+        for (int u = 0; u < KMAX; ++u) {
+            const int i = t + u * nthr;
+            if (u < per && i < nk4) {
+                const size_t off = (size_t)(i / q4) * a.kv_dim + kvh * hs + 4 * (i % q4);
+                kreg[u] = *reinterpret_cast<const float4*>(a.kcache + off);
+                vreg[u] = *reinterpret_cast<const float4*>(a.vcache + off);
+            }
+        }
+    }
+    for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.qkv[(kvh * kvmul) * hs + i];
+    for (int i = t; i < half; i += nthr) { cr_s[i] = a.rope_cr[(size_t)pos * half + i]; ci_s[i] = a.rope_ci[(size_t)pos * half + i]; }
+    float* krow = kt + pos * pitch;
+    for (int i = t; i < hs; i += nthr) {
+        krow[i] = a.qkv[a.q_dim + kvh * hs + i];
+        vt[pos * hs + i] = a.qkv[a.q_dim + a.kv_dim + kvh * hs + i];
+    }
+    if (per <= KMAX) {
+#pragma unroll
+        for (int u = 0; u < KMAX; ++u) {
+            const int i = t + u * nthr;
+            if (u < per && i < nk4) {
+                *reinterpret_cast<float4*>(kt + (i / q4) * pitch + 4 * (i % q4)) = kreg[u];
+                *reinterpret_cast<float4*>(vt + (i / q4) * hs + 4 * (i % q4)) = vreg[u];
+            }
+        }
+    } else {
+        for (int i = t; i < nk4; i += nthr) {
+            const size_t off = (size_t)(i / q4) * a.kv_dim + kvh * hs + 4 * (i % q4);
+            *reinterpret_cast<float4*>(kt + (i / q4) * pitch + 4 * (i % q4)) = *reinterpret_cast<const float4*>(a.kcache + off);
+            *reinterpret_cast<float4*>(vt + (i / q4) * hs + 4 * (i % q4)) = *reinterpret_cast<const float4*>(a.vcache + off);
+        }
+    }
+    __syncthreads();
+    if (a.arch == 1) {
+        if (t < kvmul) head_rmsnorm_1t(q_s + t * hs, a.qnorm, hs, a.eps);
+        if (t == kvmul) head_rmsnorm_1t(krow, a.knorm, hs, a.eps);
+        __syncthreads();
+    }
+    for (int h = 0; h < kvmul; ++h) rope_head(q_s + h * hs, hs, cr_s, ci_s, a.arch, t, nthr);
+    rope_head(krow, hs, cr_s, ci_s, a.arch, t, nthr);
+    __syncthreads();
+    if (t < hs) {                                    // KV write, InferenceCore.java:92-93
+        a.kcache[(size_t)pos * a.kv_dim + kvh * hs + t] = krow[t];
+        a.vcache[(size_t)pos * a.kv_dim + kvh * hs + t] = vt[pos * hs + t];
+    }
+    // wavefront w: query head w % kvMul, score tile w / kvMul (two tiles of 64 timesteps run side by side)
+    const int wv = t >> 6, hq = wv % kvmul, mytile = wv / kvmul, r = t & 63;
+    float* e = e_s + hq * AF_MAXN;
+    const float sqrt_hs = (float)sqrt((double)hs);
+    {
+        const int tt = mytile * 64 + r;
+        if (tt < n) {
+            const float* q = q_s + hq * hs;
+            const float* kk = kt + tt * pitch;
+            float score = 0.f;                       // strict j order, mul then add (FloatTensor.scalarDot)
+            float4 qv = *reinterpret_cast<const float4*>(q), kv = *reinterpret_cast<const float4*>(kk);
+            for (int j = 4; j < hs; j += 4) {
+                const float4 qn = *reinterpret_cast<const float4*>(q + j), kn = *reinterpret_cast<const float4*>(kk + j);
+                score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
+                qv = qn; kv = kn;
+            }
+            score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
+            e[tt] = score / sqrt_hs;
+        }
+    }
+    __syncthreads();
+    if (mytile != 0) return;                         // the first kvMul wavefronts carry on: one per query head
+    float sc[AF_MAXN / 64];
+#pragma unroll
+    for (int tile = 0; tile < AF_MAXN / 64; ++tile) {
+        const int tt = tile * 64 + r;
+        sc[tile] = tt < n ? e[tt] : -INFINITY;
+    }
+    // softmax (FloatTensor.softmaxInPlace :211-219): max, exp in double, strict sum, divide
+    float mx = sc[0];
+#pragma unroll
+    for (int tile = 1; tile < AF_MAXN / 64; ++tile) mx = fmaxf(mx, sc[tile]);
+    mx = wave_max(mx);
+#pragma unroll
+    for (int tile = 0; tile < AF_MAXN / 64; ++tile) {
+        const int tt = tile * 64 + r;
+        if (tt < n) { sc[tile] = (float)exp((double)(sc[tile] - mx)); e[tt] = sc[tile]; }
+    }
+    __syncthreads();
+    const float sum = seq_sum_lds<false>(e, n);
+    __syncthreads();
+#pragma unroll
+    for (int tile = 0; tile < AF_MAXN / 64; ++tile) {
+        const int tt = tile * 64 + r;
+        if (tt < n) e[tt] = sc[tile] / sum;
+    }
+    __syncthreads();
+    // weighted V sum, t ascending: xb[j] = a_t * v[t][j] + xb[j] (saxpyInPlace :221-227); lane = 1 or 2 columns
+    const int nc = hs > 64 ? 2 : 1;
+    const int c0 = r * nc;
+    float acc0 = 0.f, acc1 = 0.f;
+    if (c0 < hs) {
+        int tt = 0;
+        for (; tt + 4 <= n; tt += 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(e + tt);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (nc == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(vt + (tt + i) * hs + c0);
+                    acc0 = av[i] * v.x + acc0; acc1 = av[i] * v.y + acc1;
+                } else acc0 = av[i] * vt[(tt + i) * hs + c0] + acc0;
+            }
+        }
+        for (; tt < n; ++tt) {
+            const float at = e[tt];
+            if (nc == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(vt + tt * hs + c0);
+                acc0 = at * v.x + acc0; acc1 = at * v.y + acc1;
+            } else acc0 = at * vt[tt * hs + c0] + acc0;
+        }
+        float* o = a.xb + (size_t)(kvh * kvmul + hq) * hs + c0;
+        o[0] = acc0;
+        if (nc == 2) o[1] = acc1;
+    }
+}
+
 // Decode attention, part 2: softmax + weighted V sum.   Grid = n_heads x hs/16, block = 256.
 //   FloatTensor.softmaxInPlace :211-219 (max, exp in double, strict sum, divide); saxpyInPlace :221-227 with
 //   t ascending: xb[j] = a_t * v[t][j] + xb[j].

@@ -106,6 +106,40 @@ def test_graph_and_eager_launches_agree_bitwise(pkg, planmod):
     a.freeTornadoExecutionPlan(); b.freeTornadoExecutionPlan()
 
 
+@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3"])        # head sizes 64 and 128 (qwen3: per-head norms, NeoX RoPE)
+def test_fused_short_context_attention_and_the_handover_at_128(pkg, orc, planmod, cfg):
+    """Positions < 128 run attn_fused_kernel (one launch per layer), later ones the scores + softmax/PV pair; both must
+    reproduce the oracle bit for bit, also across the handover, and agree with each other."""
+    plan_mod, hip = planmod
+    base = pkg.synth.CONFIGS[cfg]
+    m = pkg.synth.make_numpy(pkg.synth.ModelConfig(**{**base.__dict__, "ctx": 160}), seed=29)
+    os.environ["GL3_FUSED_ATTN_HS"] = "128"          # default: head sizes <= 64 only (where it is faster)
+    try:
+        plan = plan_mod.HipMasterPlan(m)
+        os.environ["GL3_NO_FUSED_ATTN"] = "1"
+        plain = plan_mod.HipMasterPlan(m)
+    finally:
+        os.environ.pop("GL3_NO_FUSED_ATTN", None)
+        del os.environ["GL3_FUSED_ATTN_HS"]
+    o = orc.COracle(m)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 134)
+    for pos in range(122):
+        plan.forward_decode(toks[pos], pos, copy=False)
+        plain.forward_decode(toks[pos], pos, copy=False)
+    o.prefill(toks[:122], 0)
+    for pos in range(122, 134):
+        ref = o.forward(toks[pos], pos)
+        got = plan.forward_decode(toks[pos], pos)
+        assert np.array_equal(got, ref), (pos, rel(got, ref))
+        assert np.array_equal(plain.forward_decode(toks[pos], pos), ref), pos
+    for l in range(m.cfg.n_layers):
+        for p in (0, 60, 127, 128, 133):
+            k, v = plan.kv(l, p)
+            ko, vo = o.kv(l, p)
+            assert np.array_equal(k, ko) and np.array_equal(v, vo)
+    plan.freeTornadoExecutionPlan(); plain.freeTornadoExecutionPlan()
+
+
 def test_sequential_prefill_then_decode(pkg, orc, planmod):
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], seed=7)
