@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--no-pp", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--wtype", default="q8_0", choices=["q8_0", "f16", "q4_0"], help="ggml type of the matrices (default: the headline Q8_0)")
+    ap.add_argument("--decode-batch", type=int, default=0, help="BASELINE configs[4]: static-batched decode of B independent sequences "
+                    "(e.g. --model qwen3-4b --decode-batch 32); prints its own JSON line instead of the tg/pp line")
     args = ap.parse_args()
 
     import numpy as np
@@ -75,6 +77,8 @@ def main():
 
     cfg = synth.CONFIGS[args.model]
     cfg = synth.ModelConfig(**{**cfg.__dict__, "ctx": args.n_prompt + args.n_gen + 8})   # LlamaBench: max(depth+tokens)+8
+    if args.decode_batch > 0:
+        return bench_decode_batch(args, cfg, synth, plan_mod, pkg, torch, np, dev)
     t0 = time.time()
     keep_host = (world == 1 and not args.no_cpu_baseline)
     uid = None
@@ -242,6 +246,50 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_decode_batch(args, cfg, synth, plan_mod, pkg, torch, np, dev):
+    """BASELINE configs[4]: B independent sequences advance one token per step through the int8-MFMA GEMM path
+    (gl3_forward_decode_batch); one step reads every weight once, so the bound is still HBM.  Greedy ids are returned
+    per step (B x 4 bytes D2H), logits stay on the device as with -Dllama.deviceSample."""
+    B = args.decode_batch
+    cfg = synth.ModelConfig(**{**cfg.__dict__, "ctx": args.n_gen + 8})
+    model = synth.StreamModel(cfg, synth.GGML_Q8_0, synth.iter_torch(cfg, seed=args.seed, device=dev))
+    t0 = time.time()
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(model, prefill_batch_size=B, n_seqs=B)
+    setup_s = time.time() - t0
+    toks = np.asarray(pkg.javarand.bench_tokens(cfg.vocab, args.n_gen * B), np.int32).reshape(args.n_gen, B)
+    seqs = np.arange(B, dtype=np.int32)
+
+    def rep():
+        for i in range(args.n_gen):
+            plan.forward_decode_batch(toks[i], seqs, np.full(B, i, np.int32), want_logits=False)
+
+    for _ in range(args.warmup):
+        rep()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        rep()
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t1
+    steps_s = args.steps * args.n_gen / total
+    L, kvd = cfg.n_layers, cfg.kv_dim
+    mat_elems = L * (cfg.q_dim * cfg.dim + 2 * kvd * cfg.dim + cfg.dim * cfg.q_dim + 3 * cfg.hidden * cfg.dim) + cfg.vocab * cfg.dim
+    step_bytes = mat_elems * 34 // 32 + (2 * L + 1) * cfg.dim * 4
+    gbs = step_bytes * steps_s / 1e9
+    print(json.dumps({
+        "metric": "static-batched decode B=%d tok/s, %s Q8_0" % (B, args.model), "value": round(steps_s * B, 2), "unit": "tok/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(total / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+        "config": {"workload": "%s Q8_0 random weights, %d sequences x %d decode steps from position 0 (one bench step = %d batched "
+                               "steps), greedy ids D2H" % (cfg.name, B, args.n_gen, args.n_gen), "parallelism": "single GPU"},
+        "batched_steps_per_s": round(steps_s, 2), "ms_per_batched_step": round(1e3 / steps_s, 4),
+        "roofline": {"bound": "hbm", "kernel": "whole batched step (weights read once per step)", "achieved": round(gbs, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "bytes_per_step": int(step_bytes)},
+        "init": dict(plan.init_ms(), setup_s=round(setup_s, 2))}))
+    plan.freeTornadoExecutionPlan()
 
 
 if __name__ == "__main__":

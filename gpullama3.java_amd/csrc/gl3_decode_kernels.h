@@ -238,12 +238,18 @@ __global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_
     float scale = 1.0f;
     constexpr int NXV = (PRO == PRO_RMS) ? 5 : 14;       // quads of the activation held in registers per aux thread
     float4 nwv[5], xv[NXV];                              // this thread's RMSNorm weights and activations
+    // all activation loads first: they come from L2, the norm weights behind them from HBM (vmcnt retires in order, and the
+    // activation is needed 5 us before the weights)
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
         const int qd = ta + 256 * i;
-        if (qd < nquads) {
-            xv[i] = *reinterpret_cast<const float4*>(a.x + 4 * qd);
-            if (PRO == PRO_RMS) nwv[i] = *reinterpret_cast<const float4*>(a.norm_w + 4 * qd);
+        if (qd < nquads) xv[i] = *reinterpret_cast<const float4*>(a.x + 4 * qd);
+    }
+    if (PRO == PRO_RMS) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int qd = ta + 256 * i;
+            if (qd < nquads) nwv[i] = *reinterpret_cast<const float4*>(a.norm_w + 4 * qd);
         }
     }
     __syncthreads();                                     // activation loads are queued ahead of the weight stream

@@ -13,17 +13,17 @@ using namespace gl3;
 
 struct Shape { const char* name; int pro, epi, rows, k; };
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, int NPW = 4>
 static float run(const MatvecArgs& a, int wgs, size_t smem, int iters, std::vector<uint8_t*>& wbufs, std::vector<uint8_t*>& w2bufs) {
-    CK(hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    CK(hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO, EPI, true, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     MatvecArgs b = a;
     for (int i = 0; i < 3; ++i) { b.w = wbufs[i % wbufs.size()]; b.w2 = w2bufs.empty() ? nullptr : w2bufs[i % w2bufs.size()];
-        hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, true>), dim3(wgs), dim3(MV_THREADS), smem, 0, b); }
+        hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, true, NPW>), dim3(wgs), dim3(mv_threads(NPW)), smem, 0, b); }
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
     for (int i = 0; i < iters; ++i) { b.w = wbufs[i % wbufs.size()]; b.w2 = w2bufs.empty() ? nullptr : w2bufs[i % w2bufs.size()];
-        hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, true>), dim3(wgs), dim3(MV_THREADS), smem, 0, b); }
+        hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, true, NPW>), dim3(wgs), dim3(mv_threads(NPW)), smem, 0, b); }
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -65,6 +65,7 @@ int main(int argc, char** argv) {
             const int iters = 200;
             float us;
             if (sh.pro == PRO_RMS && sh.epi == EPI_STORE) us = run<PRO_RMS, EPI_STORE>(a, g, smem, iters, wb, w2b);
+            else if (sh.pro == PRO_QUANT && a.nstrips <= 256) us = run<PRO_QUANT, EPI_RESID, 8>(a, g, smem, iters, wb, w2b);
             else if (sh.pro == PRO_QUANT) us = run<PRO_QUANT, EPI_RESID>(a, g, smem, iters, wb, w2b);
             else us = run<PRO_RMS, EPI_SWIGLU>(a, g, smem, iters, wb, w2b);
             { long long st[32]; hipMemcpyFromSymbol(st, HIP_SYMBOL(gl3::gl3_mv_stamp), sizeof(st)); printf("   WG0 cycles: xload %lld sumsq %lld quant %lld | prod0 %lld bar %lld | chain0 wait->start %lld chain %lld\n", st[1]-st[0], st[2]-st[1], st[3]-st[2], st[4]-st[3], st[5]-st[4], st[16]-st[3], st[17]-st[16]); }
