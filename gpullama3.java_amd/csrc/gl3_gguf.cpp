@@ -1,0 +1,327 @@
+// gl3_gguf.cpp — native GGUF v2/v3 reader + weight upload (the on-disk format feeding every kernel).
+// Replaces, for the HIP path, the Java host's loader chain
+//   J/tensor/GGUF.java:43-92 (header, metadata KV, tensor infos), :105-137 (alignment, tensor data offset), :217-311 (value
+//   types); J/model/loader/LlamaModelLoader.java:47-69 / Qwen3ModelLoader.java:48-79 (config keys), :83-98 (tensor names);
+//   J/inference/operation/RoPE.java:6-37 (frequency table)
+// with one mmap and one gl3_upload_tensor per tensor: no 16-byte-header private mapping (GGUF.java:157-194 is a TornadoVM
+// device-buffer trick) and no 2 GiB per-tensor limit (GGMLType.java:70-74 Math.toIntExact).  Host-only C++.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gpullama3_hip.h"
+
+namespace {
+
+enum { GT_U8 = 0, GT_I8, GT_U16, GT_I16, GT_U32, GT_I32, GT_F32, GT_BOOL, GT_STRING, GT_ARRAY, GT_U64, GT_I64, GT_F64 };
+
+struct MetaValue {
+    int type = -1;
+    double num = 0;            // every scalar numeric / bool value
+    std::string str;           // GT_STRING
+    uint64_t array_len = 0;    // GT_ARRAY (elements are skipped, only the length is kept: vocabulary size)
+    int array_type = -1;
+};
+
+struct TensorInfo {
+    std::string name;
+    int n_dims = 0;
+    uint64_t ne[4] = {1, 1, 1, 1};
+    int type = 0;
+    uint64_t offset = 0;       // relative to the tensor-data section
+    uint64_t bytes = 0;
+};
+
+uint64_t type_bytes(int type, uint64_t n) {       // GGMLType.java:5-21 (type size / block size)
+    switch (type) {
+    case GL3_TYPE_F32: return n * 4;
+    case GL3_TYPE_F16: return n * 2;
+    case GL3_TYPE_Q4_0: return n / 32 * 18;
+    case GL3_TYPE_Q8_0: return n / 32 * 34;
+    default: return 0;
+    }
+}
+
+}  // namespace
+
+struct gl3_gguf {
+    int fd = -1;
+    const uint8_t* base = nullptr;
+    size_t size = 0;
+    uint32_t version = 0;
+    uint64_t alignment = 32, data_off = 0;
+    std::map<std::string, MetaValue> meta;
+    std::vector<TensorInfo> tensors;
+    std::map<std::string, int> by_name;
+    std::string err;
+};
+
+namespace {
+
+struct Cursor {
+    const uint8_t* p; const uint8_t* end; bool ok = true;
+    template <class T> T get() {
+        T v{};
+        if (p + sizeof(T) > end) { ok = false; return v; }
+        memcpy(&v, p, sizeof(T)); p += sizeof(T);
+        return v;
+    }
+    std::string str(bool v1_len32 = false) {
+        const uint64_t n = v1_len32 ? get<uint32_t>() : get<uint64_t>();
+        if (!ok || n > (uint64_t)(end - p)) { ok = false; return {}; }
+        std::string s((const char*)p, (size_t)n); p += n;
+        return s;
+    }
+};
+
+bool read_scalar(Cursor& c, int ty, MetaValue& v) {
+    switch (ty) {
+    case GT_U8: v.num = c.get<uint8_t>(); break;
+    case GT_I8: v.num = c.get<int8_t>(); break;
+    case GT_U16: v.num = c.get<uint16_t>(); break;
+    case GT_I16: v.num = c.get<int16_t>(); break;
+    case GT_U32: v.num = c.get<uint32_t>(); break;
+    case GT_I32: v.num = c.get<int32_t>(); break;
+    case GT_F32: v.num = c.get<float>(); break;
+    case GT_BOOL: v.num = c.get<uint8_t>() != 0; break;
+    case GT_U64: v.num = (double)c.get<uint64_t>(); break;
+    case GT_I64: v.num = (double)c.get<int64_t>(); break;
+    case GT_F64: v.num = c.get<double>(); break;
+    case GT_STRING: v.str = c.str(); break;
+    default: return false;
+    }
+    return c.ok;
+}
+
+bool read_value(Cursor& c, int ty, MetaValue& v) {
+    v.type = ty;
+    if (ty != GT_ARRAY) return read_scalar(c, ty, v);
+    v.array_type = (int)c.get<uint32_t>();
+    v.array_len = c.get<uint64_t>();
+    if (!c.ok || v.array_type == GT_ARRAY) return false;      // nested arrays do not occur in model files
+    static const int fixed[] = {1, 1, 2, 2, 4, 4, 4, 1, 0, 0, 8, 8, 8};
+    if (v.array_type == GT_STRING) {
+        for (uint64_t i = 0; i < v.array_len && c.ok; ++i) {
+            const uint64_t n = c.get<uint64_t>();
+            if (!c.ok || n > (uint64_t)(c.end - c.p)) { c.ok = false; break; }
+            c.p += n;
+        }
+    } else {
+        if (v.array_type < 0 || v.array_type > GT_F64) return false;
+        const uint64_t nb = v.array_len * fixed[v.array_type];
+        if (nb > (uint64_t)(c.end - c.p)) return false;
+        c.p += nb;
+    }
+    return c.ok;
+}
+
+int32_t fail(gl3_gguf* g, int32_t code, const std::string& m) { g->err = m; return code; }
+
+bool meta_num(const gl3_gguf* g, const std::string& key, double* out) {
+    auto it = g->meta.find(key);
+    if (it == g->meta.end() || it->second.type == GT_STRING || it->second.type == GT_ARRAY) return false;
+    *out = it->second.num;
+    return true;
+}
+
+thread_local std::string g_open_err;
+
+}  // namespace
+
+extern "C" {
+
+const char* gl3_gguf_last_error(const gl3_gguf* g) { return g ? g->err.c_str() : g_open_err.c_str(); }
+
+void gl3_gguf_close(gl3_gguf* g) {
+    if (!g) return;
+    if (g->base) munmap((void*)g->base, g->size);
+    if (g->fd >= 0) close(g->fd);
+    delete g;
+}
+
+int32_t gl3_gguf_open(const char* path, gl3_gguf** out) {
+    if (!path || !out) return GL3_E_ARG;
+    *out = nullptr;
+    gl3_gguf* g = new gl3_gguf();
+    auto bail = [&](int32_t code, const std::string& m) { g_open_err = m; gl3_gguf_close(g); return code; };
+    g->fd = open(path, O_RDONLY);
+    if (g->fd < 0) return bail(GL3_E_ARG, std::string("cannot open ") + path);
+    struct stat st;
+    if (fstat(g->fd, &st) != 0 || st.st_size < 24) return bail(GL3_E_ARG, "not a GGUF file (too short)");
+    g->size = (size_t)st.st_size;
+    void* m = mmap(nullptr, g->size, PROT_READ, MAP_PRIVATE, g->fd, 0);
+    if (m == MAP_FAILED) return bail(GL3_E_OOM, "mmap failed");
+    g->base = (const uint8_t*)m;
+    Cursor c{g->base, g->base + g->size};
+    if (c.get<uint32_t>() != 0x46554747u) return bail(GL3_E_ARG, "bad magic: not a GGUF file");    // "GGUF" (GGUF.java:43)
+    g->version = c.get<uint32_t>();
+    if (g->version != 2 && g->version != 3) return bail(GL3_E_UNSUPPORTED, "unsupported GGUF version " + std::to_string(g->version));
+    const uint64_t n_tensors = c.get<uint64_t>(), n_kv = c.get<uint64_t>();
+    if (!c.ok || n_tensors > (1u << 20) || n_kv > (1u << 20)) return bail(GL3_E_ARG, "corrupt GGUF header");
+    for (uint64_t i = 0; i < n_kv; ++i) {
+        std::string key = c.str();
+        const int ty = (int)c.get<uint32_t>();
+        MetaValue v;
+        if (!c.ok || !read_value(c, ty, v)) return bail(GL3_E_ARG, "corrupt GGUF metadata near key '" + key + "'");
+        g->meta[key] = v;
+    }
+    double al;
+    if (meta_num(g, "general.alignment", &al) && al >= 1) g->alignment = (uint64_t)al;
+    g->tensors.resize((size_t)n_tensors);
+    for (auto& t : g->tensors) {
+        t.name = c.str();
+        t.n_dims = (int)c.get<uint32_t>();
+        if (!c.ok || t.n_dims < 1 || t.n_dims > 4) return bail(GL3_E_ARG, "corrupt GGUF tensor info");
+        uint64_t n = 1;
+        for (int d = 0; d < t.n_dims; ++d) { t.ne[d] = c.get<uint64_t>(); n *= t.ne[d]; }
+        t.type = (int)c.get<uint32_t>();
+        t.offset = c.get<uint64_t>();
+        if (!c.ok) return bail(GL3_E_ARG, "corrupt GGUF tensor info");
+        t.bytes = type_bytes(t.type, n);
+    }
+    const uint64_t pos = (uint64_t)(c.p - g->base);
+    g->data_off = (pos + g->alignment - 1) / g->alignment * g->alignment;        // GGUF.java:105-137
+    for (size_t i = 0; i < g->tensors.size(); ++i) {
+        const TensorInfo& t = g->tensors[i];
+        if (t.bytes && (g->data_off + t.offset + t.bytes > g->size || t.offset % g->alignment))
+            return bail(GL3_E_ARG, "tensor '" + t.name + "' lies outside the file or is misaligned");
+        g->by_name[t.name] = (int)i;
+    }
+    *out = g;
+    return GL3_OK;
+}
+
+int32_t gl3_gguf_tensor_count(const gl3_gguf* g) { return g ? (int32_t)g->tensors.size() : 0; }
+
+int32_t gl3_gguf_tensor_info(const gl3_gguf* g, int32_t i, const char** name, int32_t* type, uint64_t* ne /*[4]*/, const void** data,
+                             uint64_t* bytes) {
+    if (!g || i < 0 || i >= (int32_t)g->tensors.size()) return GL3_E_ARG;
+    const TensorInfo& t = g->tensors[i];
+    if (name) *name = t.name.c_str();
+    if (type) *type = t.type;
+    if (ne) for (int d = 0; d < 4; ++d) ne[d] = t.ne[d];
+    if (data) *data = g->base + g->data_off + t.offset;
+    if (bytes) *bytes = t.bytes;
+    return GL3_OK;
+}
+
+int32_t gl3_gguf_meta_number(const gl3_gguf* g, const char* key, double* out) {
+    if (!g || !key || !out) return GL3_E_ARG;
+    return meta_num(g, key, out) ? GL3_OK : GL3_E_ARG;
+}
+
+int32_t gl3_gguf_meta_string(const gl3_gguf* g, const char* key, const char** out) {
+    if (!g || !key || !out) return GL3_E_ARG;
+    auto it = g->meta.find(key);
+    if (it == g->meta.end() || it->second.type != GT_STRING) return GL3_E_ARG;
+    *out = it->second.str.c_str();
+    return GL3_OK;
+}
+
+// Fills the shape fields of desc from the metadata (LlamaModelLoader.java:47-63, Qwen3ModelLoader.java:48-74);
+// max_batch / device / tp_* / flags / n_seqs are left as the caller set them.  rope_theta is returned separately.
+int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
+    if (!g || !d) return GL3_E_ARG;
+    auto it = g->meta.find("general.architecture");
+    if (it == g->meta.end()) return fail(g, GL3_E_ARG, "general.architecture missing");
+    const std::string a = it->second.str;
+    if (a == "llama") d->arch = GL3_ARCH_LLAMA;
+    else if (a == "qwen3") d->arch = GL3_ARCH_QWEN3;
+    else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, qwen3)");
+    auto need = [&](const char* k, double* v) { return meta_num(g, a + "." + k, v); };
+    double dim, hid, nl, nh, nkv, eps, theta = 10000.0, ctx, kl;
+    if (!need("embedding_length", &dim) || !need("feed_forward_length", &hid) || !need("block_count", &nl) ||
+        !need("attention.head_count", &nh) || !need("attention.layer_norm_rms_epsilon", &eps) || !need("context_length", &ctx))
+        return fail(g, GL3_E_ARG, "model shape keys missing from the metadata");
+    if (!need("attention.head_count_kv", &nkv)) nkv = nh;
+    need("rope.freq_base", &theta);
+    auto te = g->by_name.find("token_embd.weight");
+    if (te == g->by_name.end()) return fail(g, GL3_E_ARG, "token_embd.weight missing");
+    const TensorInfo& emb = g->tensors[te->second];
+    d->struct_size = sizeof(gl3_model_desc);
+    d->dim = (int32_t)dim; d->hidden = (int32_t)hid; d->n_layers = (int32_t)nl; d->n_heads = (int32_t)nh; d->n_kv_heads = (int32_t)nkv;
+    d->head_size = need("attention.key_length", &kl) ? (int32_t)kl : d->dim / d->n_heads;
+    d->vocab = (int32_t)emb.ne[1];
+    if (d->ctx <= 0 || d->ctx > (int32_t)ctx) d->ctx = (int32_t)ctx;      // caller may ask for a shorter KV cache
+    d->rms_eps = (float)eps;
+    d->weight_type = emb.type;
+    if (rope_theta) *rope_theta = (float)theta;
+    return GL3_OK;
+}
+
+// RoPE.precomputeFreqsCis (J/inference/operation/RoPE.java:6-37, ropeScaling = false): freq = (float)(1 / pow(theta, i / hs))
+// in double, val = pos * freq in f32, cos / sin evaluated in double and cast.  cr / ci: f32[ctx * hs/2].
+void gl3_rope_table(int32_t ctx, int32_t head_size, float theta, float* cr, float* ci) {
+    const int half = head_size / 2;
+    for (int pos = 0; pos < ctx; ++pos)
+        for (int i = 0; i < half; ++i) {
+            const float freq = (float)(1.0 / pow((double)theta, (double)(2 * i) / (double)head_size));
+            const float val = (float)pos * freq;
+            cr[(size_t)pos * half + i] = (float)cos((double)val);
+            ci[(size_t)pos * half + i] = (float)sin((double)val);
+        }
+}
+
+// Opens the file, builds the plan and uploads every tensor straight from the mapping (tensor names as
+// LlamaModelLoader.java:83-98).  opts (nullable) supplies ctx / max_batch / device / tp_* / flags / n_seqs; shape fields
+// are overwritten from the metadata.  Tensor-parallel plans are returned un-finalized when tp_size > 1 (the caller must
+// gl3_tp_init / gl3_tp_attach_local first); otherwise the plan is finalized.
+int32_t gl3_load_gguf(const char* path, const gl3_model_desc* opts, gl3_ctx** out) {
+    if (!out) return GL3_E_ARG;
+    *out = nullptr;
+    gl3_gguf* g = nullptr;
+    int32_t r = gl3_gguf_open(path, &g);
+    if (r != GL3_OK) return r;
+    gl3_model_desc d{};
+    if (opts) d = *opts;
+    float theta = 10000.f;
+    if ((r = gl3_gguf_model_desc(g, &d, &theta)) != GL3_OK) { g_open_err = g->err; gl3_gguf_close(g); return r; }
+    gl3_ctx* ctx = nullptr;
+    if ((r = gl3_create(&d, &ctx)) != GL3_OK) { g_open_err = gl3_last_error(nullptr); gl3_gguf_close(g); return r; }
+    auto up = [&](const std::string& name, int id, int layer, bool required) -> int32_t {
+        auto it = g->by_name.find(name);
+        if (it == g->by_name.end()) return required ? GL3_E_STATE : GL3_OK;
+        const TensorInfo& t = g->tensors[it->second];
+        return gl3_upload_tensor(ctx, id, layer, g->base + g->data_off + t.offset, t.bytes, t.type);
+    };
+    r = up("token_embd.weight", GL3_T_TOKEN_EMBD, 0, true);
+    if (r == GL3_OK) r = up("output_norm.weight", GL3_T_OUTPUT_NORM, 0, true);
+    if (r == GL3_OK) r = up("output.weight", GL3_T_OUTPUT, 0, false);                       // absent: tied embeddings
+    static const struct { const char* name; int id; bool qwen_only; } per_layer[] = {
+        {"attn_norm.weight", GL3_T_ATTN_NORM, false}, {"attn_q.weight", GL3_T_WQ, false}, {"attn_k.weight", GL3_T_WK, false},
+        {"attn_v.weight", GL3_T_WV, false}, {"attn_output.weight", GL3_T_WO, false}, {"ffn_norm.weight", GL3_T_FFN_NORM, false},
+        {"ffn_gate.weight", GL3_T_W1, false}, {"ffn_down.weight", GL3_T_W2, false}, {"ffn_up.weight", GL3_T_W3, false},
+        {"attn_q_norm.weight", GL3_T_ATTN_Q_NORM, true}, {"attn_k_norm.weight", GL3_T_ATTN_K_NORM, true}};
+    for (int l = 0; l < d.n_layers && r == GL3_OK; ++l)
+        for (const auto& t : per_layer) {
+            if (t.qwen_only && d.arch != GL3_ARCH_QWEN3) continue;
+            r = up("blk." + std::to_string(l) + "." + t.name, t.id, l, true);
+            if (r != GL3_OK) break;
+        }
+    if (r == GL3_OK) {
+        const size_t n = (size_t)d.ctx * (d.head_size / 2);
+        std::vector<float> cr(n), ci(n);
+        gl3_rope_table(d.ctx, d.head_size, theta, cr.data(), ci.data());
+        r = gl3_upload_rope(ctx, cr.data(), ci.data(), n);
+    }
+    if (r == GL3_OK && d.tp_size <= 1 && !(d.flags & GL3_FLAG_FORCE_RCCL)) r = gl3_finalize(ctx);
+    if (r != GL3_OK) {
+        g_open_err = r == GL3_E_STATE ? std::string("a required tensor is missing from the GGUF file") : std::string(gl3_last_error(ctx));
+        gl3_destroy(ctx);
+        gl3_gguf_close(g);
+        return r;
+    }
+    gl3_gguf_close(g);        // weights are resident in HBM; the mapping is no longer needed
+    *out = ctx;
+    return GL3_OK;
+}
+
+}  // extern "C"

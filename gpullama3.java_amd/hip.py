@@ -63,6 +63,17 @@ _SIGS = {  # symbol -> (restype, argtypes): exactly the declarations of include/
     "gl3_get_init_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gl3_destroy": (None, [C.c_void_p]),
     "gl3_last_error": (C.c_char_p, [C.c_void_p]),
+    "gl3_gguf_open": (C.c_int32, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "gl3_gguf_close": (None, [C.c_void_p]),
+    "gl3_gguf_last_error": (C.c_char_p, [C.c_void_p]),
+    "gl3_gguf_tensor_count": (C.c_int32, [C.c_void_p]),
+    "gl3_gguf_tensor_info": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "gl3_gguf_meta_number": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
+    "gl3_gguf_meta_string": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p)]),
+    "gl3_gguf_model_desc": (C.c_int32, [C.c_void_p, C.POINTER(ModelDesc), C.POINTER(C.c_float)]),
+    "gl3_rope_table": (None, [C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "gl3_load_gguf": (C.c_int32, [C.c_char_p, C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
 }
 
 _lib = None
@@ -92,6 +103,12 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
+
+
+def check_gguf(code: int, g=None):
+    if code != 0:
+        msg = lib().gl3_gguf_last_error(g)
+        raise Gl3Error(code, msg.decode() if msg else "")
 
 
 def check_exports():

@@ -17,6 +17,7 @@ where the reference throws UnsupportedOperationException (ForwardPlanFactory.jav
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -65,6 +66,42 @@ class HipMasterPlan:
             raise
         self._logits = np.empty(c.vocab, np.float32)
         self._arg = C.c_int32()
+
+    @classmethod
+    def from_gguf(cls, path: str, prefill_batch_size: int = 1, ctx: int = 0, device: int = 0, flags: int = 0, n_seqs: int = 1):
+        """Native loader (gl3_load_gguf): the library mmaps the GGUF file, reads the config keys the reference loaders read
+        (LlamaModelLoader.java:47-69, Qwen3ModelLoader.java:48-79), uploads every tensor and builds the RoPE table itself."""
+        from . import synth
+        L = hip.lib()
+        self = cls.__new__(cls)
+        g = C.c_void_p()
+        hip.check_gguf(L.gl3_gguf_open(path.encode(), C.byref(g)))
+        try:
+            d = hip.ModelDesc()
+            d.ctx = ctx
+            theta = C.c_float()
+            hip.check_gguf(L.gl3_gguf_model_desc(g, C.byref(d), C.byref(theta)), g)
+            name = C.c_char_p()
+            nm = name.value.decode() if L.gl3_gguf_meta_string(g, b"general.name", C.byref(name)) == 0 else os.path.basename(path)
+            tied = True
+            for i in range(L.gl3_gguf_tensor_count(g)):
+                tn = C.c_char_p()
+                L.gl3_gguf_tensor_info(g, i, C.byref(tn), None, None, None, None)
+                if tn.value == b"output.weight":
+                    tied = False
+        finally:
+            L.gl3_gguf_close(g)
+        self.cfg = synth.ModelConfig(nm, d.arch, d.dim, d.hidden, d.n_layers, d.n_heads, d.n_kv_heads, d.head_size, d.vocab, d.ctx,
+                                     d.rms_eps, float(theta.value), tied)
+        opts = hip.ModelDesc()
+        opts.struct_size = C.sizeof(hip.ModelDesc)
+        opts.ctx, opts.max_batch, opts.device, opts.tp_size, opts.flags, opts.n_seqs = ctx, prefill_batch_size, device, 1, flags, n_seqs
+        self._ctx = C.c_void_p()
+        hip.check_gguf(L.gl3_load_gguf(path.encode(), C.byref(opts), C.byref(self._ctx)))
+        self.tp_size, self.tp_rank, self.max_batch = 1, 0, prefill_batch_size
+        self._logits = np.empty(self.cfg.vocab, np.float32)
+        self._arg = C.c_int32()
+        return self
 
     # ---- reference-named interface -------------------------------------------------------------
     @classmethod

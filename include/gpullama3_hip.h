@@ -202,6 +202,30 @@ GL3_API int32_t gl3_get_init_ms(gl3_ctx* ctx, double* plan_ms, double* copy_in_m
 GL3_API void gl3_destroy(gl3_ctx* ctx);
 GL3_API const char* gl3_last_error(gl3_ctx* ctx);  /* ctx may be NULL: last create error */
 
+/* ---- native GGUF loader.  Replaces, for this path, J/tensor/GGUF.java:43-137,217-311 (header,
+ * metadata, tensor infos, alignment), the config extraction of LlamaModelLoader.java:47-69 / Qwen3ModelLoader.java:48-79, the
+ * tensor-name map :83-98 and RoPE.precomputeFreqsCis (J/inference/operation/RoPE.java:6-37).  The file is mmap'd; tensor
+ * bytes go from the mapping straight to gl3_upload_tensor (no 2 GiB limit, no TornadoVM 16-byte header remapping). */
+typedef struct gl3_gguf gl3_gguf;
+GL3_API int32_t gl3_gguf_open(const char* path, gl3_gguf** out);            /* GGUF v2 / v3 */
+GL3_API void gl3_gguf_close(gl3_gguf* g);
+GL3_API const char* gl3_gguf_last_error(const gl3_gguf* g);                 /* g may be NULL: last open / load error */
+GL3_API int32_t gl3_gguf_tensor_count(const gl3_gguf* g);
+/* ne[4]: GGUF dimension order (ne[0] = row length); data points into the mapping (valid until gl3_gguf_close). */
+GL3_API int32_t gl3_gguf_tensor_info(const gl3_gguf* g, int32_t i, const char** name, int32_t* type, uint64_t* ne, const void** data,
+                                     uint64_t* bytes);
+GL3_API int32_t gl3_gguf_meta_number(const gl3_gguf* g, const char* key, double* out);   /* any scalar numeric / bool key */
+GL3_API int32_t gl3_gguf_meta_string(const gl3_gguf* g, const char* key, const char** out);
+/* Shape fields of desc (arch, dim, hidden, layers, heads, head_size, vocab, rms_eps, weight_type) from the metadata; desc->ctx is
+ * kept if it is > 0 and not larger than <arch>.context_length; the other fields are left as the caller set them. */
+GL3_API int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* desc, float* rope_theta);
+/* RoPE.precomputeFreqsCis with ropeScaling = false: cr / ci are f32[ctx * head_size/2]. */
+GL3_API void gl3_rope_table(int32_t ctx, int32_t head_size, float theta, float* cr, float* ci);
+/* open + gl3_create + one gl3_upload_tensor per tensor + RoPE table + gl3_finalize (not finalized when opts->tp_size > 1 or
+ * GL3_FLAG_FORCE_RCCL is set: call gl3_tp_init / gl3_tp_attach_local and gl3_finalize).  opts may be NULL; it supplies
+ * ctx / max_batch / device / tp_rank / tp_size / flags / n_seqs. */
+GL3_API int32_t gl3_load_gguf(const char* path, const gl3_model_desc* opts, gl3_ctx** out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -238,3 +238,24 @@ def test_static_batched_decode_matches_independent_cpu_runs(pkg, orc, planmod, c
     with pytest.raises(hip.Gl3Error):
         plan.forward_decode_batch([1, 2], [0, 0], [pos[0], pos[0]])       # duplicate sequence id
     plan.freeTornadoExecutionPlan()
+
+
+@pytest.mark.parametrize("cfg,wtype", [("tiny-llama", 8), ("tiny-qwen3", 8), ("tiny-llama-tied", 1)])
+def test_native_gguf_loader_builds_the_same_plan(pkg, planmod, tmp_path, cfg, wtype):
+    """gl3_load_gguf (mmap + native config / tensor-name map / RoPE table) vs the per-tensor upload path driven from Python."""
+    plan_mod, hip = planmod
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=13)
+    path = str(tmp_path / "m.gguf")
+    m.write_gguf(path)
+    a = plan_mod.HipMasterPlan(m)
+    b = plan_mod.HipMasterPlan.from_gguf(path, prefill_batch_size=8)
+    assert (b.cfg.dim, b.cfg.n_layers, b.cfg.vocab, b.cfg.head_size) == (m.cfg.dim, m.cfg.n_layers, m.cfg.vocab, m.cfg.head_size)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 10)
+    b.prefill(toks[:5], 0)
+    for pos, t in enumerate(toks):
+        la = a.forward_decode(t, pos)
+        if pos >= 5:
+            assert np.array_equal(b.forward_decode(t, pos), la), pos
+    a.freeTornadoExecutionPlan(); b.freeTornadoExecutionPlan()
+    with pytest.raises(hip.Gl3Error):
+        plan_mod.HipMasterPlan.from_gguf(str(tmp_path / "missing.gguf"))
