@@ -110,6 +110,7 @@ struct GemmArgs {
     const uint8_t* w; const uint8_t* w2;  // Q8T matrices (w2: up projection for the SwiGLU epilogue)
     int rows, ng, nb;                     // valid rows, tile groups per strip, real blocks per row (k/32)
     const uint8_t* XQ; const float* XS; int maxk;
+    int ntt, nrt;                         // token tiles, row tiles (grid = 8 * ceil(ntt * nrt / 8), see the XCD mapping)
     int ntok;
     float* out; int out_stride;           // EPI_STORE / EPI_SWIGLU: out[b*stride + row]; EPI_RESID: out +=
 };
@@ -148,8 +149,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
     const int tl = lane & 31, hi = lane >> 5;
     const int wr = NW == 4 ? wave >> 1 : wave >> 2;    // wavefront grid: row half wr,
     const int wc = NW == 4 ? wave & 1 : wave & 3;      // tokens wc * 32 * TF ..
-    const int row0 = blockIdx.y * RPM;                 // first output row (per matrix)
-    const int tok0 = blockIdx.x * GM_TOK;
+    // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so the token tiles that
+    // share a weight row tile are given consecutive slots of ONE XCD — the weights cross the fabric once, not once per
+    // token tile (rocprofv3 FETCH_SIZE of the gate/up GEMM at 512 tokens: 517 MB -> see profiles/).
+    const int ntt_g = a.ntt, per_xcd = (a.ntt * a.nrt + 7) >> 3;
+    const int lin = blockIdx.x, J = (lin & 7) * per_xcd + (lin >> 3);
+    if (J >= ntt_g * a.nrt) return;
+    const int row0 = (J / ntt_g) * RPM;                // first output row (per matrix)
+    const int tok0 = (J % ntt_g) * GM_TOK;
     const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
     const int nkb = a.ng;                              // K stages = tile groups per strip
     const int nstrips = (a.rows + 15) >> 4;
@@ -752,14 +759,20 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     // 128-row tiles only when they still give >= 2 workgroups per CU; otherwise 64-row tiles, and 8 wavefronts per
     // workgroup when even those leave a single workgroup per CU
     const int ntt = (ntok + GM_TOK - 1) / GM_TOK;
+    a.ntt = ntt;
+    auto grid = [&](int nrt) { a.nrt = nrt; return dim3(8 * ((ntt * nrt + 7) / 8)); };
     if constexpr (EPI == EPI_SWIGLU) {
-        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 4>), dim3(ntt, (w.rows + 63) / 64), dim3(256), 2 * gm_stage_bytes(128), ctx->stream, a);
+        const dim3 g = grid((w.rows + 63) / 64);
+        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 4>), g, dim3(256), 2 * gm_stage_bytes(128), ctx->stream, a);
     } else if ((size_t)ntt * ((w.rows + 127) / 128) >= 512) {
-        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 2, 4>), dim3(ntt, (w.rows + 127) / 128), dim3(256), 2 * gm_stage_bytes(128), ctx->stream, a);
+        const dim3 g = grid((w.rows + 127) / 128);
+        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 2, 4>), g, dim3(256), 2 * gm_stage_bytes(128), ctx->stream, a);
     } else if ((size_t)ntt * ((w.rows + 63) / 64) > 256) {
-        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 4>), dim3(ntt, (w.rows + 63) / 64), dim3(256), 2 * gm_stage_bytes(64), ctx->stream, a);
+        const dim3 g = grid((w.rows + 63) / 64);
+        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 4>), g, dim3(256), 2 * gm_stage_bytes(64), ctx->stream, a);
     } else {
-        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 8>), dim3(ntt, (w.rows + 63) / 64), dim3(512), 2 * gm_stage_bytes(64), ctx->stream, a);
+        const dim3 g = grid((w.rows + 63) / 64);
+        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 8>), g, dim3(512), 2 * gm_stage_bytes(64), ctx->stream, a);
     }
 }
 

@@ -12,20 +12,21 @@ src, tag = sys.argv[1], sys.argv[2]
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(out, exist_ok=True)
 
-rows = list(csv.DictReader(open(os.path.join(src, "trace", [f for f in os.listdir(os.path.join(src, "trace")) if f.endswith("kernel_stats.csv")][0]))))
+import glob
+rows = list(csv.DictReader(open(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0])))
 with open(os.path.join(out, tag + "_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
     for r in rows:
-        if "gl3" in r["Name"]:
+        if "gl3" in r["Name"] or "pf_" in r["Name"]:
             w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 
 pmc_dir = os.path.join(src, "pmc_fetch")
 if os.path.isdir(pmc_dir):
-    f = [x for x in os.listdir(pmc_dir) if x.endswith("counter_collection.csv")][0]
+    f = glob.glob(os.path.join(pmc_dir, "**", "*counter_collection.csv"), recursive=True)[0]
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(os.path.join(pmc_dir, f))):
-        if "gl3" in r["Kernel_Name"]:
+    for r in csv.DictReader(open(f)):
+        if "gl3" in r["Kernel_Name"] or "pf_" in r["Kernel_Name"]:
             acc[(r["Kernel_Name"], r["Counter_Name"], r["Grid_Size"], r["LDS_Block_Size"], r["VGPR_Count"])].append(float(r["Counter_Value"]))
     with open(os.path.join(out, tag + "_pmc_fetch_summary.csv"), "w", newline="") as fo:
         w = csv.writer(fo)
