@@ -249,6 +249,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
     v16i_t cbias;
 #pragma unroll
     for (int r = 0; r < 16; ++r) cbias[r] = 0x4B400000;
+    if constexpr (NM * RF == 1) asm volatile("" : "+v"(cbias));   // keep the splat in VGPRs (else 8 v_mov_b64 per MFMA pair)
     gload(0);
     lstore(0, 0);
     __syncthreads();
@@ -313,12 +314,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
             // one wavefront per SIMD in the narrow-matrix launches: fetch block b+1's fragments while block b computes
             Frag fa, fb;
             fload(fa, 0, true);
+            if constexpr (TF == 1) {          // small fragments: static registers for the whole stage, no loop-carried copies
+#pragma unroll
+                for (int blk = 0; blk < GM_KB; blk += 2) {
+                    fload(fb, blk + 1, true);
+                    fcompute(fa, 0, false);
+                    if (blk + 2 < GM_KB) fload(fa, blk + 2, true);
+                    fcompute(fb, 0, false);
+                }
+            } else {
 #pragma unroll 1
-            for (int blk = 0; blk < GM_KB; blk += 2) {
-                fload(fb, blk + 1, true);
-                fcompute(fa, 0, false);
-                if (blk + 2 < GM_KB) fload(fa, blk + 2, true);
-                fcompute(fb, 0, false);
+                for (int blk = 0; blk < GM_KB; blk += 2) {
+                    fload(fb, blk + 1, true);
+                    fcompute(fa, 0, false);
+                    if (blk + 2 < GM_KB) fload(fa, blk + 2, true);
+                    fcompute(fb, 0, false);
+                }
             }
         } else {
 #pragma unroll 1
