@@ -127,28 +127,33 @@ struct GemmArgs {
 constexpr int GM_TOK = 128, GM_KB = 4;
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
-__host__ __device__ constexpr int gm_stage_bytes(int arows) {
-    return GM_KB * 2 * arows * 16 + GM_KB * arows * 4 + GM_KB * 2 * GM_TOK * 16 + GM_KB * GM_TOK * 4;
+__host__ __device__ constexpr int gm_stage_bytes(int arows, int toks = 128) {
+    return GM_KB * 2 * arows * 16 + GM_KB * arows * 4 + GM_KB * 2 * toks * 16 + GM_KB * toks * 4;
 }
 
 // NW = wavefronts per workgroup: 4 (2 x 2, two token fragments each) or 8 (2 x 4, one token fragment each; used for the
 // 4096-row matrices where only one workgroup fits a CU, so that every SIMD still interleaves two wavefronts).
-template <int EPI, int RF, int NW>
+// TOK = tokens per workgroup: 128, or 32 for static-batched decode (few tokens: four wavefronts side by side along the
+// rows, one token fragment each, so that a batch of 32 does not pay for 128 padded columns).
+template <int EPI, int RF, int NW, int TOK = GM_TOK>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
     static_assert(NM * RF <= 2, "accumulator budget");
     static_assert(NW == 4 || (NW == 8 && NM * RF == 1), "8-wavefront layout is for the single-fragment variant");
-    constexpr int NT = 64 * NW, TF = 8 / NW;          // threads; 32-token fragments per wavefront
-    constexpr int AROWS = NM * RF * 64;                // weight rows staged per K stage (both matrices together)
+    static_assert(TOK == GM_TOK || (TOK == 32 && NW == 4 && RF == 1), "32-token tiles: 4 wavefronts x one fragment");
+    constexpr int NT = 64 * NW;                        // threads
+    constexpr int TF = TOK == 32 ? 1 : 8 / NW;         // 32-token fragments per wavefront
+    constexpr int WR = TOK == 32 ? 4 : 2;              // wavefronts along the rows
+    constexpr int AROWS = NM * RF * 32 * WR;           // weight rows staged per K stage (both matrices together)
     constexpr int RPM = AROWS / NM;                    // output rows per matrix covered by this workgroup
-    constexpr int STAGE = gm_stage_bytes(AROWS);
+    constexpr int STAGE = gm_stage_bytes(AROWS, TOK);
     constexpr int NAP = (AROWS * 4 + NT - 1) / NT;     // (strip, lane) pairs per thread
-    constexpr int NBP = 1024 / NT;                     // 16-byte activation pieces per thread
+    constexpr int NBP = (TOK * 8 + NT - 1) / NT;       // 16-byte activation pieces per thread
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tl = lane & 31, hi = lane >> 5;
-    const int wr = NW == 4 ? wave >> 1 : wave >> 2;    // wavefront grid: row half wr,
-    const int wc = NW == 4 ? wave & 1 : wave & 3;      // tokens wc * 32 * TF ..
+    const int wr = TOK == 32 ? wave : NW == 4 ? wave >> 1 : wave >> 2;    // wavefront grid: row part wr,
+    const int wc = TOK == 32 ? 0 : NW == 4 ? wave & 1 : wave & 3;         // tokens wc * 32 * TF ..
     // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so the token tiles that
     // share a weight row tile are given consecutive slots of ONE XCD — the weights cross the fabric once, not once per
     // token tile (rocprofv3 FETCH_SIZE of the gate/up GEMM at 512 tokens: 517 MB -> see profiles/).
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
     const int lin = blockIdx.x, J = (lin & 7) * per_xcd + (lin >> 3);
     if (J >= ntt_g * a.nrt) return;
     const int row0 = (J / ntt_g) * RPM;                // first output row (per matrix)
-    const int tok0 = (J % ntt_g) * GM_TOK;
+    const int tok0 = (J % ntt_g) * TOK;
     const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
     const int nkb = a.ng;                              // K stages = tile groups per strip
     const int nstrips = (a.rows + 15) >> 4;
@@ -167,8 +172,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
     v4i_t ra_lo[NAP], ra_hi[NAP], ra_sc, rb[NBP];
     float4 rb_s;
     auto tile_of = [&](int sl, int kb) -> const uint8_t* {   // sl: local strip 0..AROWS/16-1
-        const int m = NM == 2 ? (sl >> 2) : 0;
-        const int strip = min(nstrips - 1, (row0 >> 4) + (NM == 2 ? (sl & 3) : sl));
+        constexpr int SPM = RPM / 16;                      // strips per matrix in this workgroup
+        const int m = NM == 2 ? (sl / SPM) : 0;
+        const int strip = min(nstrips - 1, (row0 >> 4) + (NM == 2 ? (sl % SPM) : sl));
         return (m == 0 ? a.w : a.w2) + (size_t)strip * strip_bytes + (size_t)kb * TILE_BYTES;
     };
     auto gload = [&](int kb) {
@@ -187,9 +193,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
 #pragma unroll
         for (int i = 0; i < NBP; ++i) {
             const int pc = t + NT * i, tk = min(a.ntok - 1, tok0 + (pc >> 3)), c = pc & 7;
-            rb[i] = *reinterpret_cast<const v4i_t*>(a.XQ + (size_t)tk * a.maxk + (size_t)kb * 128 + 16 * c);
+            if (pc < TOK * 8) rb[i] = *reinterpret_cast<const v4i_t*>(a.XQ + (size_t)tk * a.maxk + (size_t)kb * 128 + 16 * c);
         }
-        if (t < GM_TOK) {
+        if (t < TOK) {
             const int tk = min(a.ntok - 1, tok0 + t);
             rb_s = *reinterpret_cast<const float4*>(a.XS + (size_t)tk * (a.maxk >> 5) + kb * 4);
         }
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
         uint8_t* Aq = base;
         float* As = reinterpret_cast<float*>(base + GM_KB * 2 * AROWS * 16);
         uint8_t* Bq = base + GM_KB * 2 * AROWS * 16 + GM_KB * AROWS * 4;
-        float* Bs = reinterpret_cast<float*>(Bq + GM_KB * 2 * GM_TOK * 16);
+        float* Bs = reinterpret_cast<float*>(Bq + GM_KB * 2 * TOK * 16);
 #pragma unroll
         for (int i = 0; i < NAP; ++i) {
             const int pr = t + NT * i, sl = pr >> 6, lt = pr & 63;
@@ -221,15 +227,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
 #pragma unroll
         for (int i = 0; i < NBP; ++i) {
             const int pc = t + NT * i, tk = pc >> 3, c = pc & 7;
-            *reinterpret_cast<v4i_t*>(Bq + ((size_t)c * GM_TOK + (tk ^ c)) * 16) = rb[i]; // c = blk*2 + half; xor: bank spread
+            if (pc < TOK * 8) *reinterpret_cast<v4i_t*>(Bq + ((size_t)c * TOK + (tk ^ c)) * 16) = rb[i]; // c = blk*2 + half; xor: bank spread
         }
-        if (t < GM_TOK) {
+        if (t < TOK) {
             // ragged K (k % 128 != 0): the padded blocks carry zero weights; zero their activation scale too.  (Done
             // here, not at load time, so that the global loads stay in flight across the compute phase.)
-            Bs[0 * GM_TOK + t] = rb_s.x;
-            Bs[1 * GM_TOK + t] = kbs * 4 + 1 < a.nb ? rb_s.y : 0.f;
-            Bs[2 * GM_TOK + t] = kbs * 4 + 2 < a.nb ? rb_s.z : 0.f;
-            Bs[3 * GM_TOK + t] = kbs * 4 + 3 < a.nb ? rb_s.w : 0.f;
+            Bs[0 * TOK + t] = rb_s.x;
+            Bs[1 * TOK + t] = kbs * 4 + 1 < a.nb ? rb_s.y : 0.f;
+            Bs[2 * TOK + t] = kbs * 4 + 2 < a.nb ? rb_s.z : 0.f;
+            Bs[3 * TOK + t] = kbs * 4 + 3 < a.nb ? rb_s.w : 0.f;
         }
     };
 
@@ -259,11 +265,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
         const uint8_t* Aq = base;
         const float* As = reinterpret_cast<const float*>(base + GM_KB * 2 * AROWS * 16);
         const uint8_t* Bq = base + GM_KB * 2 * AROWS * 16 + GM_KB * AROWS * 4;
-        const float* Bs = reinterpret_cast<const float*>(Bq + GM_KB * 2 * GM_TOK * 16);
+        const float* Bs = reinterpret_cast<const float*>(Bq + GM_KB * 2 * TOK * 16);
         // operand fragments of one Q8_0 block for this wavefront
         struct Frag { v4i_t bf[TF]; v2f_t xsc[TF]; v4i_t af[NF]; v2f_t wsf[NF][8]; };
         auto fload_a = [&](Frag& fr, int blk, int f) {
-            const int lrow = NM == 2 ? f * 64 + wr * 32 : wr * (32 * RF) + f * 32;     // local row of this fragment
+            const int lrow = NM == 2 ? f * RPM + wr * 32 : wr * (32 * RF) + f * 32;    // local row of this fragment
             fr.af[f] = *reinterpret_cast<const v4i_t*>(Aq + ((size_t)(blk * 2 + hi) * AROWS + lrow + tl) * 16);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -276,8 +282,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
 #pragma unroll
             for (int tf = 0; tf < TF; ++tf) {
                 const int tk = wc * (32 * TF) + tf * 32 + tl;
-                fr.bf[tf] = *reinterpret_cast<const v4i_t*>(Bq + ((size_t)(blk * 2 + hi) * GM_TOK + (tk ^ (blk * 2 + hi))) * 16);
-                const float x = Bs[blk * GM_TOK + tk];
+                fr.bf[tf] = *reinterpret_cast<const v4i_t*>(Bq + ((size_t)(blk * 2 + hi) * TOK + (tk ^ (blk * 2 + hi))) * 16);
+                const float x = Bs[blk * TOK + tk];
                 fr.xsc[tf] = v2f_t{x, x};
             }
             if (with_a) {
@@ -746,6 +752,7 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_GEMM_LDS(EPI_STORE, 1, 4); GL3_GEMM_LDS(EPI_STORE, 2, 4); GL3_GEMM_LDS(EPI_STORE, 1, 8);
     GL3_GEMM_LDS(EPI_RESID, 1, 4); GL3_GEMM_LDS(EPI_RESID, 2, 4); GL3_GEMM_LDS(EPI_RESID, 1, 8);
     GL3_GEMM_LDS(EPI_SWIGLU, 1, 4);
+    GL3_GEMM_LDS(EPI_STORE, 1, 4, 32); GL3_GEMM_LDS(EPI_RESID, 1, 4, 32); GL3_GEMM_LDS(EPI_SWIGLU, 1, 4, 32);
 #undef GL3_GEMM_LDS
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -769,6 +776,13 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     a.XQ = p->XQ; a.XS = p->XS; a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride;
     // 128-row tiles only when they still give >= 2 workgroups per CU; otherwise 64-row tiles, and 8 wavefronts per
     // workgroup when even those leave a single workgroup per CU
+    if (ntok <= 64) {      // static-batched decode: 32-token tiles, 128 rows (x2 matrices for SwiGLU) per workgroup
+        const int ntt = (ntok + 31) / 32, nrt = (w.rows + 127) / 128;
+        a.ntt = ntt; a.nrt = nrt;
+        constexpr int AR = EPI == EPI_SWIGLU ? 256 : 128;
+        hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 4, 32>), dim3(8 * ((ntt * nrt + 7) / 8)), dim3(256), 2 * gm_stage_bytes(AR, 32), ctx->stream, a);
+        return;
+    }
     const int ntt = (ntok + GM_TOK - 1) / GM_TOK;
     a.ntt = ntt;
     auto grid = [&](int nrt) { a.nrt = nrt; return dim3(8 * ((ntt * nrt + 7) / 8)); };
