@@ -398,6 +398,142 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Static-batched decode (<= 32 sequences, one token each): out[b][n] for a handful of tokens is a long-K, tiny-MN product.
+// The LDS-tiled GEMM above has only rows/128 workgroups then and runs each 32x32 tile's K loop as one latency chain
+// (LDS -> MFMA -> 40 VALU per block); here the work is split like the single-token matvec:
+//   workgroup = 32 weight rows x 32 tokens x all K; producers (waves 1-8): wave w takes block 8r + w - 1 of round r —
+//       A fragment + 16 row scales straight from the Q8T tiles (kept BD_D rounds ahead in registers so ~100 KB per CU are in
+//       flight), B fragment from XQ (L2), one int8 MFMA, p = float(isum) * (wScale * aScale) into a double-buffered LDS ring;
+//   chain (wave 0, raised priority): result += p in block order (16 independent chains per lane) and the epilogue.
+// One barrier per round of 8 blocks.  Grid = rows / 32.
+constexpr int BD_NP = 8, BD_THREADS = 64 * (BD_NP + 1), BD_D = 4;
+__host__ __device__ constexpr int bd_smem_bytes(int nm) { return 2 * nm * BD_NP * 1024 * 4; }
+
+template <int EPI>
+__global__ __launch_bounds__(BD_THREADS) void bd_gemm_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float P[];           // [2][NM][BD_NP][4][64][4]
+    constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6) - 1;     // -1: chain
+    const int tl = lane & 31, hi = lane >> 5;
+    const int row0 = blockIdx.x * 32;
+    const int nstrips = (a.rows + 15) >> 4;
+    const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
+    const int nrounds = (a.nb + BD_NP - 1) / BD_NP;
+
+    if (wave >= 0) {
+        // ------------------------------------------------------------------ producers
+        const int strip = min(nstrips - 1, (row0 >> 4) + (tl >> 4));        // strip of this lane's A row
+        const int tok = min(a.ntok - 1, tl);
+        const uint8_t* wbase[NM];
+        wbase[0] = a.w;
+        if (NM == 2) wbase[NM - 1] = a.w2;
+        v4i_t af[NM][BD_D];
+        uint2 wsr[NM][BD_D][4];
+        v4i_t bf[2];
+        float xsv[2];
+        auto load_a = [&](int u, int blk) {
+            const int g = blk >> 2, bi = blk & 3;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const uint8_t* tile = wbase[m] + (size_t)strip * strip_bytes + (size_t)g * TILE_BYTES;
+                af[m][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(tile + (hi ? 1152 : 128) + 16 * ((tl & 15) + 16 * bi)));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {        // scales of rows 8q + 4hi .. +3 of the 32-row group (q < 2: first strip)
+                    const int s2 = min(nstrips - 1, (row0 >> 4) + (q >> 1));
+                    const uint8_t* t2 = wbase[m] + (size_t)s2 * strip_bytes + (size_t)g * TILE_BYTES;
+                    wsr[m][u][q] = *reinterpret_cast<const uint2*>(t2 + 2 * (((8 * q + 4 * hi) & 15) + 16 * bi));
+                }
+            }
+        };
+        auto load_b = [&](int u, int blk) {
+            bf[u] = *reinterpret_cast<const v4i_t*>(a.XQ + (size_t)tok * a.maxk + (size_t)blk * 32 + 16 * hi);
+            xsv[u] = a.XS[(size_t)tok * (a.maxk >> 5) + blk];
+        };
+        v16i_t cbias;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cbias[r] = 0x4B400000;
+#pragma unroll
+        for (int u = 0; u < BD_D; ++u)
+            if (u * BD_NP + wave < a.nb) load_a(u, u * BD_NP + wave);
+        if (wave < a.nb) load_b(0, wave);
+        for (int base = 0; base < nrounds; base += BD_D) {
+#pragma unroll
+            for (int u = 0; u < BD_D; ++u) {
+                const int r = base + u;
+                if (r < nrounds) {
+                    const int blk = r * BD_NP + wave;
+                    if (blk < a.nb) {
+                        if (blk + BD_NP < a.nb) load_b((u + 1) & 1, blk + BD_NP);
+                        const v2f_t xs2 = v2f_t{xsv[u & 1], xsv[u & 1]};
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+                            const v16i_t c = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m][u], bf[u & 1], cbias, 0, 0, 0);
+                            float* dst = P + ((size_t)((r & 1) * NM + m) * BD_NP + wave) * 1024 + lane * 4;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const uint2 w2 = wsr[m][u][q];
+                                const v2f_t wa = v2f_t{h2f((uint16_t)(w2.x & 0xFFFF)), h2f((uint16_t)(w2.x >> 16))};
+                                const v2f_t wb = v2f_t{h2f((uint16_t)(w2.y & 0xFFFF)), h2f((uint16_t)(w2.y >> 16))};
+                                const v2f_t ca = v2f_t{__int_as_float(c[4 * q]), __int_as_float(c[4 * q + 1])} - v2f_t{12582912.f, 12582912.f};
+                                const v2f_t cb = v2f_t{__int_as_float(c[4 * q + 2]), __int_as_float(c[4 * q + 3])} - v2f_t{12582912.f, 12582912.f};
+                                const v2f_t pa = ca * (wa * xs2), pb = cb * (wb * xs2);      // isum * (wScale * aScale)
+                                *reinterpret_cast<float4*>(dst + q * 256) = make_float4(pa[0], pa[1], pb[0], pb[1]);
+                            }
+                        }
+                        if (blk + BD_D * BD_NP < a.nb) load_a(u, blk + BD_D * BD_NP);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    // ---------------------------------------------------------------------- chain wavefront
+    __builtin_amdgcn_s_setprio(3);
+    float acc[NM][16];
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    for (int r = 0; r < nrounds; ++r) {
+        __syncthreads();
+        const int nblk = min(BD_NP, a.nb - r * BD_NP);
+        for (int w = 0; w < nblk; ++w) {                     // blocks ascending: result += p
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const float* src = P + ((size_t)((r & 1) * NM + m) * BD_NP + w) * 1024 + lane * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + q * 256);
+                    acc[m][4 * q] = acc[m][4 * q] + v.x; acc[m][4 * q + 1] = acc[m][4 * q + 1] + v.y;
+                    acc[m][4 * q + 2] = acc[m][4 * q + 2] + v.z; acc[m][4 * q + 3] = acc[m][4 * q + 3] + v.w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // epilogue.  C layout: token = lane & 31, weight row = (r & 3) + 8 * (r >> 2) + 4 * hi
+    const int b = tl;
+    if (b >= a.ntok) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rbase = row0 + 8 * q + 4 * hi;
+        float* o = a.out + (size_t)b * a.out_stride + rbase;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (rbase + i >= a.rows) continue;
+            if (EPI == EPI_SWIGLU) {
+                float g = acc[0][4 * q + i];
+                g = g / (float)(1.0 + exp(-(double)g));
+                o[i] = g * acc[NM - 1][4 * q + i];
+            } else if (EPI == EPI_STORE) o[i] = acc[0][4 * q + i];
+            else o[i] = o[i] + acc[0][4 * q + i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // RoPE on q and k of every token + KV-cache write (batchForwardJavaPrefill :106-121; Qwen3 adds the per-head
 // RMSNorm, InferenceCore.java:594-600).  Grid = (n_heads + n_kv_heads, ntok), block = 64.
 struct RopeArgs {
@@ -752,6 +888,9 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_GEMM_LDS(EPI_STORE, 1, 4); GL3_GEMM_LDS(EPI_STORE, 2, 4); GL3_GEMM_LDS(EPI_STORE, 1, 8);
     GL3_GEMM_LDS(EPI_RESID, 1, 4); GL3_GEMM_LDS(EPI_RESID, 2, 4); GL3_GEMM_LDS(EPI_RESID, 1, 8);
     GL3_GEMM_LDS(EPI_SWIGLU, 1, 4);
+    GL3_HIP(hipFuncSetAttribute((const void*)bd_gemm_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, bd_smem_bytes(1)));
+    GL3_HIP(hipFuncSetAttribute((const void*)bd_gemm_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, bd_smem_bytes(1)));
+    GL3_HIP(hipFuncSetAttribute((const void*)bd_gemm_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, bd_smem_bytes(2)));
     GL3_GEMM_LDS(EPI_STORE, 1, 4, 32); GL3_GEMM_LDS(EPI_RESID, 1, 4, 32); GL3_GEMM_LDS(EPI_SWIGLU, 1, 4, 32);
 #undef GL3_GEMM_LDS
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -776,7 +915,12 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     a.XQ = p->XQ; a.XS = p->XS; a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride;
     // 128-row tiles only when they still give >= 2 workgroups per CU; otherwise 64-row tiles, and 8 wavefronts per
     // workgroup when even those leave a single workgroup per CU
-    if (ntok <= 64) {      // static-batched decode: 32-token tiles, 128 rows (x2 matrices for SwiGLU) per workgroup
+    static const bool bd_off = getenv("GL3_NO_BD_GEMM") && atoi(getenv("GL3_NO_BD_GEMM"));
+    if (ntok <= 32 && !bd_off) {      // static-batched decode: producer / chain split over all K (bd_gemm_kernel)
+        hipLaunchKernelGGL((bd_gemm_kernel<EPI>), dim3((w.rows + 31) / 32), dim3(BD_THREADS), bd_smem_bytes(EPI == EPI_SWIGLU ? 2 : 1), ctx->stream, a);
+        return;
+    }
+    if (ntok <= 64) {      // 32-token tiles, 128 rows (x2 matrices for SwiGLU) per workgroup
         const int ntt = (ntok + 31) / 32, nrt = (w.rows + 127) / 128;
         a.ntt = ntt; a.nrt = nrt;
         constexpr int AR = EPI == EPI_SWIGLU ? 256 : 128;
