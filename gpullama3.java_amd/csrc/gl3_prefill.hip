@@ -406,14 +406,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
 //       flight), B fragment from XQ (L2), one int8 MFMA, p = float(isum) * (wScale * aScale) into a double-buffered LDS ring;
 //   chain (wave 0, raised priority): result += p in block order (16 independent chains per lane) and the epilogue.
 // One barrier per round of 8 blocks.  Grid = rows / 32.
-constexpr int BD_NP = 8, BD_THREADS = 64 * (BD_NP + 1), BD_D = 4;
-__host__ __device__ constexpr int bd_smem_bytes(int nm) { return 2 * nm * BD_NP * 1024 * 4; }
+constexpr int BD_NP = 8, BD_NC = 2, BD_THREADS = 64 * (BD_NP + BD_NC), BD_DB = 4;
+__host__ __device__ constexpr int bd_smem_bytes(int nm) { return 2 * nm * BD_NP * 1024 * 4 + BD_NP * 2 * 32 * 4; }
 
 template <int EPI>
 __global__ __launch_bounds__(BD_THREADS) void bd_gemm_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float P[];           // [2][NM][BD_NP][4][64][4]
+    extern __shared__ __attribute__((aligned(16))) float P[];           // [2][NM][BD_NP][4][64][4] | wscale[BD_NP][NM][32]
     constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6) - 1;     // -1: chain
+    // weight blocks in flight per producer wavefront (5 VGPRs each): a workgroup of a 4096-row matrix must keep ~100 KB
+    // of the weight stream in flight by itself, because only rows/32 workgroups exist
+    constexpr int BD_D = NM == 1 ? 16 : 8;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6) - BD_NC;  // < 0: chain wavefronts
     const int tl = lane & 31, hi = lane >> 5;
     const int row0 = blockIdx.x * 32;
     const int nstrips = (a.rows + 15) >> 4;
@@ -424,25 +427,21 @@ __global__ __launch_bounds__(BD_THREADS) void bd_gemm_kernel(const GemmArgs a) {
         // ------------------------------------------------------------------ producers
         const int strip = min(nstrips - 1, (row0 >> 4) + (tl >> 4));        // strip of this lane's A row
         const int tok = min(a.ntok - 1, tl);
+        float* wsl = P + 2 * NM * BD_NP * 1024 + (size_t)wave * NM * 32;     // this wavefront's scale scratch
         const uint8_t* wbase[NM];
         wbase[0] = a.w;
         if (NM == 2) wbase[NM - 1] = a.w2;
         v4i_t af[NM][BD_D];
-        uint2 wsr[NM][BD_D][4];
-        v4i_t bf[2];
-        float xsv[2];
+        uint16_t wsr[NM][BD_D];           // lane l: f16 scale of row l & 31
+        v4i_t bf[BD_DB];
+        float xsv[BD_DB];
         auto load_a = [&](int u, int blk) {
             const int g = blk >> 2, bi = blk & 3;
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const uint8_t* tile = wbase[m] + (size_t)strip * strip_bytes + (size_t)g * TILE_BYTES;
                 af[m][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(tile + (hi ? 1152 : 128) + 16 * ((tl & 15) + 16 * bi)));
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {        // scales of rows 8q + 4hi .. +3 of the 32-row group (q < 2: first strip)
-                    const int s2 = min(nstrips - 1, (row0 >> 4) + (q >> 1));
-                    const uint8_t* t2 = wbase[m] + (size_t)s2 * strip_bytes + (size_t)g * TILE_BYTES;
-                    wsr[m][u][q] = *reinterpret_cast<const uint2*>(t2 + 2 * (((8 * q + 4 * hi) & 15) + 16 * bi));
-                }
+                wsr[m][u] = *reinterpret_cast<const uint16_t*>(tile + 2 * ((tl & 15) + 16 * bi));
             }
         };
         auto load_b = [&](int u, int blk) {
@@ -455,7 +454,9 @@ __global__ __launch_bounds__(BD_THREADS) void bd_gemm_kernel(const GemmArgs a) {
 #pragma unroll
         for (int u = 0; u < BD_D; ++u)
             if (u * BD_NP + wave < a.nb) load_a(u, u * BD_NP + wave);
-        if (wave < a.nb) load_b(0, wave);
+#pragma unroll
+        for (int u = 0; u < BD_DB; ++u)
+            if (u * BD_NP + wave < a.nb) load_b(u, u * BD_NP + wave);
         for (int base = 0; base < nrounds; base += BD_D) {
 #pragma unroll
             for (int u = 0; u < BD_D; ++u) {
@@ -463,23 +464,26 @@ __global__ __launch_bounds__(BD_THREADS) void bd_gemm_kernel(const GemmArgs a) {
                 if (r < nrounds) {
                     const int blk = r * BD_NP + wave;
                     if (blk < a.nb) {
-                        if (blk + BD_NP < a.nb) load_b((u + 1) & 1, blk + BD_NP);
-                        const v2f_t xs2 = v2f_t{xsv[u & 1], xsv[u & 1]};
+                        constexpr int dummy = 0; (void)dummy;
+                        const int ub = u % BD_DB;
+                        const v2f_t xs2 = v2f_t{xsv[ub], xsv[ub]};
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) wsl[m * 32 + tl] = h2f(wsr[m][u]);      // both halves write the same value
 #pragma unroll
                         for (int m = 0; m < NM; ++m) {
-                            const v16i_t c = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m][u], bf[u & 1], cbias, 0, 0, 0);
+                            const v16i_t c = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m][u], bf[ub], cbias, 0, 0, 0);
                             float* dst = P + ((size_t)((r & 1) * NM + m) * BD_NP + wave) * 1024 + lane * 4;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const uint2 w2 = wsr[m][u][q];
-                                const v2f_t wa = v2f_t{h2f((uint16_t)(w2.x & 0xFFFF)), h2f((uint16_t)(w2.x >> 16))};
-                                const v2f_t wb = v2f_t{h2f((uint16_t)(w2.y & 0xFFFF)), h2f((uint16_t)(w2.y >> 16))};
+                            for (int q = 0; q < 4; ++q) {        // rows 8q + 4hi .. +3 of the 32-row group
+                                const float4 w4 = *reinterpret_cast<const float4*>(wsl + m * 32 + 8 * q + 4 * hi);
+                                const v2f_t wa = v2f_t{w4.x, w4.y}, wb = v2f_t{w4.z, w4.w};
                                 const v2f_t ca = v2f_t{__int_as_float(c[4 * q]), __int_as_float(c[4 * q + 1])} - v2f_t{12582912.f, 12582912.f};
                                 const v2f_t cb = v2f_t{__int_as_float(c[4 * q + 2]), __int_as_float(c[4 * q + 3])} - v2f_t{12582912.f, 12582912.f};
                                 const v2f_t pa = ca * (wa * xs2), pb = cb * (wb * xs2);      // isum * (wScale * aScale)
                                 *reinterpret_cast<float4*>(dst + q * 256) = make_float4(pa[0], pa[1], pb[0], pb[1]);
                             }
                         }
+                        if (blk + BD_DB * BD_NP < a.nb) load_b(ub, blk + BD_DB * BD_NP);
                         if (blk + BD_D * BD_NP < a.nb) load_a(u, blk + BD_D * BD_NP);
                     }
                     __syncthreads();
@@ -489,27 +493,47 @@ __global__ __launch_bounds__(BD_THREADS) void bd_gemm_kernel(const GemmArgs a) {
         __syncthreads();
         return;
     }
-    // ---------------------------------------------------------------------- chain wavefront
+    // ---------------------------------------------------------------------- chain wavefronts
+    // Chain wavefront c owns accumulator quads q = 2c, 2c + 1 (rows 8q + 4hi .. +3) of every (token, row) pair: two quads x
+    // NM matrices = 4 or 8 independent packed chains per lane; block w + 1 is fetched from LDS while block w is added.
     __builtin_amdgcn_s_setprio(3);
-    float acc[NM][16];
+    const int cw = wave + BD_NC;                         // 0 .. BD_NC - 1
+    v2f_t acc[NM][2][2];
 #pragma unroll
     for (int m = 0; m < NM; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        for (int j = 0; j < 2; ++j) { acc[m][j][0] = v2f_t{0.f, 0.f}; acc[m][j][1] = v2f_t{0.f, 0.f}; }
+    auto pload = [&](float4 (&v)[NM][2], int r, int w) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                v[m][j] = *reinterpret_cast<const float4*>(P + ((size_t)((r & 1) * NM + m) * BD_NP + w) * 1024 + (2 * cw + j) * 256 + lane * 4);
+    };
+    auto padd = [&](const float4 (&v)[NM][2]) {          // result += p (packed: two chains per instruction)
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[m][j][0] = acc[m][j][0] + v2f_t{v[m][j].x, v[m][j].y};
+                acc[m][j][1] = acc[m][j][1] + v2f_t{v[m][j].z, v[m][j].w};
+            }
+    };
     for (int r = 0; r < nrounds; ++r) {
         __syncthreads();
         const int nblk = min(BD_NP, a.nb - r * BD_NP);
-        for (int w = 0; w < nblk; ++w) {                     // blocks ascending: result += p
+        float4 va[NM][2], vb[NM][2];
+        if (nblk == BD_NP) {
+            pload(va, r, 0);
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const float* src = P + ((size_t)((r & 1) * NM + m) * BD_NP + w) * 1024 + lane * 4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = *reinterpret_cast<const float4*>(src + q * 256);
-                    acc[m][4 * q] = acc[m][4 * q] + v.x; acc[m][4 * q + 1] = acc[m][4 * q + 1] + v.y;
-                    acc[m][4 * q + 2] = acc[m][4 * q + 2] + v.z; acc[m][4 * q + 3] = acc[m][4 * q + 3] + v.w;
-                }
+            for (int w = 0; w < BD_NP; w += 2) {         // blocks ascending
+                pload(vb, r, w + 1);
+                padd(va);
+                if (w + 2 < BD_NP) pload(va, r, w + 2);
+                padd(vb);
             }
+        } else {
+            for (int w = 0; w < nblk; ++w) { pload(va, r, w); padd(va); }
         }
     }
     __syncthreads();
@@ -517,18 +541,19 @@ __global__ __launch_bounds__(BD_THREADS) void bd_gemm_kernel(const GemmArgs a) {
     const int b = tl;
     if (b >= a.ntok) return;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int rbase = row0 + 8 * q + 4 * hi;
+    for (int j = 0; j < 2; ++j) {
+        const int rbase = row0 + 8 * (2 * cw + j) + 4 * hi;
         float* o = a.out + (size_t)b * a.out_stride + rbase;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (rbase + i >= a.rows) continue;
+            const float v0 = acc[0][j][i >> 1][i & 1];
             if (EPI == EPI_SWIGLU) {
-                float g = acc[0][4 * q + i];
+                float g = v0;
                 g = g / (float)(1.0 + exp(-(double)g));
-                o[i] = g * acc[NM - 1][4 * q + i];
-            } else if (EPI == EPI_STORE) o[i] = acc[0][4 * q + i];
-            else o[i] = o[i] + acc[0][4 * q + i];
+                o[i] = g * acc[NM - 1][j][i >> 1][i & 1];
+            } else if (EPI == EPI_STORE) o[i] = v0;
+            else o[i] = o[i] + v0;
         }
     }
 }
