@@ -406,11 +406,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
 //       flight), B fragment from XQ (L2), one int8 MFMA, p = float(isum) * (wScale * aScale) into a double-buffered LDS ring;
 //   chain (wave 0, raised priority): result += p in block order (16 independent chains per lane) and the epilogue.
 // One barrier per round of 8 blocks.  Grid = rows / 32.
-constexpr int BD_NP = 8, BD_NC = 2, BD_THREADS = 64 * (BD_NP + BD_NC), BD_DB = 4;
-__host__ __device__ constexpr int bd_smem_bytes(int nm) { return 2 * nm * BD_NP * 1024 * 4 + BD_NP * 2 * 32 * 4; }
+// BD_NP = producer wavefronts = blocks per round (8; the 4-producer variant with half the LDS ring measured slower).
+constexpr int BD_NC = 2, BD_DB = 4;
+__host__ __device__ constexpr int bd_threads(int np) { return 64 * (np + BD_NC); }
+__host__ __device__ constexpr int bd_smem_bytes(int nm, int np) { return 2 * nm * np * 1024 * 4 + np * 2 * 32 * 4; }
 
-template <int EPI>
-__global__ __launch_bounds__(BD_THREADS) void bd_gemm_kernel(const GemmArgs a) {
+template <int EPI, int BD_NP>
+__global__ __launch_bounds__(bd_threads(BD_NP)) void bd_gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float P[];           // [2][NM][BD_NP][4][64][4] | wscale[BD_NP][NM][32]
     constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
     // weight blocks in flight per producer wavefront (5 VGPRs each): a workgroup of a 4096-row matrix must keep ~100 KB
@@ -913,9 +915,11 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_GEMM_LDS(EPI_STORE, 1, 4); GL3_GEMM_LDS(EPI_STORE, 2, 4); GL3_GEMM_LDS(EPI_STORE, 1, 8);
     GL3_GEMM_LDS(EPI_RESID, 1, 4); GL3_GEMM_LDS(EPI_RESID, 2, 4); GL3_GEMM_LDS(EPI_RESID, 1, 8);
     GL3_GEMM_LDS(EPI_SWIGLU, 1, 4);
-    GL3_HIP(hipFuncSetAttribute((const void*)bd_gemm_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, bd_smem_bytes(1)));
-    GL3_HIP(hipFuncSetAttribute((const void*)bd_gemm_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, bd_smem_bytes(1)));
-    GL3_HIP(hipFuncSetAttribute((const void*)bd_gemm_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, bd_smem_bytes(2)));
+#define GL3_BD_LDS(EPI_, NM_) \
+    GL3_HIP(hipFuncSetAttribute((const void*)bd_gemm_kernel<EPI_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bd_smem_bytes(NM_, 8))); \
+    GL3_HIP(hipFuncSetAttribute((const void*)bd_gemm_kernel<EPI_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bd_smem_bytes(NM_, 4)))
+    GL3_BD_LDS(EPI_STORE, 1); GL3_BD_LDS(EPI_RESID, 1); GL3_BD_LDS(EPI_SWIGLU, 2);
+#undef GL3_BD_LDS
     GL3_GEMM_LDS(EPI_STORE, 1, 4, 32); GL3_GEMM_LDS(EPI_RESID, 1, 4, 32); GL3_GEMM_LDS(EPI_SWIGLU, 1, 4, 32);
 #undef GL3_GEMM_LDS
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -942,7 +946,11 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     // workgroup when even those leave a single workgroup per CU
     static const bool bd_off = getenv("GL3_NO_BD_GEMM") && atoi(getenv("GL3_NO_BD_GEMM"));
     if (ntok <= 32 && !bd_off) {      // static-batched decode: producer / chain split over all K (bd_gemm_kernel)
-        hipLaunchKernelGGL((bd_gemm_kernel<EPI>), dim3((w.rows + 31) / 32), dim3(BD_THREADS), bd_smem_bytes(EPI == EPI_SWIGLU ? 2 : 1), ctx->stream, a);
+        constexpr int NMX = EPI == EPI_SWIGLU ? 2 : 1;
+        const int nwg = (w.rows + 31) / 32;
+        static const bool np4 = getenv("GL3_BD_NP4") && atoi(getenv("GL3_BD_NP4"));      // measured slower (6.1 vs 5.7 ms / step, Qwen3-4B B=32)
+        if (nwg <= 256 || !np4) hipLaunchKernelGGL((bd_gemm_kernel<EPI, 8>), dim3(nwg), dim3(bd_threads(8)), bd_smem_bytes(NMX, 8), ctx->stream, a);
+        else hipLaunchKernelGGL((bd_gemm_kernel<EPI, 4>), dim3(nwg), dim3(bd_threads(4)), bd_smem_bytes(NMX, 4), ctx->stream, a);
         return;
     }
     if (ntok <= 64) {      // 32-token tiles, 128 rows (x2 matrices for SwiGLU) per workgroup
