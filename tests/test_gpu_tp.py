@@ -19,10 +19,11 @@ def planmod():
     return import_module(ge.PKG_NAME + ".plan"), import_module(ge.PKG_NAME + ".hip")
 
 
-@pytest.mark.parametrize("cfg,tp", [("mid-llama", 2), ("mid-llama", 4), ("mid-qwen3", 2), ("tiny-llama-tied", 2)])
-def test_row_split_ranks_are_bit_identical_to_the_oracle(pkg, orc, planmod, cfg, tp):
+@pytest.mark.parametrize("cfg,tp,wtype", [("mid-llama", 2, 8), ("mid-llama", 4, 8), ("mid-qwen3", 2, 8), ("tiny-llama-tied", 2, 8),
+                                          ("mid-llama", 2, 2), ("mid-llama", 4, 1), ("mid-qwen3", 2, 1)])   # BASELINE configs[3]: Q4_0 row split
+def test_row_split_ranks_are_bit_identical_to_the_oracle(pkg, orc, planmod, cfg, tp, wtype):
     plan_mod, hip = planmod
-    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], seed=17)
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=17)
     o = orc.COracle(m)
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 6)
     ref = [o.forward(t, p) for p, t in enumerate(toks)]
