@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
         const size_t bytes = (size_t)a.nstrips * a.ng * TILE_BYTES;
         const int nm = sh.epi == EPI_SWIGLU ? 2 : 1;
         // enough distinct buffers to defeat the 256 MiB infinity cache
-        const int nbuf = (int)std::max<size_t>(2, (600ull << 20) / (bytes * nm) + 1);
+        const int nbuf = getenv("MB_WARM") ? 1 : (int)std::max<size_t>(2, (600ull << 20) / (bytes * nm) + 1);   // MB_WARM=1: same buffer every launch (Infinity-Cache resident)
         std::vector<uint8_t*> wb, w2b;
         for (int i = 0; i < nbuf; ++i) { uint8_t* p; CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0x11 + i, bytes)); wb.push_back(p);
             if (nm == 2) { CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0x23 + i, bytes)); w2b.push_back(p); } }

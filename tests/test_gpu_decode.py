@@ -259,3 +259,22 @@ def test_native_gguf_loader_builds_the_same_plan(pkg, planmod, tmp_path, cfg, wt
     a.freeTornadoExecutionPlan(); b.freeTornadoExecutionPlan()
     with pytest.raises(hip.Gl3Error):
         plan_mod.HipMasterPlan.from_gguf(str(tmp_path / "missing.gguf"))
+
+
+def test_native_bench_host_over_the_c_abi(pkg, planmod, tmp_path):
+    """tools/gl3_bench (plain C++, links only the C-ABI): loads a GGUF natively, runs the LlamaBench protocol and must produce
+    the same greedy ids as the Python host for the java.util.Random(42) token stream."""
+    import subprocess
+    plan_mod, hip = planmod
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], seed=23)
+    path = str(tmp_path / "m.gguf")
+    m.write_gguf(path)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gl3_bench")
+    out = subprocess.run([exe, "-m", path, "-p", "16", "-n", "12", "-b", "8", "-r", "1", "--ids"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "| tiny-llama-random | pp16 -b 8 |" in out.stdout and "| tiny-llama-random | tg12 |" in out.stdout
+    ids = [int(x) for x in out.stdout.split("greedy ids:")[1].split()]
+    plan = plan_mod.HipMasterPlan(m)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 16)
+    assert ids == [plan.forward_decode_argmax(toks[i], i) for i in range(12)]
+    plan.freeTornadoExecutionPlan()
