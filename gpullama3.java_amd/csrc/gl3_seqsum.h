@@ -107,23 +107,22 @@ __device__ __forceinline__ void replay_events(const float* x, int m, int nseg, i
             sq.x = v.x * v.x; sq.y = v.y * v.y; sq.z = v.z * v.z; sq.w = v.w * v.w;
         }
         SS_STAMP(5);
-        const int nev = min(64, nhard + 1 - c0);
-        // the sequential part: a pure register chain fed by v_readlane (lane index uniform)
-        for (int jj = 0; jj < nev; ++jj) {
-            const uint32_t e_r = (uint32_t)__builtin_amdgcn_readlane((int)er, jj);
-            const float ra = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(runadd), jj));
-            const float s0 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sq.x), jj));
-            const float s1 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sq.y), jj));
-            const float s2 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sq.z), jj));
-            const float s3 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sq.w), jj));
-            if (e_r != 0u) {
-                fail |= (f2u(base) >> 23) != e_r;
-                base = base + ra;
-                fail |= (f2u(base) >> 23) != e_r;
-            }
+        const int nev = __builtin_amdgcn_readfirstlane(min(64, nhard + 1 - c0));   // scalar loop control (s_cmp, not a VALU compare + vcc branch)
+        // the sequential part: a pure register chain fed by v_readlane (lane index uniform).  The run add is unconditional
+        // (+0 when there is no easy run before the event) and the binade checks are deferred: lane jj keeps the chain value
+        // before and after event jj's run add (v_cndmask) and all lanes check their own event in parallel afterwards.
+        float b_before = 0.f, b_after = 0.f;
+        auto rl = [&](float v, int j) { return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), j)); };
+        for (int jj = 0; jj < nev; ++jj) {                 // ~45 cycles per event = the five dependent adds
+            const float ra = rl(runadd, jj), s0 = rl(sq.x, jj), s1 = rl(sq.y, jj), s2 = rl(sq.z, jj), s3 = rl(sq.w, jj);
+            b_before = lane == jj ? base : b_before;
+            base = base + ra;
+            b_after = lane == jj ? base : b_after;
             base = base + s0; base = base + s1; base = base + s2; base = base + s3;
         }
+        if (lane < nev && er != 0u) fail |= (int)((f2u(b_before) >> 23) != er) | (int)((f2u(b_after) >> 23) != er);
     }
+    fail = __builtin_amdgcn_ballot_w64(fail != 0) != 0;          // any lane's violation fails the wavefront
 }
 
 // Barrier functors for exact_sumsq_lds: `sync()` must be a barrier over exactly the 4 participating wavefronts.
