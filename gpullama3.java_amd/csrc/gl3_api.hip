@@ -122,15 +122,13 @@ static uint64_t mv_bytes(const Q8Mat& w) { return w.algo_bytes() + (uint64_t)w.k
 // Tensor parallelism keeps the reference's arithmetic bit for bit: every matrix is split by OUTPUT rows (heads /
 // hidden units / dim rows / vocab rows), so each dot product is still evaluated in full, in order, by one rank;
 // the activations are re-assembled with an in-place all-gather (4 per layer + 1 for the logits).
-enum { GB_XB = 0, GB_X = 1, GB_HB = 2, GB_LOGITS = 3 };
-static float* gather_buf(gl3_ctx* c, int which) {
+float* gl3_gather_buf(gl3_ctx* c, int which) {
+    if (which >= GB_PF_X) return gl3_prefill_buf(c, which);
     return which == GB_XB ? c->xb : which == GB_X ? c->x : which == GB_HB ? c->hb : c->logits;
 }
 
-static int32_t all_gather(gl3_ctx* ctx, int which, int count_per_rank, Prof& pr) {
-    if (!ctx->use_rccl) return GL3_OK;
-    float* buf = gather_buf(ctx, which);
-    pr.begin(GL3_K_COLLECTIVE, 0);
+static int32_t all_gather_impl(gl3_ctx* ctx, int which, size_t count_per_rank) {
+    float* buf = gl3_gather_buf(ctx, which);
     if (ctx->lgrp) {                                   // in-process test transport (see gl3_local_group)
         gl3_local_group* g = ctx->lgrp;
         const int me = ctx->d.tp_rank;
@@ -139,8 +137,8 @@ static int32_t all_gather(gl3_ctx* ctx, int which, int count_per_rank, Prof& pr)
         for (int p = 0; p < g->n; ++p) {
             if (p == me) continue;
             GL3_HIP(hipStreamWaitEvent(ctx->stream, g->ready[p], 0));
-            GL3_HIP(hipMemcpyAsync(buf + (size_t)p * count_per_rank, gather_buf(g->ranks[p], which) + (size_t)p * count_per_rank,
-                                   (size_t)count_per_rank * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            GL3_HIP(hipMemcpyAsync(buf + (size_t)p * count_per_rank, gl3_gather_buf(g->ranks[p], which) + (size_t)p * count_per_rank,
+                                   count_per_rank * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
         GL3_HIP(hipEventRecord(g->done[me], ctx->stream));
         g->barrier();                                  // nobody overwrites a slice a peer is still copying
@@ -150,6 +148,19 @@ static int32_t all_gather(gl3_ctx* ctx, int which, int count_per_rank, Prof& pr)
     } else {
         GL3_NCCL(ncclAllGather(buf + (size_t)ctx->d.tp_rank * count_per_rank, buf, count_per_rank, ncclFloat, ctx->comm, ctx->stream));
     }
+    return GL3_OK;
+}
+
+int32_t gl3_all_gather(gl3_ctx* ctx, int which, size_t count_per_rank) {
+    if (!ctx->use_rccl) return GL3_OK;
+    return all_gather_impl(ctx, which, count_per_rank);
+}
+
+static int32_t all_gather(gl3_ctx* ctx, int which, int count_per_rank, Prof& pr) {
+    if (!ctx->use_rccl) return GL3_OK;
+    pr.begin(GL3_K_COLLECTIVE, 0);
+    const int32_t r = all_gather_impl(ctx, which, (size_t)count_per_rank);
+    if (r != GL3_OK) return r;
     pr.end();
     return GL3_OK;
 }

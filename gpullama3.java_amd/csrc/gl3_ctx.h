@@ -120,7 +120,14 @@ struct gl3_ctx {
         return (code);                                                                                 \
     } while (0)
 
+// gl3_api.hip: in-place all-gather of buf = [tp][count_per_rank] over the plan's transport (RCCL or the local test group);
+// which = GB_* id of the buffer (the local transport resolves the peers' pointers through gl3_gather_buf)
+enum { GB_XB = 0, GB_X = 1, GB_HB = 2, GB_LOGITS = 3, GB_PF_X = 4, GB_PF_AO = 5, GB_PF_HB = 6 };
+float* gl3_gather_buf(gl3_ctx* c, int which);
+int32_t gl3_all_gather(gl3_ctx* ctx, int which, size_t count_per_rank);
+
 // gl3_prefill.hip
+float* gl3_prefill_buf(gl3_ctx* ctx, int which);
 int32_t gl3_prefill_alloc(gl3_ctx* ctx);
 void gl3_prefill_free(gl3_ctx* ctx);
 int32_t gl3_prefill_run(gl3_ctx* ctx, int32_t seq, const int32_t* tokens, int32_t n, int32_t start_pos);

@@ -39,19 +39,24 @@ typedef int v16i_t __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------------
 // token_embedding_table.copyTo per token (batchForwardJavaPrefill :96)
+// Activation layout under tensor parallelism ("rank-chunked"): a [ntok][cols] activation that is produced by row-split
+// matrices is kept as [tp][ntok][cols / tp], so every rank's output is one contiguous chunk and the all-gather is in
+// place; element j of token b sits at (j / cc) * ntok * cc + b * cc + j % cc with cc = cols / tp (tp = 1: the plain layout).
+__device__ __forceinline__ size_t chunked(int b, int j, int cc, int ntok) { return ((size_t)(j / cc) * ntok + b) * cc + (j % cc); }
+
 __global__ __launch_bounds__(256) void pf_embed_kernel(const uint8_t* __restrict__ emb, int ng, int dim,
-                                                        const int32_t* __restrict__ tokens, float* __restrict__ X) {
+                                                        const int32_t* __restrict__ tokens, float* __restrict__ X, int cc) {
     const int token = tokens[blockIdx.x];
     const uint8_t* strip = emb + (size_t)(token >> 4) * ng * TILE_BYTES;
     const int i16 = token & 15;
-    float* x = X + (size_t)blockIdx.x * dim;
+    const int bt = blockIdx.x, nt = gridDim.x;
     for (int i = threadIdx.x; i < dim; i += 256) {
         const int b = i >> 5, j = i & 31;
         const uint8_t* p = strip + (size_t)(b >> 2) * TILE_BYTES;
         const int l = i16 + 16 * (b & 3);
         const float d = h2f(*reinterpret_cast<const uint16_t*>(p + 2 * l));
         const int8_t q = (int8_t)p[(j < 16 ? 128 : 1152) + 16 * l + (j & 15)];
-        x[i] = (float)q * d;
+        X[chunked(bt, i, cc, nt)] = (float)q * d;
     }
 }
 
@@ -67,12 +72,13 @@ __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restr
     uint8_t* scratch = smem + (size_t)(k + 32) * 4;             // ss_scratch_bytes(k)
     float* red = reinterpret_cast<float*>(scratch + ss_scratch_bytes(k));
     const int t = threadIdx.x, b = blockIdx.x;
-    const float* x = in + (size_t)b * in_stride;
+    const int cc = in_stride, nt = gridDim.x;                    // in_stride = chunk columns (k / tp); cc % 4 == 0
+    auto xquad = [&](int qd) { return *reinterpret_cast<const float4*>(in + chunked(b, 4 * qd, cc, nt)); };
     const int nquads = k >> 2;
     float scale = 1.0f;
     if (NORM) {
         for (int qd = t; qd < nquads; qd += 256)
-            *reinterpret_cast<float4*>(xf + 4 * qd) = *reinterpret_cast<const float4*>(x + 4 * qd);
+            *reinterpret_cast<float4*>(xf + 4 * qd) = xquad(qd);
         if (t < 32) xf[k + t] = 0.f;
         __syncthreads();
         float ss;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restr
             const float4 w = *reinterpret_cast<const float4*>(norm_w + 4 * qd);
             v.x = w.x * (scale * v.x); v.y = w.y * (scale * v.y); v.z = w.z * (scale * v.z); v.w = w.w * (scale * v.w);
         } else {
-            v = *reinterpret_cast<const float4*>(x + 4 * qd);
+            v = xquad(qd);
         }
         quantize_quad(v, qd, xq, xs);
     }
@@ -987,24 +993,31 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
     const int32_t* seq = p->seqpos;
     const int32_t* pos = p->seqpos + p->max_batch;
     const int kvmul = d.n_heads / d.n_kv_heads;
-    const int qkv_dim = ctx->q_dim + 2 * ctx->kv_dim;
-    const size_t kv_layer = (size_t)d.ctx * ctx->kv_dim;
-    hipLaunchKernelGGL(pf_embed_kernel, dim3(n), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, p->tokens, p->X);
+    // tensor parallel: this rank's heads / hidden units / dim rows; activations that are gathered use the rank-chunked layout
+    const int rank = d.tp_rank, H = ctx->heads_l, KVH = ctx->kv_heads_l, qd = ctx->q_dim_l, kvd = ctx->kv_dim_l;
+    const int hid = ctx->hidden_l, dml = ctx->dim_l;
+    const int qkv_dim = qd + 2 * kvd;
+    const size_t kv_layer = (size_t)d.ctx * kvd;
+    float* Xr = p->X + (size_t)rank * n * dml;           // this rank's chunk of X / AO / HB
+    float* AOr = p->AO + (size_t)rank * n * qd;
+    float* HBr = p->HB + (size_t)rank * n * hid;
+    int32_t r;
+    hipLaunchKernelGGL(pf_embed_kernel, dim3(n), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, p->tokens, p->X, dml);
     auto nq_smem = [&](int k) { return (size_t)(k + 32) * 4 + ss_scratch_bytes(k) + 64; };
     for (int l = 0; l < d.n_layers; ++l) {
         gl3_layer& L = ctx->layers[l];
-        hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, d.dim, L.attn_norm, d.rms_eps,
+        hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.attn_norm, d.rms_eps,
                            p->XQ, p->XS, p->maxk);
         launch_gemm<EPI_STORE>(ctx, L.wqkv, nullptr, n, p->QKV, qkv_dim);
         RopeArgs ra{};
         ra.QKV = p->QKV; ra.qkv_stride = qkv_dim; ra.kcache = ctx->kcache + l * kv_layer; ra.vcache = ctx->vcache + l * kv_layer;
-        ra.cr = ctx->rope_cr; ra.ci = ctx->rope_ci; ra.qnorm = L.qnorm; ra.knorm = L.knorm; ra.n_heads = d.n_heads;
-        ra.n_kv_heads = d.n_kv_heads; ra.hs = d.head_size; ra.q_dim = ctx->q_dim; ra.kv_dim = ctx->kv_dim;
+        ra.cr = ctx->rope_cr; ra.ci = ctx->rope_ci; ra.qnorm = L.qnorm; ra.knorm = L.knorm; ra.n_heads = H;
+        ra.n_kv_heads = KVH; ra.hs = d.head_size; ra.q_dim = qd; ra.kv_dim = kvd;
         ra.arch = d.arch; ra.eps = d.rms_eps; ra.seq = seq; ra.pos = pos; ra.seq_stride = ctx->kv_seq_stride;
-        hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(d.n_heads + d.n_kv_heads, n), dim3(64), 0, s, ra);
+        hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(H + KVH, n), dim3(64), 0, s, ra);
         PfAttnArgs aa{};
-        aa.Q = p->QKV; aa.q_stride = qkv_dim; aa.kcache = ra.kcache; aa.vcache = ra.vcache; aa.att = p->ATT; aa.out = p->AO;
-        aa.out_stride = ctx->q_dim; aa.n_heads = d.n_heads; aa.n_kv_heads = d.n_kv_heads; aa.hs = d.head_size; aa.kv_dim = ctx->kv_dim;
+        aa.Q = p->QKV; aa.q_stride = qkv_dim; aa.kcache = ra.kcache; aa.vcache = ra.vcache; aa.att = p->ATT; aa.out = AOr;
+        aa.out_stride = qd; aa.n_heads = H; aa.n_kv_heads = KVH; aa.hs = d.head_size; aa.kv_dim = kvd;
         aa.ctx = d.ctx; aa.seq = seq; aa.pos = pos; aa.seq_stride = ctx->kv_seq_stride;
         const int nsplit = (max_pos + 1 + ATT_TT - 1) / ATT_TT;
         const int hs = d.head_size;
@@ -1012,7 +1025,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         if (tiled) {
             const int pos0 = max_pos + 1 - n, ntt = (n + PA_TB - 1) / PA_TB;
             const size_t sms = (size_t)64 * (hs + 4) * 4;
-            const dim3 g1(nsplit, d.n_kv_heads, ntt), b1(64 * kvmul);
+            const dim3 g1(nsplit, KVH, ntt), b1(64 * kvmul);
             const float* kc1 = aa.kcache + (size_t)one_seq * ctx->kv_seq_stride;
 #define GL3_SCORES(HS_) hipLaunchKernelGGL((pf_scores_tiled_kernel<HS_>), g1, b1, sms, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n)
             if (hs == 128) GL3_SCORES(128);
@@ -1022,26 +1035,40 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
             const int npad = (max_pos + 1 + 63) & ~63;
             int wpw = (int)((60 * 1024) / ((size_t)npad * 4));
             wpw = wpw > 4 ? 4 : wpw;
-            hipLaunchKernelGGL(pf_softmax_kernel, dim3((n * d.n_heads + wpw - 1) / wpw), dim3(256), (size_t)wpw * npad * 4, s, aa, n, wpw, npad);
-            if (hs > 64) hipLaunchKernelGGL((pf_pv_tiled_kernel<2>), dim3(d.n_heads, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
-            else hipLaunchKernelGGL((pf_pv_tiled_kernel<1>), dim3(d.n_heads, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
+            hipLaunchKernelGGL(pf_softmax_kernel, dim3((n * H + wpw - 1) / wpw), dim3(256), (size_t)wpw * npad * 4, s, aa, n, wpw, npad);
+            if (hs > 64) hipLaunchKernelGGL((pf_pv_tiled_kernel<2>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
+            else hipLaunchKernelGGL((pf_pv_tiled_kernel<1>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
         } else {
             const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
-            hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, d.n_kv_heads, n), dim3(64 * kvmul), sm1, s, aa);
-            hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(d.n_heads * ((d.head_size + 63) / 64), n), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
+            hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, KVH, n), dim3(64 * kvmul), sm1, s, aa);
+            hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(H * ((d.head_size + 63) / 64), n), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
         }
-        hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->AO, ctx->q_dim, ctx->q_dim, (const float*)nullptr,
+        if ((r = gl3_all_gather(ctx, GB_PF_AO, (size_t)n * qd)) != GL3_OK) return r;
+        hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->AO, ctx->q_dim, qd, (const float*)nullptr,
                            0.f, p->XQ, p->XS, p->maxk);
-        launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, p->X, d.dim);
-        hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, d.dim, L.ffn_norm, d.rms_eps,
+        launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, Xr, dml);
+        if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
+        hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.ffn_norm, d.rms_eps,
                            p->XQ, p->XS, p->maxk);
-        launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, p->HB, d.hidden);
-        hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->HB, d.hidden, d.hidden, (const float*)nullptr, 0.f,
+        launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, HBr, hid);
+        if ((r = gl3_all_gather(ctx, GB_PF_HB, (size_t)n * hid)) != GL3_OK) return r;
+        hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->HB, d.hidden, hid, (const float*)nullptr, 0.f,
                            p->XQ, p->XS, p->maxk);
-        launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, p->X, d.dim);
+        launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, Xr, dml);
+        if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
     }
     GL3_HIP(hipGetLastError());
     return GL3_OK;
+}
+
+float* gl3_prefill_buf(gl3_ctx* ctx, int which) {
+    gl3_prefill_state* p = ctx->pf;
+    return which == GB_PF_X ? p->X : which == GB_PF_AO ? p->AO : p->HB;
+}
+
+// x of token b from the rank-chunked X into the decode path's plain ctx->x (parity tap gl3_get_x)
+static __global__ void pf_unchunk_row_kernel(const float* __restrict__ X, int b, int dim, int cc, int ntok, float* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x) out[i] = X[chunked(b, i, cc, ntok)];
 }
 
 static int32_t pf_stage_tokens(gl3_ctx* ctx, const int32_t* tokens, const int32_t* seqs, const int32_t* poss, int n) {
@@ -1055,7 +1082,6 @@ static int32_t pf_stage_tokens(gl3_ctx* ctx, const int32_t* tokens, const int32_
 int32_t gl3_prefill_run(gl3_ctx* ctx, int32_t seq, const int32_t* tokens, int32_t n, int32_t start_pos) {
     gl3_prefill_state* p = ctx->pf;
     const gl3_model_desc& d = ctx->d;
-    if (d.tp_size > 1) GL3_FAIL(GL3_E_UNSUPPORTED, "batched prefill under tensor parallelism is not implemented: use max_batch = 1");
     for (int i = 0; i < n; ++i)
         if (tokens[i] < 0 || tokens[i] >= d.vocab) GL3_FAIL(GL3_E_ARG, "token id out of range");
     GL3_HIP(hipSetDevice(d.device));
@@ -1065,7 +1091,7 @@ int32_t gl3_prefill_run(gl3_ctx* ctx, int32_t seq, const int32_t* tokens, int32_
     if (r != GL3_OK) return r;
     if ((r = pf_layers(ctx, n, start_pos + n - 1, seq)) != GL3_OK) return r;
     // keep the decode path's x in step with the last prefilled token (parity tap gl3_get_x)
-    GL3_HIP(hipMemcpyAsync(ctx->x, p->X + (size_t)(n - 1) * d.dim, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(pf_unchunk_row_kernel, dim3(4), dim3(256), 0, ctx->stream, p->X, n - 1, d.dim, ctx->dim_l, n, ctx->x);
     GL3_HIP(hipStreamSynchronize(ctx->stream));
     return GL3_OK;
 }

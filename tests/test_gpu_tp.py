@@ -59,3 +59,47 @@ def test_single_rank_rccl_communicator(pkg, orc, planmod):
     for pos, t in enumerate(pkg.javarand.bench_tokens(m.cfg.vocab, 4)):
         assert np.array_equal(plan.forward_decode(t, pos), o.forward(t, pos))
     plan.freeTornadoExecutionPlan()
+
+
+@pytest.mark.parametrize("cfg,tp,chunks", [("mid-llama", 2, [40, 9]), ("mid-qwen3", 2, [20, 7])])
+def test_batched_prefill_under_row_split(pkg, orc, planmod, cfg, tp, chunks):
+    """Batched (int8 MFMA) prefill on tensor-parallel ranks: row-split GEMMs, rank-chunked activations, three all-gathers
+    per layer.  Every rank's KV slice and the decode step that follows must equal the CPU oracle bit for bit."""
+    plan_mod, hip = planmod
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], seed=41)
+    o = orc.COracle(m)
+    n = sum(chunks)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, n + 2)
+    o.prefill(toks[:n], 0)
+    ref = [o.forward(toks[n], n), o.forward(toks[n + 1], n + 1)]
+    kvl = m.cfg.kv_dim // tp
+    grp = plan_mod.make_local_group(tp)
+    out, kvs, err = [None] * tp, [None] * tp, [None] * tp
+
+    def rank_main(r):
+        try:
+            plan = plan_mod.HipMasterPlan(m, prefill_batch_size=64, tp_rank=r, tp_size=tp, local_group=grp)
+            pos = 0
+            for c in chunks:
+                plan.tornadoVMForwardBatchPrefill(toks[pos:pos + c], pos)
+                pos += c
+            out[r] = [plan.forward_decode(toks[n], n), plan.forward_decode(toks[n + 1], n + 1)]
+            kvs[r] = [plan.kv(l, p) for l in range(m.cfg.n_layers) for p in (0, n // 2, n - 1)]
+            plan.freeTornadoExecutionPlan()
+        except Exception as e:   # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(tp)]
+    [t.start() for t in th]
+    [t.join(timeout=180) for t in th]
+    assert all(e is None for e in err), err
+    assert not any(t.is_alive() for t in th)
+    hip.lib().gl3_local_group_destroy(grp)
+    for r in range(tp):
+        assert np.array_equal(out[r][0], ref[0]) and np.array_equal(out[r][1], ref[1]), r
+        i = 0
+        for l in range(m.cfg.n_layers):
+            for p in (0, n // 2, n - 1):
+                ko, vo = o.kv(l, p)
+                k, v = kvs[r][i]; i += 1
+                assert np.array_equal(k, ko[r * kvl:(r + 1) * kvl]) and np.array_equal(v, vo[r * kvl:(r + 1) * kvl]), (r, l, p)
