@@ -278,3 +278,30 @@ def test_native_bench_host_over_the_c_abi(pkg, planmod, tmp_path):
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 16)
     assert ids == [plan.forward_decode_argmax(toks[i], i) for i in range(12)]
     plan.freeTornadoExecutionPlan()
+
+
+@pytest.mark.parametrize("cfg", ["tiny-llama", "tiny-qwen3"])
+def test_long_context_prefill_and_decode(pkg, orc, planmod, cfg):
+    """Context beyond one V slab (PV_ROWS = 1024) and beyond 16 score tiles: batched prefill in 512-token chunks that start
+    at non-zero positions, then decode steps at positions > 1024, all bit-identical to the oracle."""
+    plan_mod, hip = planmod
+    base = pkg.synth.CONFIGS[cfg]
+    m = pkg.synth.make_numpy(pkg.synth.ModelConfig(**{**base.__dict__, "ctx": 1300}), seed=31)
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=512)
+    o = orc.COracle(m)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 1104)
+    pos = 0
+    for c in (512, 512, 76):
+        plan.tornadoVMForwardBatchPrefill(toks[pos:pos + c], pos)
+        pos += c
+    o.prefill(toks[:1100], 0)
+    for p in range(1100, 1104):
+        ref = o.forward(toks[p], p)
+        got = plan.forward_decode(toks[p], p)
+        assert np.array_equal(got, ref), (p, rel(got, ref))
+    for l in range(m.cfg.n_layers):
+        for p in (0, 511, 512, 1023, 1024, 1099, 1103):
+            k, v = plan.kv(l, p)
+            ko, vo = o.kv(l, p)
+            assert np.array_equal(k, ko) and np.array_equal(v, vo), (l, p)
+    plan.freeTornadoExecutionPlan()
