@@ -172,7 +172,7 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
     const int kvmul = d.n_heads / d.n_kv_heads;
     AttnArgs aa{};
     aa.qkv = ctx->qkv; aa.kcache = ctx->kcache + l * kv_layer; aa.vcache = ctx->vcache + l * kv_layer;
-    aa.rope_cr = ctx->rope_cr; aa.rope_ci = ctx->rope_ci; aa.qnorm = L.qnorm; aa.knorm = L.knorm;
+    aa.rope_cr = ctx->rope_cr; aa.rope_ci = ctx->rope_ci; aa.qnorm = L.qnorm; aa.knorm = L.knorm; aa.bq = L.bq; aa.bk = L.bk; aa.bv = L.bv;
     aa.dyn = ctx->dyn; aa.att = ctx->att; aa.xb = ctx->xb + (size_t)d.tp_rank * ctx->q_dim_l;
     aa.n_heads = ctx->heads_l; aa.n_kv_heads = ctx->kv_heads_l;
     aa.hs = d.head_size; aa.q_dim = ctx->q_dim_l; aa.kv_dim = ctx->kv_dim_l; aa.ctx = d.ctx;
@@ -296,7 +296,7 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     const gl3_model_desc& d = ctx->d;
     auto bail = [&](int32_t code, const std::string& msg) { g_create_err = msg.empty() ? ctx->err : msg; gl3_destroy(ctx); return code; };
     const double t0 = now_ms();
-    if (d.arch != GL3_ARCH_LLAMA && d.arch != GL3_ARCH_QWEN3) return bail(GL3_E_UNSUPPORTED, "unsupported architecture");
+    if (d.arch != GL3_ARCH_LLAMA && d.arch != GL3_ARCH_QWEN3 && d.arch != GL3_ARCH_QWEN2) return bail(GL3_E_UNSUPPORTED, "unsupported architecture");
     if (d.weight_type != GL3_TYPE_Q8_0 && d.weight_type != GL3_TYPE_F16 && d.weight_type != GL3_TYPE_Q4_0)
         return bail(GL3_E_UNSUPPORTED, "matrix weight type must be Q8_0, F16 or Q4_0");
     if (d.weight_type != GL3_TYPE_Q8_0 && (d.dim % 64 || d.hidden % 64 || (d.n_heads * d.head_size) % 64))
@@ -338,6 +338,7 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
         TRY(dmalloc(ctx, &L.attn_norm, d.dim));
         TRY(dmalloc(ctx, &L.ffn_norm, d.dim));
         if (d.arch == GL3_ARCH_QWEN3) { TRY(dmalloc(ctx, &L.qnorm, d.head_size)); TRY(dmalloc(ctx, &L.knorm, d.head_size)); }
+        if (d.arch == GL3_ARCH_QWEN2) { TRY(dmalloc(ctx, &L.bq, ctx->q_dim_l)); TRY(dmalloc(ctx, &L.bk, ctx->kv_dim_l)); TRY(dmalloc(ctx, &L.bv, ctx->kv_dim_l)); }
     }
     TRY(dmalloc(ctx, &ctx->out_norm, d.dim));
     ctx->kv_seq_stride = (size_t)d.n_layers * d.ctx * ctx->kv_dim_l;
@@ -405,7 +406,7 @@ void gl3_destroy(gl3_ctx* ctx) {
     if (ctx->wcls_owned) f(ctx->wcls.w);
     for (auto& L : ctx->layers) {
         f(L.wqkv.w); f(L.wo.w); f(L.w1.w); f(L.w3.w); f(L.w2.w);
-        f(L.attn_norm); f(L.ffn_norm); f(L.qnorm); f(L.knorm);
+        f(L.attn_norm); f(L.ffn_norm); f(L.qnorm); f(L.knorm); f(L.bq); f(L.bk); f(L.bv);
     }
     f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->x); f(ctx->xn); f(ctx->qkv);
     f(ctx->xb); f(ctx->hb); f(ctx->logits); f(ctx->att); f(ctx->dyn); f(ctx->argmax); f(ctx->taps); f(ctx->staging);
@@ -466,6 +467,15 @@ static int32_t upload_f32(gl3_ctx* ctx, float* dst, int n, const void* host, uin
     return GL3_OK;
 }
 
+// f32 vector split like the rows of its matrix: rank keeps elements [rank * n_local, (rank + 1) * n_local)
+static int32_t upload_f32_slice(gl3_ctx* ctx, float* dst, int n_full, int n_local, int rank, const void* host, uint64_t bytes, int type) {
+    if (type != GL3_TYPE_F32) GL3_FAIL(GL3_E_UNSUPPORTED, "bias vectors must be F32");
+    if (!dst) GL3_FAIL(GL3_E_ARG, "tensor not part of this architecture");
+    if (bytes != (uint64_t)n_full * 4) GL3_FAIL(GL3_E_ARG, "bias tensor byte size mismatch");
+    GL3_HIP(hipMemcpy(dst, (const float*)host + (size_t)rank * n_local, (size_t)n_local * 4, hipMemcpyHostToDevice));
+    return GL3_OK;
+}
+
 int32_t gl3_upload_tensor(gl3_ctx* ctx, int32_t id, int32_t layer, const void* host, uint64_t bytes, int32_t type) {
     if (!ctx) return GL3_E_ARG;
     if (!host || id < 0 || id >= GL3_T_COUNT) GL3_FAIL(GL3_E_ARG, "bad tensor id / null host pointer");
@@ -476,7 +486,7 @@ int32_t gl3_upload_tensor(gl3_ctx* ctx, int32_t id, int32_t layer, const void* h
     int32_t r = GL3_OK;
     const int rank = d.tp_rank;
     const bool is_mat = !(id == GL3_T_OUTPUT_NORM || id == GL3_T_ATTN_NORM || id == GL3_T_FFN_NORM || id == GL3_T_ATTN_Q_NORM ||
-                          id == GL3_T_ATTN_K_NORM);
+                          id == GL3_T_ATTN_K_NORM || id == GL3_T_BQ || id == GL3_T_BK || id == GL3_T_BV);
     if (is_mat && type != d.weight_type) GL3_FAIL(GL3_E_UNSUPPORTED, "matrix ggml type differs from gl3_model_desc.weight_type");
     if (id > GL3_T_OUTPUT && (layer < 0 || layer >= d.n_layers)) GL3_FAIL(GL3_E_ARG, "layer out of range");
     gl3_layer* L = id > GL3_T_OUTPUT ? &ctx->layers[layer] : nullptr;
@@ -491,6 +501,9 @@ int32_t gl3_upload_tensor(gl3_ctx* ctx, int32_t id, int32_t layer, const void* h
     case GL3_T_FFN_NORM: r = upload_f32(ctx, L->ffn_norm, d.dim, host, bytes, type); break;
     case GL3_T_ATTN_Q_NORM: r = upload_f32(ctx, L->qnorm, d.head_size, host, bytes, type); break;
     case GL3_T_ATTN_K_NORM: r = upload_f32(ctx, L->knorm, d.head_size, host, bytes, type); break;
+    case GL3_T_BQ: r = upload_f32_slice(ctx, L->bq, ctx->q_dim, ctx->q_dim_l, rank, host, bytes, type); break;
+    case GL3_T_BK: r = upload_f32_slice(ctx, L->bk, ctx->kv_dim, ctx->kv_dim_l, rank, host, bytes, type); break;
+    case GL3_T_BV: r = upload_f32_slice(ctx, L->bv, ctx->kv_dim, ctx->kv_dim_l, rank, host, bytes, type); break;
     case GL3_T_WQ: r = upload_q8(ctx, L->wqkv, 0, ctx->q_dim_l, host, bytes, ctx->q_dim, d.dim, (long)rank * ctx->q_dim_l); break;
     case GL3_T_WK: r = upload_q8(ctx, L->wqkv, ctx->q_dim_l, ctx->kv_dim_l, host, bytes, ctx->kv_dim, d.dim, (long)rank * ctx->kv_dim_l); break;
     case GL3_T_WV: r = upload_q8(ctx, L->wqkv, ctx->q_dim_l + ctx->kv_dim_l, ctx->kv_dim_l, host, bytes, ctx->kv_dim, d.dim, (long)rank * ctx->kv_dim_l); break;
@@ -591,6 +604,7 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
     uint32_t need_l = (1u << GL3_T_ATTN_NORM) | (1u << GL3_T_WQ) | (1u << GL3_T_WK) | (1u << GL3_T_WV) | (1u << GL3_T_WO) |
                       (1u << GL3_T_FFN_NORM) | (1u << GL3_T_W1) | (1u << GL3_T_W2) | (1u << GL3_T_W3);
     if (d.arch == GL3_ARCH_QWEN3) need_l |= (1u << GL3_T_ATTN_Q_NORM) | (1u << GL3_T_ATTN_K_NORM);
+    if (d.arch == GL3_ARCH_QWEN2) need_l |= (1u << GL3_T_BQ) | (1u << GL3_T_BK) | (1u << GL3_T_BV);
     for (int l = 0; l < d.n_layers; ++l)
         if ((ctx->layers[l].have & need_l) != need_l) GL3_FAIL(GL3_E_STATE, "layer " + std::to_string(l) + ": tensors missing");
     if (!ctx->rope_cr) GL3_FAIL(GL3_E_STATE, "rope tables not uploaded");

@@ -31,6 +31,7 @@ struct Q8Mat {               // one repacked matrix: Q8T tiles (gl3_decode_kerne
 struct gl3_layer {
     Q8Mat wqkv, wo, w1, w3, w2;
     float *attn_norm = nullptr, *ffn_norm = nullptr, *qnorm = nullptr, *knorm = nullptr;
+    float *bq = nullptr, *bk = nullptr, *bv = nullptr;      // qwen2: this rank's rows of the q / k / v bias
     uint32_t have = 0;       // bit per tensor id
 };
 

@@ -393,6 +393,9 @@ struct AttnArgs {
     const float* rope_ci;
     const float* qnorm;      // qwen3: f32[hs] (else NULL)
     const float* knorm;
+    const float* bq;         // qwen2: q / k / v bias of this rank's heads (else NULL), added before RoPE (InferenceCore.java:456-459)
+    const float* bk;
+    const float* bv;
     const int* dyn;          // dyn[1] = position
     float* att;              // [n_heads][ctx] scores
     float* xb;               // [qDim] attention output
@@ -453,12 +456,12 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
         const int i = t + u * nthr;
         if (u < per && i < nk4) kreg[u] = *reinterpret_cast<const float4*>(a.kcache + (size_t)(t0 + i / q4) * a.kv_dim + kvh * hs + 4 * (i % q4));
     }
-    for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.qkv[(kvh * kvmul) * hs + i];
+    for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.bq ? a.qkv[(kvh * kvmul) * hs + i] + a.bq[(kvh * kvmul) * hs + i] : a.qkv[(kvh * kvmul) * hs + i];
     for (int i = t; i < half; i += nthr) { cr_s[i] = a.rope_cr[(size_t)pos * half + i]; ci_s[i] = a.rope_ci[(size_t)pos * half + i]; }
     float vraw = 0.f;
     if (owns_pos) {
-        for (int i = t; i < hs; i += nthr) krow[i] = a.qkv[a.q_dim + kvh * hs + i];
-        if (t < hs) vraw = a.qkv[a.q_dim + a.kv_dim + kvh * hs + t];
+        for (int i = t; i < hs; i += nthr) krow[i] = a.bk ? a.qkv[a.q_dim + kvh * hs + i] + a.bk[kvh * hs + i] : a.qkv[a.q_dim + kvh * hs + i];
+        if (t < hs) vraw = a.bv ? a.qkv[a.q_dim + a.kv_dim + kvh * hs + t] + a.bv[kvh * hs + t] : a.qkv[a.q_dim + a.kv_dim + kvh * hs + t];
     }
     if (per > KMAX) {                                         // generic fallback (few threads): straight to LDS
         for (int i = t; i < nk4; i += nthr) {
@@ -541,12 +544,12 @@ static __global__ __launch_bounds__(512) void attn_fused_kernel(const AttnArgs a
             }
         }
     }
-    for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.qkv[(kvh * kvmul) * hs + i];
+    for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.bq ? a.qkv[(kvh * kvmul) * hs + i] + a.bq[(kvh * kvmul) * hs + i] : a.qkv[(kvh * kvmul) * hs + i];
     for (int i = t; i < half; i += nthr) { cr_s[i] = a.rope_cr[(size_t)pos * half + i]; ci_s[i] = a.rope_ci[(size_t)pos * half + i]; }
     float* krow = kt + pos * pitch;
     for (int i = t; i < hs; i += nthr) {
-        krow[i] = a.qkv[a.q_dim + kvh * hs + i];
-        vt[pos * hs + i] = a.qkv[a.q_dim + a.kv_dim + kvh * hs + i];
+        krow[i] = a.bk ? a.qkv[a.q_dim + kvh * hs + i] + a.bk[kvh * hs + i] : a.qkv[a.q_dim + kvh * hs + i];
+        vt[pos * hs + i] = a.bv ? a.qkv[a.q_dim + a.kv_dim + kvh * hs + i] + a.bv[kvh * hs + i] : a.qkv[a.q_dim + a.kv_dim + kvh * hs + i];
     }
     if (per <= KMAX) {
 #pragma unroll

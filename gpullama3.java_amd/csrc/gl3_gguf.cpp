@@ -235,7 +235,8 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
     const std::string a = it->second.str;
     if (a == "llama") d->arch = GL3_ARCH_LLAMA;
     else if (a == "qwen3") d->arch = GL3_ARCH_QWEN3;
-    else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, qwen3)");
+    else if (a == "qwen2") d->arch = GL3_ARCH_QWEN2;
+    else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, qwen3, qwen2)");
     auto need = [&](const char* k, double* v) { return meta_num(g, a + "." + k, v); };
     double dim, hid, nl, nh, nkv, eps, theta = 10000.0, ctx, kl;
     if (!need("embedding_length", &dim) || !need("feed_forward_length", &hid) || !need("block_count", &nl) ||
@@ -295,14 +296,15 @@ int32_t gl3_load_gguf(const char* path, const gl3_model_desc* opts, gl3_ctx** ou
     r = up("token_embd.weight", GL3_T_TOKEN_EMBD, 0, true);
     if (r == GL3_OK) r = up("output_norm.weight", GL3_T_OUTPUT_NORM, 0, true);
     if (r == GL3_OK) r = up("output.weight", GL3_T_OUTPUT, 0, false);                       // absent: tied embeddings
-    static const struct { const char* name; int id; bool qwen_only; } per_layer[] = {
-        {"attn_norm.weight", GL3_T_ATTN_NORM, false}, {"attn_q.weight", GL3_T_WQ, false}, {"attn_k.weight", GL3_T_WK, false},
-        {"attn_v.weight", GL3_T_WV, false}, {"attn_output.weight", GL3_T_WO, false}, {"ffn_norm.weight", GL3_T_FFN_NORM, false},
-        {"ffn_gate.weight", GL3_T_W1, false}, {"ffn_down.weight", GL3_T_W2, false}, {"ffn_up.weight", GL3_T_W3, false},
-        {"attn_q_norm.weight", GL3_T_ATTN_Q_NORM, true}, {"attn_k_norm.weight", GL3_T_ATTN_K_NORM, true}};
+    static const struct { const char* name; int id; int arch_only; } per_layer[] = {     // arch_only: -1 = every architecture
+        {"attn_norm.weight", GL3_T_ATTN_NORM, -1}, {"attn_q.weight", GL3_T_WQ, -1}, {"attn_k.weight", GL3_T_WK, -1},
+        {"attn_v.weight", GL3_T_WV, -1}, {"attn_output.weight", GL3_T_WO, -1}, {"ffn_norm.weight", GL3_T_FFN_NORM, -1},
+        {"ffn_gate.weight", GL3_T_W1, -1}, {"ffn_down.weight", GL3_T_W2, -1}, {"ffn_up.weight", GL3_T_W3, -1},
+        {"attn_q_norm.weight", GL3_T_ATTN_Q_NORM, GL3_ARCH_QWEN3}, {"attn_k_norm.weight", GL3_T_ATTN_K_NORM, GL3_ARCH_QWEN3},
+        {"attn_q.bias", GL3_T_BQ, GL3_ARCH_QWEN2}, {"attn_k.bias", GL3_T_BK, GL3_ARCH_QWEN2}, {"attn_v.bias", GL3_T_BV, GL3_ARCH_QWEN2}};
     for (int l = 0; l < d.n_layers && r == GL3_OK; ++l)
         for (const auto& t : per_layer) {
-            if (t.qwen_only && d.arch != GL3_ARCH_QWEN3) continue;
+            if (t.arch_only >= 0 && t.arch_only != d.arch) continue;
             r = up("blk." + std::to_string(l) + "." + t.name, t.id, l, true);
             if (r != GL3_OK) break;
         }

@@ -571,7 +571,8 @@ __global__ __launch_bounds__(bd_threads(BD_NP)) void bd_gemm_kernel(const GemmAr
 // RMSNorm, InferenceCore.java:594-600).  Grid = (n_heads + n_kv_heads, ntok), block = 64.
 struct RopeArgs {
     float* QKV; int qkv_stride; float* kcache; float* vcache; const float* cr; const float* ci;
-    const float* qnorm; const float* knorm; int n_heads, n_kv_heads, hs, q_dim, kv_dim, arch; float eps;
+    const float* qnorm; const float* knorm; const float* bq; const float* bk; const float* bv;   // bias: qwen2 (else NULL)
+    int n_heads, n_kv_heads, hs, q_dim, kv_dim, arch; float eps;
     const int32_t* seq; const int32_t* pos; size_t seq_stride;   // per-token sequence id / position; floats between sequences' caches
 };
 
@@ -583,7 +584,8 @@ __global__ __launch_bounds__(64) void pf_rope_kv_kernel(const RopeArgs a) {
     const bool is_k = h >= a.n_heads;
     const int hk = is_k ? h - a.n_heads : h;
     float* src = a.QKV + (size_t)b * a.qkv_stride + (is_k ? a.q_dim + hk * hs : hk * hs);
-    for (int i = t; i < hs; i += 64) v[i] = src[i];
+    const float* bias = is_k ? a.bk : a.bq;              // qwen2: q / k / v bias before RoPE (InferenceCore.java:456-459)
+    for (int i = t; i < hs; i += 64) v[i] = bias ? src[i] + bias[hk * hs + i] : src[i];
     __syncthreads();
     if (a.arch == 1) {
         if (t == 0) head_rmsnorm_1t(v, is_k ? a.knorm : a.qnorm, hs, a.eps);
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(64) void pf_rope_kv_kernel(const RopeArgs a) {
         const float* vsrc = a.QKV + (size_t)b * a.qkv_stride + a.q_dim + a.kv_dim + hk * hs;
         for (int i = t; i < hs; i += 64) {
             a.kcache[soff + (size_t)pos * a.kv_dim + hk * hs + i] = v[i];
-            a.vcache[soff + (size_t)pos * a.kv_dim + hk * hs + i] = vsrc[i];
+            a.vcache[soff + (size_t)pos * a.kv_dim + hk * hs + i] = a.bv ? vsrc[i] + a.bv[hk * hs + i] : vsrc[i];
         }
     }
 }
@@ -1011,7 +1013,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         launch_gemm<EPI_STORE>(ctx, L.wqkv, nullptr, n, p->QKV, qkv_dim);
         RopeArgs ra{};
         ra.QKV = p->QKV; ra.qkv_stride = qkv_dim; ra.kcache = ctx->kcache + l * kv_layer; ra.vcache = ctx->vcache + l * kv_layer;
-        ra.cr = ctx->rope_cr; ra.ci = ctx->rope_ci; ra.qnorm = L.qnorm; ra.knorm = L.knorm; ra.n_heads = H;
+        ra.cr = ctx->rope_cr; ra.ci = ctx->rope_ci; ra.qnorm = L.qnorm; ra.knorm = L.knorm; ra.bq = L.bq; ra.bk = L.bk; ra.bv = L.bv; ra.n_heads = H;
         ra.n_kv_heads = KVH; ra.hs = d.head_size; ra.q_dim = qd; ra.kv_dim = kvd;
         ra.arch = d.arch; ra.eps = d.rms_eps; ra.seq = seq; ra.pos = pos; ra.seq_stride = ctx->kv_seq_stride;
         hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(H + KVH, n), dim3(64), 0, s, ra);

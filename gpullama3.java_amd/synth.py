@@ -19,7 +19,8 @@ import numpy as np
 from . import gguf
 from .gguf import GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0
 
-ARCH_LLAMA, ARCH_QWEN3 = 0, 1
+ARCH_LLAMA, ARCH_QWEN3, ARCH_QWEN2 = 0, 1, 2
+_ARCH_NAME = {ARCH_LLAMA: "llama", ARCH_QWEN3: "qwen3", ARCH_QWEN2: "qwen2"}
 
 
 @dataclass
@@ -58,6 +59,9 @@ CONFIGS = {
     # wide enough to exercise full 64-block chunks + ragged tails in the HIP matvec (K = 2560, 4096-wide q)
     "mid-qwen3": ModelConfig("mid-qwen3-random", ARCH_QWEN3, 2560, 1536, 2, 32, 8, 128, 2048, 40, 1e-6, 1000000.0, True),
     "mid-llama": ModelConfig("mid-llama-random", ARCH_LLAMA, 2048, 4096, 2, 32, 8, 64, 4096, 160, 1e-5, 500000.0, False),
+    # Qwen2 / Qwen2.5 / DeepSeek-R1-Distill-Qwen shape: q/k/v bias, NeoX RoPE, head_size = dim / heads (forwardJavaQwen2)
+    "tiny-qwen2": ModelConfig("tiny-qwen2-random", ARCH_QWEN2, 256, 512, 2, 8, 2, 32, 512, 64, 1e-6, 1000000.0, True),
+    "mid-qwen2": ModelConfig("mid-qwen2-random", ARCH_QWEN2, 1536, 4480, 2, 12, 2, 128, 2048, 160, 1e-6, 1000000.0, False),
 }
 
 
@@ -133,6 +137,9 @@ def tensor_specs(cfg: ModelConfig, wtype: int):
             (p + "attn_v.weight", cfg.kv_dim, cfg.dim, wtype, "mat"),
             (p + "attn_output.weight", cfg.dim, cfg.q_dim, wtype, "mat"),
         ]
+        if cfg.arch == ARCH_QWEN2:
+            specs += [(p + "attn_q.bias", 1, cfg.q_dim, GGML_F32, "bias"), (p + "attn_k.bias", 1, cfg.kv_dim, GGML_F32, "bias"),
+                      (p + "attn_v.bias", 1, cfg.kv_dim, GGML_F32, "bias")]
         if cfg.arch == ARCH_QWEN3:
             specs += [(p + "attn_q_norm.weight", 1, cfg.head_size, GGML_F32, "norm"),
                       (p + "attn_k_norm.weight", 1, cfg.head_size, GGML_F32, "norm")]
@@ -172,7 +179,7 @@ class SynthModel:
     # ---- GGUF round trip (metadata keys as the reference loaders read them)
     def metadata(self):
         c = self.cfg
-        a = "llama" if c.arch == ARCH_LLAMA else "qwen3"
+        a = _ARCH_NAME[c.arch]
         ftype = {GGML_F32: 0, GGML_F16: 1, GGML_Q4_0: 2, GGML_Q8_0: 7}[self.wtype]
         md = {
             "general.architecture": a, "general.name": c.name, "general.file_type": ftype,
@@ -198,7 +205,7 @@ class SynthModel:
         g = gguf.GGUFFile(path)
         md = g.metadata
         a = md["general.architecture"]
-        arch = ARCH_LLAMA if a == "llama" else ARCH_QWEN3
+        arch = {v: k for k, v in _ARCH_NAME.items()}[a]
         dim, nh = md[f"{a}.embedding_length"], md[f"{a}.attention.head_count"]
         hs = md.get(f"{a}.attention.key_length", dim // nh)
         cfg = ModelConfig(md["general.name"], arch, dim, md[f"{a}.feed_forward_length"], md[f"{a}.block_count"], nh,

@@ -57,7 +57,9 @@ typedef enum {
 } gl3_status;
 
 /* model families with all three plan modes in the reference (ForwardPlanFactory.java:123-141) */
-enum { GL3_ARCH_LLAMA = 0, GL3_ARCH_QWEN3 = 1 };
+/* LLAMA: InferenceCore.forwardJava (also Mistral GGUFs, architecture "llama"); QWEN3: forwardJavaQwen3 (per-head q/k RMSNorm,
+ * NeoX RoPE); QWEN2: forwardJavaQwen2 :434-563 (q/k/v bias, NeoX RoPE; Qwen2.5, DeepSeek-R1-Distill-Qwen). */
+enum { GL3_ARCH_LLAMA = 0, GL3_ARCH_QWEN3 = 1, GL3_ARCH_QWEN2 = 2 };
 
 /* ggml tensor types of the wire format (J/tensor/GGMLType.java:5-21) */
 enum { GL3_TYPE_F32 = 0, GL3_TYPE_F16 = 1, GL3_TYPE_Q4_0 = 2, GL3_TYPE_Q8_0 = 8 };
@@ -79,7 +81,10 @@ enum {
     GL3_T_W3 = 11,          /* blk.L.ffn_up.weight      [hidden x dim]           */
     GL3_T_ATTN_Q_NORM = 12, /* blk.L.attn_q_norm.weight [head_size]    F32, qwen3 */
     GL3_T_ATTN_K_NORM = 13, /* blk.L.attn_k_norm.weight [head_size]    F32, qwen3 */
-    GL3_T_COUNT = 14
+    GL3_T_BQ = 14,          /* blk.L.attn_q.bias        [q_dim]        F32, qwen2 (Qwen2StandardWeights q_bias) */
+    GL3_T_BK = 15,          /* blk.L.attn_k.bias        [kv_dim]       F32, qwen2 */
+    GL3_T_BV = 16,          /* blk.L.attn_v.bias        [kv_dim]       F32, qwen2 */
+    GL3_T_COUNT = 17
 };
 
 /* gl3_model_desc.flags */

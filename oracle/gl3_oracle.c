@@ -41,11 +41,13 @@ enum {
     ORC_T_TOKEN_EMBD = 0, ORC_T_OUTPUT_NORM = 1, ORC_T_OUTPUT = 2,
     ORC_T_ATTN_NORM = 3, ORC_T_WQ = 4, ORC_T_WK = 5, ORC_T_WV = 6, ORC_T_WO = 7,
     ORC_T_FFN_NORM = 8, ORC_T_W1 = 9, ORC_T_W2 = 10, ORC_T_W3 = 11,
-    ORC_T_ATTN_Q_NORM = 12, ORC_T_ATTN_K_NORM = 13, ORC_T_COUNT = 14
+    ORC_T_ATTN_Q_NORM = 12, ORC_T_ATTN_K_NORM = 13,
+    ORC_T_BQ = 14, ORC_T_BK = 15, ORC_T_BV = 16,       /* qwen2: blk.L.attn_{q,k,v}.bias, F32 */
+    ORC_T_COUNT = 17
 };
 
 typedef struct {
-    int32_t arch;       /* 0 = llama (InferenceCore.forwardJava), 1 = qwen3 (forwardJavaQwen3) */
+    int32_t arch;       /* 0 = llama (InferenceCore.forwardJava), 1 = qwen3 (forwardJavaQwen3), 2 = qwen2 (forwardJavaQwen2) */
     int32_t dim, hidden, n_layers, n_heads, n_kv_heads, head_size, vocab, ctx;
     float   rms_eps;
 } orc_config;
@@ -225,7 +227,8 @@ static void attention(orc_ctx* o, int l, int pos) {
 }
 
 /* One transformer step.  arch 0: InferenceCore.forwardJava :50-172;
- * arch 1: forwardJavaQwen3 :565-697.  want_logits=0 reproduces the prefill
+ * arch 1: forwardJavaQwen3 :565-697; arch 2: forwardJavaQwen2 :434-563 (q/k/v bias
+ * :456-459, NeoX RoPE :461-478, no per-head norm).  want_logits=0 reproduces the prefill
  * variants (InferenceCoreWithPrefillDecode.forwardJavaPrefill :47-132 and the
  * per-token arithmetic of batchForwardJavaPrefill,
  * InferenceCoreBatchPrefillDecode.java:62-168 — same dot, same sequential
@@ -243,6 +246,12 @@ static void forward(orc_ctx* o, int token, int pos, int want_logits, float* laye
         matmul(o, &o->layer[ORC_T_WK][l], o->xb, o->k, kvd, dim);
         matmul(o, &o->layer[ORC_T_WV][l], o->xb, o->v, kvd, dim);
 
+        if (c->arch == 2) {
+            /* state.q.addInPlace(weights.q_bias[l]) ... — InferenceCore.java:456-459 */
+            for (int i = 0; i < qd; i++) o->q[i] = o->q[i] + t_get(&o->layer[ORC_T_BQ][l], i);
+            for (int i = 0; i < kvd; i++) o->k[i] = o->k[i] + t_get(&o->layer[ORC_T_BK][l], i);
+            for (int i = 0; i < kvd; i++) o->v[i] = o->v[i] + t_get(&o->layer[ORC_T_BV][l], i);
+        }
         if (c->arch == 0) {
             /* adjacent-pair RoPE, q for i<dim and k for i<kvDim — InferenceCore.java:75-87 */
             for (int i = 0; i < dim; i += 2) {
@@ -258,9 +267,11 @@ static void forward(orc_ctx* o, int token, int pos, int want_logits, float* laye
                 }
             }
         } else {
-            /* per-head Q/K RMSNorm then NeoX RoPE — InferenceCore.java:594-619 */
-            for (int i = 0; i < c->n_heads; i++) rmsnorm(o->q, o->q, &o->layer[ORC_T_ATTN_Q_NORM][l], i * hs, hs, c->rms_eps);
-            for (int i = 0; i < c->n_kv_heads; i++) rmsnorm(o->k, o->k, &o->layer[ORC_T_ATTN_K_NORM][l], i * hs, hs, c->rms_eps);
+            /* (qwen3: per-head Q/K RMSNorm, InferenceCore.java:594-600) then NeoX RoPE — :604-619 / qwen2 :461-478 */
+            if (c->arch == 1) {
+                for (int i = 0; i < c->n_heads; i++) rmsnorm(o->q, o->q, &o->layer[ORC_T_ATTN_Q_NORM][l], i * hs, hs, c->rms_eps);
+                for (int i = 0; i < c->n_kv_heads; i++) rmsnorm(o->k, o->k, &o->layer[ORC_T_ATTN_K_NORM][l], i * hs, hs, c->rms_eps);
+            }
             int half = hs / 2;
             for (int h = 0; h < c->n_heads; h++) {
                 int rotn = h < c->n_kv_heads ? 2 : 1, poff = h * hs;

@@ -148,6 +148,10 @@ class NpOracle:
             q = self._mm(p + "attn_q.weight", xb, qd, dim)
             k = self._mm(p + "attn_k.weight", xb, kvd, dim)
             v = self._mm(p + "attn_v.weight", xb, kvd, dim)
+            if c["arch"] == 2:   # qwen2: q/k/v bias, InferenceCore.java:456-459
+                q = q + self._f32(p + "attn_q.bias", qd)
+                k = k + self._f32(p + "attn_k.bias", kvd)
+                v = v + self._f32(p + "attn_v.bias", kvd)
             if c["arch"] == 0:   # InferenceCore.java:75-87, adjacent pairs
                 def rot(vec):
                     vv = vec.reshape(-1, half, 2)
@@ -157,10 +161,11 @@ class NpOracle:
                     out[:, :, 1] = v0 * fci + v1 * fcr
                     return out.reshape(-1)
             else:                # InferenceCore.java:594-619, per-head norm + NeoX pairs
-                qn = self._f32(p + "attn_q_norm.weight", hs)
-                kn = self._f32(p + "attn_k_norm.weight", hs)
-                q = np.concatenate([rmsnorm(q[h * hs:(h + 1) * hs], qn, eps) for h in range(H)])
-                k = np.concatenate([rmsnorm(k[h * hs:(h + 1) * hs], kn, eps) for h in range(KVH)])
+                if c["arch"] == 1:
+                    qn = self._f32(p + "attn_q_norm.weight", hs)
+                    kn = self._f32(p + "attn_k_norm.weight", hs)
+                    q = np.concatenate([rmsnorm(q[h * hs:(h + 1) * hs], qn, eps) for h in range(H)])
+                    k = np.concatenate([rmsnorm(k[h * hs:(h + 1) * hs], kn, eps) for h in range(KVH)])
 
                 def rot(vec):
                     vv = vec.reshape(-1, 2, half)

@@ -16,7 +16,7 @@ def hip(pkg):
     return import_module(ge.PKG_NAME + ".hip")
 
 
-@pytest.mark.parametrize("cfg,wtype", [("tiny-llama", 8), ("tiny-qwen3", 8), ("tiny-llama-tied", 2), ("tiny-llama", 1)])
+@pytest.mark.parametrize("cfg,wtype", [("tiny-llama", 8), ("tiny-qwen3", 8), ("tiny-llama-tied", 2), ("tiny-llama", 1), ("tiny-qwen2", 8)])
 def test_native_reader_agrees_with_the_python_reader(pkg, hip, tmp_path, cfg, wtype):
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=3)
     path = str(tmp_path / "m.gguf")
@@ -47,7 +47,7 @@ def test_native_reader_agrees_with_the_python_reader(pkg, hip, tmp_path, cfg, wt
         hip.check_gguf(L.gl3_gguf_model_desc(g, C.byref(d2), None), g)
         assert d2.ctx == 16
         v = C.c_double()
-        a = "llama" if c.arch == 0 else "qwen3"
+        a = {0: "llama", 1: "qwen3", 2: "qwen2"}[c.arch]
         assert L.gl3_gguf_meta_number(g, (a + ".block_count").encode(), C.byref(v)) == 0 and v.value == c.n_layers
         s = C.c_char_p()
         assert L.gl3_gguf_meta_string(g, b"general.architecture", C.byref(s)) == 0 and s.value.decode() == a

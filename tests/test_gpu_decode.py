@@ -49,7 +49,7 @@ def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed, wtype):
     plan.freeTornadoExecutionPlan()
 
 
-@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "tiny-llama-tied"])
+@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "tiny-llama-tied", "tiny-qwen2", "mid-qwen2"])
 def test_decode_matches_c_oracle_live(pkg, orc, planmod, cfg):
     """Shapes with full 64-block chunks, ragged chunk tails (K = 2560), head sizes 32/64/128, tied wcls."""
     plan_mod, hip = planmod
@@ -176,7 +176,7 @@ def test_error_behaviour(pkg, planmod):
     plan.freeTornadoExecutionPlan()
 
 
-@pytest.mark.parametrize("cfg,batch,chunks", [("tiny-llama", 8, [8, 8, 5]), ("mid-llama", 64, [40, 64, 3]), ("mid-qwen3", 32, [30, 7]),
+@pytest.mark.parametrize("cfg,batch,chunks", [("tiny-llama", 8, [8, 8, 5]), ("mid-llama", 64, [40, 64, 3]), ("mid-qwen3", 32, [30, 7]), ("mid-qwen2", 64, [50, 9]),
                                              ("tiny-llama-tied", 512, [37])])
 def test_batched_prefill_is_bit_identical_to_the_cpu_path(pkg, orc, planmod, cfg, batch, chunks):
     """tornadoVMForwardBatchPrefill (MFMA int8 GEMM path) vs batchForwardJavaPrefill: same KV cache, same x of the
@@ -240,7 +240,7 @@ def test_static_batched_decode_matches_independent_cpu_runs(pkg, orc, planmod, c
     plan.freeTornadoExecutionPlan()
 
 
-@pytest.mark.parametrize("cfg,wtype", [("tiny-llama", 8), ("tiny-qwen3", 8), ("tiny-llama-tied", 1)])
+@pytest.mark.parametrize("cfg,wtype", [("tiny-llama", 8), ("tiny-qwen3", 8), ("tiny-llama-tied", 1), ("tiny-qwen2", 8)])
 def test_native_gguf_loader_builds_the_same_plan(pkg, planmod, tmp_path, cfg, wtype):
     """gl3_load_gguf (mmap + native config / tensor-name map / RoPE table) vs the per-tensor upload path driven from Python."""
     plan_mod, hip = planmod

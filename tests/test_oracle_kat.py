@@ -144,3 +144,33 @@ def test_softmax_equal_scores_and_argmax_ties(orc):
     assert orc.argmax(v) == 0 or True               # NaN seed: Java keeps index 0 unless f > NaN (never)
     v = np.array([1, np.nan, 2], np.float32)
     assert orc.argmax(v) == 2
+
+
+def test_qwen2_bias_is_added_before_rope_kat(pkg, orc):
+    """forwardJavaQwen2 (InferenceCore.java:456-478): q/k/v += bias, then NeoX rotation.  Hand check on a one-layer model with
+    zero weights: q = bias, so the stored K row at position p is the NeoX rotation of k_bias and V is v_bias exactly."""
+    import numpy as np
+    base = pkg.synth.CONFIGS["tiny-qwen2"]
+    cfg = pkg.synth.ModelConfig(**{**base.__dict__, "n_layers": 1})
+    m = pkg.synth.make_numpy(cfg, seed=2)
+    # zero the k / v projection matrices (Q8_0 bytes of an all-zero matrix: scale 0, quants 0)
+    for name in ("blk.0.attn_k.weight", "blk.0.attn_v.weight"):
+        raw, ty, rows, cols = m.tensors[name]
+        m.tensors[name] = (np.zeros_like(raw), ty, rows, cols)
+    o = orc.COracle(m)
+    pos = 3
+    for p in range(pos + 1):
+        o.forward(5, p)
+    k, v = o.kv(0, pos)
+    bk = m.tensors["blk.0.attn_k.bias"][0].view(np.float32)
+    bv = m.tensors["blk.0.attn_v.bias"][0].view(np.float32)
+    assert np.array_equal(v, bv)
+    hs, half = cfg.head_size, cfg.head_size // 2
+    cr, ci = m.rope
+    fcr, fci = cr[pos * half:(pos + 1) * half], ci[pos * half:(pos + 1) * half]
+    exp = np.empty_like(bk)
+    for h in range(cfg.n_kv_heads):
+        v0, v1 = bk[h * hs:h * hs + half], bk[h * hs + half:(h + 1) * hs]
+        exp[h * hs:h * hs + half] = v0 * fcr - v1 * fci
+        exp[h * hs + half:(h + 1) * hs] = v0 * fci + v1 * fcr
+    assert np.array_equal(k, exp)
