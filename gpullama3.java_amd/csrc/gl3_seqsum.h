@@ -136,7 +136,7 @@ struct SubBarrier {
         target += nwaves;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {}     // busy poll: an s_sleep(1) quantum is 64 cycles
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 };
