@@ -23,6 +23,7 @@ CASES = [  # (fixture, config, ggml type, seed, prompt tokens, greedy steps)
     ("tiny_llama_f16", "tiny-llama", 1, 7, 4, 8),
     ("tiny_llama_tied_q4_0", "tiny-llama-tied", 2, 11, 4, 8),
     ("tiny_qwen3_q8_0", "tiny-qwen3", 8, 5, 6, 24),
+    ("tiny_qwen2_q8_0", "tiny-qwen2", 8, 13, 5, 12),
 ]
 
 
@@ -45,7 +46,10 @@ def run_case(pkg, cfg_name, wtype, seed, n_prompt, n_greedy):
 
 if __name__ == "__main__":
     pkg = ge.load_package()
+    only = sys.argv[1:]
     for fx, cfg_name, wt, seed, npmt, ng in CASES:
+        if only and fx not in only:
+            continue
         out = run_case(pkg, cfg_name, wt, seed, npmt, ng)
         np.savez_compressed(os.path.join(os.path.dirname(__file__), fx + ".npz"), **out)
         print(fx, out["tokens"].tolist())

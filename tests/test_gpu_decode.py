@@ -29,7 +29,8 @@ def planmod():
 
 
 @pytest.mark.parametrize("fx,cfg,seed,wtype", [("tiny_llama_q8_0", "tiny-llama", 7, 8), ("tiny_qwen3_q8_0", "tiny-qwen3", 5, 8),
-                                               ("tiny_llama_f16", "tiny-llama", 7, 1), ("tiny_llama_tied_q4_0", "tiny-llama-tied", 11, 2)])
+                                               ("tiny_llama_f16", "tiny-llama", 7, 1), ("tiny_llama_tied_q4_0", "tiny-llama-tied", 11, 2),
+                                               ("tiny_qwen2_q8_0", "tiny-qwen2", 13, 8)])
 def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed, wtype):
     plan_mod, hip = planmod
     g = np.load(os.path.join(GOLD, fx + ".npz"))

@@ -9,7 +9,8 @@ from oracle import oracle_np
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = [("tiny_llama_q8_0", "tiny-llama", 8, 7), ("tiny_llama_f16", "tiny-llama", 1, 7),
-         ("tiny_llama_tied_q4_0", "tiny-llama-tied", 2, 11), ("tiny_qwen3_q8_0", "tiny-qwen3", 8, 5)]
+         ("tiny_llama_tied_q4_0", "tiny-llama-tied", 2, 11), ("tiny_qwen3_q8_0", "tiny-qwen3", 8, 5),
+         ("tiny_qwen2_q8_0", "tiny-qwen2", 8, 13)]
 
 
 @pytest.mark.parametrize("fx,cfg,wt,seed", CASES)
