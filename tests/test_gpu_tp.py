@@ -41,7 +41,7 @@ def test_row_split_ranks_are_bit_identical_to_the_oracle(pkg, orc, planmod, cfg,
 
     th = [threading.Thread(target=rank_main, args=(r,)) for r in range(tp)]
     [t.start() for t in th]
-    [t.join(timeout=120) for t in th]
+    [t.join(timeout=900) for t in th]
     assert all(e is None for e in err), err
     assert not any(t.is_alive() for t in th)
     hip.lib().gl3_local_group_destroy(grp)
@@ -91,7 +91,7 @@ def test_batched_prefill_under_row_split(pkg, orc, planmod, cfg, tp, chunks):
 
     th = [threading.Thread(target=rank_main, args=(r,)) for r in range(tp)]
     [t.start() for t in th]
-    [t.join(timeout=180) for t in th]
+    [t.join(timeout=900) for t in th]
     assert all(e is None for e in err), err
     assert not any(t.is_alive() for t in th)
     hip.lib().gl3_local_group_destroy(grp)
