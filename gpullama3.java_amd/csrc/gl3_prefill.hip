@@ -1,4 +1,5 @@
-// gl3_prefill.hip — batched prefill (gl3_forward_prefill with max_batch > 1).
+// gl3_prefill.hip — batched prefill (gl3_forward_prefill with max_batch > 1) and static-batched decode
+// (gl3_forward_decode_batch); tensor-parallel ranks keep gathered activations rank-chunked (see `chunked`).
 //
 // Replaces the reference's batched-prefill task graphs
 //   J/tornadovm/layers/type/q8_0/prefill/LlamaQ8_0LayersBatchPrefillMMA.java:84-219 (tensor-core path, CUDA only) and
@@ -20,12 +21,12 @@ using namespace gl3;
 struct gl3_prefill_state {
     int max_batch = 0;
     int32_t* tokens = nullptr;          // [M]
-    float* X = nullptr;                 // [M][dim] residual stream
+    float* X = nullptr;                 // [M][dim] residual stream (rank-chunked [tp][n][dim/tp] under tensor parallelism)
     uint8_t* XQ = nullptr;              // [M][maxk] int8 activations
     float* XS = nullptr;                // [M][maxk/32] activation scales
     float* QKV = nullptr;               // [M][q_dim + 2 kv_dim]
-    float* AO = nullptr;                // [M][q_dim] attention output
-    float* HB = nullptr;                // [M][hidden]
+    float* AO = nullptr;                // [M][q_dim] attention output (rank-chunked)
+    float* HB = nullptr;                // [M][hidden] (rank-chunked)
     float* ATT = nullptr;               // [M][n_heads][ctx] scores
     int32_t* seqpos = nullptr;          // [2][M]: sequence id, position of every token of the step
     float* LOGITS = nullptr;            // [rows][vocab], grown on demand (batched decode)
