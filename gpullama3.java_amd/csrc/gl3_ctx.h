@@ -123,7 +123,7 @@ struct gl3_ctx {
 
 // gl3_api.hip: in-place all-gather of buf = [tp][count_per_rank] over the plan's transport (RCCL or the local test group);
 // which = GB_* id of the buffer (the local transport resolves the peers' pointers through gl3_gather_buf)
-enum { GB_XB = 0, GB_X = 1, GB_HB = 2, GB_LOGITS = 3, GB_PF_X = 4, GB_PF_AO = 5, GB_PF_HB = 6 };
+enum { GB_XB = 0, GB_X = 1, GB_HB = 2, GB_LOGITS = 3, GB_PF_X = 4, GB_PF_AO = 5, GB_PF_HB = 6, GB_PF_LOGITS = 7 };
 float* gl3_gather_buf(gl3_ctx* c, int which);
 int32_t gl3_all_gather(gl3_ctx* ctx, int which, size_t count_per_rank);
 

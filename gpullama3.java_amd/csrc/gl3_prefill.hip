@@ -875,15 +875,15 @@ __global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, in
 }
 
 // Greedy id per sequence: first index of the maximum of each logits row (FloatTensor.argmax :138-151).
-__global__ __launch_bounds__(1024) void pf_argmax_rows_kernel(const float* __restrict__ logits, int n, int32_t* __restrict__ out) {
+// logits: rank-chunked [tp][rows][n / tp] (cc = n / tp; tp = 1: plain rows)
+__global__ __launch_bounds__(1024) void pf_argmax_rows_kernel(const float* __restrict__ logits, int n, int32_t* __restrict__ out, int cc) {
     __shared__ float bv[16];
     __shared__ int bi[16];
-    const float* v = logits + (size_t)blockIdx.x * n;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, row = blockIdx.x, nrows = gridDim.x;
     float best = -INFINITY;
     int idx = 0x7FFFFFFF;
     for (int i = t; i < n; i += 1024) {
-        const float f = v[i];
+        const float f = logits[chunked(row, i, cc, nrows)];
         if (f > best || (f == best && i < idx)) { best = f; idx = i; }
     }
     for (int m = 32; m >= 1; m >>= 1) {
@@ -1066,7 +1066,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
 
 float* gl3_prefill_buf(gl3_ctx* ctx, int which) {
     gl3_prefill_state* p = ctx->pf;
-    return which == GB_PF_X ? p->X : which == GB_PF_AO ? p->AO : p->HB;
+    return which == GB_PF_X ? p->X : which == GB_PF_AO ? p->AO : which == GB_PF_HB ? p->HB : p->LOGITS;
 }
 
 // x of token b from the rank-chunked X into the decode path's plain ctx->x (parity tap gl3_get_x)
@@ -1105,7 +1105,6 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
                              float* logits_out, int32_t* argmax_out) {
     gl3_prefill_state* p = ctx->pf;
     const gl3_model_desc& d = ctx->d;
-    if (d.tp_size > 1) GL3_FAIL(GL3_E_UNSUPPORTED, "batched decode under tensor parallelism is not implemented");
     GL3_HIP(hipSetDevice(d.device));
     if (p->logits_rows < n) {
         if (p->LOGITS) hipFree(p->LOGITS);
@@ -1120,13 +1119,20 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
     if ((r = pf_layers(ctx, n, max_pos, -1)) != GL3_OK) return r;
     hipStream_t s = ctx->stream;
     const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
-    hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq, s, p->X, d.dim, d.dim, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk);
-    launch_gemm<EPI_STORE>(ctx, ctx->wcls, nullptr, n, p->LOGITS, d.vocab);
+    hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk);
+    // vocab rows are split across ranks: this rank's logits are the chunk [n][vocab / tp] of the rank-chunked buffer
+    const int vl = ctx->vocab_l;
+    launch_gemm<EPI_STORE>(ctx, ctx->wcls, nullptr, n, p->LOGITS + (size_t)d.tp_rank * n * vl, vl);
+    if ((r = gl3_all_gather(ctx, GB_PF_LOGITS, (size_t)n * vl)) != GL3_OK) return r;
     if (argmax_out) {
-        hipLaunchKernelGGL(pf_argmax_rows_kernel, dim3(n), dim3(1024), 0, s, p->LOGITS, d.vocab, p->amax);
+        hipLaunchKernelGGL(pf_argmax_rows_kernel, dim3(n), dim3(1024), 0, s, p->LOGITS, d.vocab, p->amax, vl);
         GL3_HIP(hipMemcpyAsync(argmax_out, p->amax, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     }
-    if (logits_out) GL3_HIP(hipMemcpyAsync(logits_out, p->LOGITS, (size_t)n * d.vocab * 4, hipMemcpyDeviceToHost, s));
+    if (logits_out) {      // un-chunk on the way out: [tp][n][vl] -> [n][vocab]
+        for (int c = 0; c < d.tp_size; ++c)
+            GL3_HIP(hipMemcpy2DAsync(logits_out + (size_t)c * vl, (size_t)d.vocab * 4, p->LOGITS + (size_t)c * n * vl, (size_t)vl * 4, (size_t)vl * 4, n,
+                                     hipMemcpyDeviceToHost, s));
+    }
     GL3_HIP(hipGetLastError());
     GL3_HIP(hipStreamSynchronize(s));
     return GL3_OK;

@@ -39,7 +39,7 @@ def test_row_split_ranks_are_bit_identical_to_the_oracle(pkg, orc, planmod, cfg,
         except Exception as e:   # noqa: BLE001
             err[r] = e
 
-    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(tp)]
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(tp)]
     [t.start() for t in th]
     [t.join(timeout=900) for t in th]
     assert all(e is None for e in err), err
@@ -89,7 +89,7 @@ def test_batched_prefill_under_row_split(pkg, orc, planmod, cfg, tp, chunks):
         except Exception as e:   # noqa: BLE001
             err[r] = e
 
-    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(tp)]
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(tp)]
     [t.start() for t in th]
     [t.join(timeout=900) for t in th]
     assert all(e is None for e in err), err
@@ -103,3 +103,43 @@ def test_batched_prefill_under_row_split(pkg, orc, planmod, cfg, tp, chunks):
                 ko, vo = o.kv(l, p)
                 k, v = kvs[r][i]; i += 1
                 assert np.array_equal(k, ko[r * kvl:(r + 1) * kvl]) and np.array_equal(v, vo[r * kvl:(r + 1) * kvl]), (r, l, p)
+
+
+def test_static_batched_decode_under_row_split(pkg, orc, planmod):
+    """BASELINE configs[4] on tensor-parallel ranks: vocab rows are split, the per-rank logits chunks are gathered in place and
+    un-chunked on the way to the host; logits and greedy ids of every sequence equal the oracle's on every rank."""
+    plan_mod, hip = planmod
+    tp, nseq, steps = 2, 3, 3
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS["mid-llama"], seed=43)
+    toks = np.asarray(pkg.javarand.bench_tokens(m.cfg.vocab, nseq * steps), np.int32).reshape(steps, nseq)
+    ref = []
+    for s in range(nseq):
+        o = orc.COracle(m)
+        ref.append([o.forward(int(toks[i, s]), i) for i in range(steps)])
+    grp = plan_mod.make_local_group(tp)
+    out, err = [None] * tp, [None] * tp
+
+    def rank_main(r):
+        try:
+            plan = plan_mod.HipMasterPlan(m, prefill_batch_size=8, n_seqs=nseq, tp_rank=r, tp_size=tp, local_group=grp)
+            res = []
+            for i in range(steps):
+                lg, ids = plan.forward_decode_batch(toks[i], np.arange(nseq, dtype=np.int32), np.full(nseq, i, np.int32))
+                res.append((lg.copy(), ids.copy()))
+            out[r] = res
+            plan.freeTornadoExecutionPlan()
+        except Exception as e:   # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(tp)]
+    [t.start() for t in th]
+    [t.join(timeout=900) for t in th]
+    assert all(e is None for e in err), err
+    assert not any(t.is_alive() for t in th)
+    hip.lib().gl3_local_group_destroy(grp)
+    for r in range(tp):
+        for i in range(steps):
+            lg, ids = out[r][i]
+            for s in range(nseq):
+                assert np.array_equal(lg[s], ref[s][i]), (r, i, s)
+                assert int(ids[s]) == orc.argmax(ref[s][i])
