@@ -59,3 +59,15 @@ def test_torch_generator_matches_block_layout(pkg):
     w = torch.randn(64, 64, generator=torch.Generator().manual_seed(0)) * 0.02
     assert np.array_equal(s._t_quantize_q8_0(w).numpy(), s.quantize_q8_0(w.numpy()))
     assert np.array_equal(s._t_quantize_q4_0(w).numpy(), s.quantize_q4_0(w.numpy()))
+
+
+def test_biased_int_accumulator_trick_is_exact_over_the_whole_block_sum_range():
+    """pf_gemm / bd_gemm start the int8 MFMA accumulator at 0x4B400000: reinterpreted as f32 that is 12582912 + isum, and
+    subtracting 12582912.0f must give exactly (float)isum for every possible Q8_0 block sum (|isum| <= 32 * 127 * 128)."""
+    import numpy as np
+    lim = 32 * 127 * 128
+    isum = np.arange(-lim, lim + 1, dtype=np.int64)
+    bits = (np.int64(0x4B400000) + isum).astype(np.uint32)
+    got = bits.view(np.float32) - np.float32(12582912.0)
+    assert got.dtype == np.float32 and np.array_equal(got, isum.astype(np.float32))
+    assert np.all(np.signbit(got[isum == 0]) == False)      # +0, as (float)0
