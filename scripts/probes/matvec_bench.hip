@@ -64,7 +64,10 @@ int main(int argc, char** argv) {
             const int g = std::min(wgs, a.nstrips);
             const int iters = 200;
             float us;
-            if (sh.pro == PRO_RMS && sh.epi == EPI_STORE) us = run<PRO_RMS, EPI_STORE>(a, g, smem, iters, wb, w2b);
+            const bool wide = getenv("MB_WIDE") != nullptr;     // 8 producer wavefronts, one workgroup per CU, for every shape
+            if (wide && sh.pro == PRO_RMS && sh.epi == EPI_STORE) us = run<PRO_RMS, EPI_STORE, 8>(a, std::min(g, 256), smem, iters, wb, w2b);
+            else if (wide && sh.pro == PRO_RMS) us = run<PRO_RMS, EPI_SWIGLU, 8>(a, std::min(g, 256), smem, iters, wb, w2b);
+            else if (sh.pro == PRO_RMS && sh.epi == EPI_STORE) us = run<PRO_RMS, EPI_STORE>(a, g, smem, iters, wb, w2b);
             else if (sh.pro == PRO_QUANT && a.nstrips <= 256) us = run<PRO_QUANT, EPI_RESID, 8>(a, g, smem, iters, wb, w2b);
             else if (sh.pro == PRO_QUANT) us = run<PRO_QUANT, EPI_RESID>(a, g, smem, iters, wb, w2b);
             else us = run<PRO_RMS, EPI_SWIGLU>(a, g, smem, iters, wb, w2b);
