@@ -71,3 +71,26 @@ def test_biased_int_accumulator_trick_is_exact_over_the_whole_block_sum_range():
     got = bits.view(np.float32) - np.float32(12582912.0)
     assert got.dtype == np.float32 and np.array_equal(got, isum.astype(np.float32))
     assert np.all(np.signbit(got[isum == 0]) == False)      # +0, as (float)0
+
+
+def test_recorded_bench_lines_follow_the_driver_contract():
+    """profiles/r01_bench_*.json are bench.py lines recorded on an MI355X in round 1; the keys the driver and the judge read
+    must all be there (metric / value / unit / n_gpus / steps / warmup / ms_per_step / roofline / cpu_baseline ...)."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r01_bench_*.json")))
+    assert files
+    for f in files:
+        d = json.load(open(f))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in d, (f, k)
+        assert d["unit"] == "tok/s" and d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["parity_rel_err_fullsize"] == 0.0
+    d = json.load(open(os.path.join(root, "profiles", "r01_bench_8b.json")))
+    assert d["metric"] == "tg128 tok/s (llama-bench), Llama-3-8B Q8_0" and d["pp"]["batch"] == 512
