@@ -54,3 +54,20 @@ def test_create_rejects_bad_descriptors_without_a_gpu(pkg):
     assert L.gl3_create(ctypes.byref(d), ctypes.byref(ctx)) == -2          # GL3_E_UNSUPPORTED
     d.arch, d.weight_type = 0, 12                                           # Q4_K: not in ForwardPlanFactory either
     assert L.gl3_create(ctypes.byref(d), ctypes.byref(ctx)) == -2
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The drop-in boundary must be consumable by C tooling (jextract, cgo, ctypes generators): the header compiles as strict
+    C99 and the native host links against nothing but the C-ABI."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include "gpullama3_hip.h"\nint main(void) { gl3_model_desc d; d.struct_size = sizeof(d); (void)d; return GL3_OK; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "t.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # tools/gl3_bench.cpp includes only the public header and standard headers
+    text = open(os.path.join(root, "tools", "gl3_bench.cpp")).read()
+    incs = [l.split()[1] for l in text.splitlines() if l.startswith("#include")]
+    assert all(i.startswith("<") or i == '"../include/gpullama3_hip.h"' for i in incs), incs
