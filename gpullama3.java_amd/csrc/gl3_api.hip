@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "gl3_ctx.h"
 #include "gl3_decode_kernels.h"
@@ -173,7 +174,7 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
     AttnArgs aa{};
     aa.qkv = ctx->qkv; aa.kcache = ctx->kcache + l * kv_layer; aa.vcache = ctx->vcache + l * kv_layer;
     aa.rope_cr = ctx->rope_cr; aa.rope_ci = ctx->rope_ci; aa.qnorm = L.qnorm; aa.knorm = L.knorm; aa.bq = L.bq; aa.bk = L.bk; aa.bv = L.bv;
-    aa.dyn = ctx->dyn; aa.att = ctx->att; aa.xb = ctx->xb + (size_t)d.tp_rank * ctx->q_dim_l;
+    aa.dyn = ctx->dyn_cur; aa.att = ctx->att; aa.xb = ctx->xb + (size_t)d.tp_rank * ctx->q_dim_l;
     aa.n_heads = ctx->heads_l; aa.n_kv_heads = ctx->kv_heads_l;
     aa.hs = d.head_size; aa.q_dim = ctx->q_dim_l; aa.kv_dim = ctx->kv_dim_l; aa.ctx = d.ctx;
     aa.eps = d.rms_eps; aa.arch = d.arch;
@@ -181,7 +182,7 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
     const int pv_rows = d.ctx < PV_ROWS ? d.ctx : PV_ROWS;
     const size_t sm2 = ((size_t)((d.ctx + 3) & ~3) + (size_t)pv_rows * PV_COLS) * 4;
     if (which == 0 && short_ctx && ctx->fused_attn_ok) {      // positions < AF_MAXN: one launch
-        hipLaunchKernelGGL(attn_fused_kernel, dim3(ctx->kv_heads_l), dim3(128 * kvmul), attn_fused_smem(d.head_size, kvmul), ctx->stream, aa);
+        hipLaunchKernelGGL(attn_head_kernel, dim3(ctx->heads_l), dim3(256), attn_head_smem(d.head_size), ctx->stream, aa);
         return;
     }
     if (which != 2) hipLaunchKernelGGL(attn_scores_kernel, dim3(ctx->n_tsplit, ctx->kv_heads_l), dim3(64 * kvmul), sm1, ctx->stream, aa);
@@ -197,9 +198,9 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
     int32_t r;
 
     pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
-    if (ctx->emb.fmt == GL3_TYPE_Q8_0) hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn, ctx->x);
-    else if (ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_rl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn, ctx->x);
-    else hipLaunchKernelGGL((embed_rl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn, ctx->x);
+    if (ctx->emb.fmt == GL3_TYPE_Q8_0) hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn_cur, ctx->x);
+    else if (ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_rl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x);
+    else hipLaunchKernelGGL((embed_rl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x);
     pr.end();
 
     for (int l = 0; l < d.n_layers; ++l) {
@@ -358,12 +359,9 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP((allow_big_lds<PRO_QUANT, EPI_RESID>()));
     TRYHIP((allow_big_lds<PRO_RMS, EPI_SWIGLU>()));
     {
-        const int kvmul = d.n_heads / d.n_kv_heads;
-        // measured: wins for head_size 64 (Llama-3.2-1B tg128 +4 %), loses for 128 (K/V tiles of 128 KB per workgroup)
-        const int hs_max = getenv("GL3_FUSED_ATTN_HS") ? atoi(getenv("GL3_FUSED_ATTN_HS")) : 64;
-        ctx->fused_attn_ok = kvmul <= 4 && d.head_size <= hs_max && d.head_size <= 128 && d.head_size % 4 == 0 && attn_fused_smem(d.head_size, kvmul) <= 150 * 1024 &&
-                             !env_flag("GL3_NO_FUSED_ATTN", false);
-        if (ctx->fused_attn_ok) TRYHIP(hipFuncSetAttribute((const void*)attn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        // one launch per layer for positions < AF_MAXN (attn_head_kernel); head_size 256 does not fit its K / V tiles in LDS
+        ctx->fused_attn_ok = d.head_size % 4 == 0 && attn_head_smem(d.head_size) <= 150 * 1024 && !env_flag("GL3_NO_FUSED_ATTN", false);
+        if (ctx->fused_attn_ok) TRYHIP(hipFuncSetAttribute((const void*)attn_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
     TRYHIP(hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
 #define GL3_RL_LDS(...) TRYHIP(hipFuncSetAttribute((const void*)matvec_rl_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
@@ -375,6 +373,7 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP(hipFuncSetAttribute((const void*)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     if ((size_t)d.ctx * 4 + (size_t)PV_ROWS * PV_COLS * 4 + 64 > 150 * 1024) return bail(GL3_E_UNSUPPORTED, "context length above 20k not supported by the decode attention kernel");
     TRY(dmalloc(ctx, &ctx->dyn, 4));
+    ctx->dyn_cur = ctx->dyn;
     TRY(dmalloc(ctx, &ctx->argmax, 1));
     if (d.flags & GL3_FLAG_LAYER_TAPS) TRY(dmalloc(ctx, &ctx->taps, (size_t)d.n_layers * d.dim));
     TRYHIP(hipHostMalloc((void**)&ctx->h_dyn, 4 * sizeof(int)));
@@ -409,7 +408,7 @@ void gl3_destroy(gl3_ctx* ctx) {
         f(L.attn_norm); f(L.ffn_norm); f(L.qnorm); f(L.knorm); f(L.bq); f(L.bk); f(L.bv);
     }
     f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->x); f(ctx->xn); f(ctx->qkv);
-    f(ctx->xb); f(ctx->hb); f(ctx->logits); f(ctx->att); f(ctx->dyn); f(ctx->argmax); f(ctx->taps); f(ctx->staging);
+    f(ctx->xb); f(ctx->hb); f(ctx->logits); f(ctx->att); f(ctx->dyn); f(ctx->dyn_seq); f(ctx->argmax); f(ctx->taps); f(ctx->staging);
     if (ctx->h_dyn) hipHostFree(ctx->h_dyn);
     if (ctx->h_logits) hipHostFree(ctx->h_logits);
     if (ctx->h_argmax) hipHostFree(ctx->h_argmax);
@@ -677,13 +676,30 @@ int32_t gl3_forward_prefill_seq(gl3_ctx* ctx, int32_t seq, const int32_t* tokens
     }
     if (seq != 0) GL3_FAIL(GL3_E_UNSUPPORTED, "sequences other than 0 need max_batch > 1");
     // max_batch <= 1: sequential single-token prefill without logits
-    // (TornadoVMMasterPlanPrefillDecode.tornadoVMForwardPrefill, J/tornadovm/TornadoVMMasterPlanPrefillDecode.java:116)
-    for (int i = 0; i < n; ++i) {
-        int32_t r = set_dyn(ctx, tokens[i], start_pos + i);
-        if (r != GL3_OK) return r;
-        if ((r = enqueue_decode(ctx, false, nullptr, ctx->fused_attn_ok && start_pos + i < AF_MAXN)) != GL3_OK) return r;
-        GL3_HIP(hipStreamSynchronize(ctx->stream));
+    // (TornadoVMMasterPlanPrefillDecode.tornadoVMForwardPrefill, J/tornadovm/TornadoVMMasterPlanPrefillDecode.java:116).
+    // All (token, position) pairs go to the device once; every token's launches read their own pair, so the host
+    // enqueues the whole chunk without waiting for the stream.
+    for (int i = 0; i < n; ++i)
+        if (tokens[i] < 0 || tokens[i] >= ctx->d.vocab) GL3_FAIL(GL3_E_ARG, "token id out of range");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    if (ctx->dyn_seq_cap < n) {
+        if (ctx->dyn_seq) hipFree(ctx->dyn_seq);
+        ctx->dyn_seq = nullptr; ctx->dyn_seq_cap = 0;
+        GL3_HIP(hipMalloc((void**)&ctx->dyn_seq, (size_t)2 * n * sizeof(int)));
+        ctx->dyn_seq_cap = n;
     }
+    std::vector<int> pairs((size_t)2 * n);
+    for (int i = 0; i < n; ++i) { pairs[2 * i] = tokens[i]; pairs[2 * i + 1] = start_pos + i; }
+    GL3_HIP(hipStreamSynchronize(ctx->stream));          // a previous chunk may still read dyn_seq
+    GL3_HIP(hipMemcpy(ctx->dyn_seq, pairs.data(), pairs.size() * sizeof(int), hipMemcpyHostToDevice));
+    int32_t r = GL3_OK;
+    for (int i = 0; i < n && r == GL3_OK; ++i) {
+        ctx->dyn_cur = ctx->dyn_seq + 2 * i;
+        r = enqueue_decode(ctx, false, nullptr, ctx->fused_attn_ok && start_pos + i < AF_MAXN);
+    }
+    ctx->dyn_cur = ctx->dyn;
+    if (r != GL3_OK) return r;
+    GL3_HIP(hipStreamSynchronize(ctx->stream));
     return GL3_OK;
 }
 
@@ -733,7 +749,7 @@ int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* o
             case GL3_K_MATVEC_WO: launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->qkv, nullptr); break;
             case GL3_K_MATVEC_GATEUP: launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr); break;
             case GL3_K_MATVEC_DOWN: launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->qkv, nullptr); break;
-            case GL3_K_ATTENTION: launch_attention(ctx, l, 1); break;      // scores only (re-run at the current position)
+            case GL3_K_ATTENTION: launch_attention(ctx, l, 0, ctx->fused_attn_ok && ctx->h_dyn[1] < AF_MAXN); break;   // whole attention at the last position
             case GL3_K_OTHER: launch_attention(ctx, l, 2); break;          // softmax + PV only
             default: launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm, ctx->logits + (size_t)rank * ctx->vocab_l, nullptr); break;
             }

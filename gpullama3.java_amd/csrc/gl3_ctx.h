@@ -74,6 +74,9 @@ struct gl3_ctx {
     float* taps = nullptr;                        // [L][dim] when GL3_FLAG_LAYER_TAPS
     int *dyn = nullptr, *argmax = nullptr;        // dyn[0] = token, dyn[1] = position
     int* h_dyn = nullptr;                         // pinned
+    const int* dyn_cur = nullptr;                 // (token, position) pair the next launches read: dyn, or an entry of dyn_seq
+    int* dyn_seq = nullptr;                       // [2 * dyn_seq_cap] pairs of a sequential (token-by-token) prefill chunk
+    int dyn_seq_cap = 0;
     float* h_logits = nullptr;                    // pinned f32[vocab]
     int* h_argmax = nullptr;
     // upload staging
@@ -87,7 +90,7 @@ struct gl3_ctx {
     hipGraphExec_t graph_exec = nullptr;          // decode step incl. logits
     hipGraph_t graph_s = nullptr;
     hipGraphExec_t graph_exec_s = nullptr;        // same step with the fused short-context attention (pos < AF_MAXN)
-    bool fused_attn_ok = false;                   // shape admits attn_fused_kernel
+    bool fused_attn_ok = false;                   // shape admits attn_head_kernel (one launch per layer for positions < AF_MAXN)
     ncclComm_t comm = nullptr;
     gl3_local_group* lgrp = nullptr;
     bool use_rccl = false;                        // tensor-parallel gathers are active (RCCL or local group)

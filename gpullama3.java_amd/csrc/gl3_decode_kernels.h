@@ -458,10 +458,14 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
     }
     for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.bq ? a.qkv[(kvh * kvmul) * hs + i] + a.bq[(kvh * kvmul) * hs + i] : a.qkv[(kvh * kvmul) * hs + i];
     for (int i = t; i < half; i += nthr) { cr_s[i] = a.rope_cr[(size_t)pos * half + i]; ci_s[i] = a.rope_ci[(size_t)pos * half + i]; }
-    float vraw = 0.f;
+    float vraw[4] = {0.f, 0.f, 0.f, 0.f};                 // element t + u * nthr of the v row (hs <= 256, nthr >= 64)
     if (owns_pos) {
         for (int i = t; i < hs; i += nthr) krow[i] = a.bk ? a.qkv[a.q_dim + kvh * hs + i] + a.bk[kvh * hs + i] : a.qkv[a.q_dim + kvh * hs + i];
-        if (t < hs) vraw = a.bv ? a.qkv[a.q_dim + a.kv_dim + kvh * hs + t] + a.bv[kvh * hs + t] : a.qkv[a.q_dim + a.kv_dim + kvh * hs + t];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = t + u * nthr;
+            if (i < hs) vraw[u] = a.bv ? a.qkv[a.q_dim + a.kv_dim + kvh * hs + i] + a.bv[kvh * hs + i] : a.qkv[a.q_dim + a.kv_dim + kvh * hs + i];
+        }
     }
     if (per > KMAX) {                                         // generic fallback (few threads): straight to LDS
         for (int i = t; i < nk4; i += nthr) {
@@ -484,9 +488,15 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
     for (int h = 0; h < kvmul; ++h) rope_head(q_s + h * hs, hs, cr_s, ci_s, a.arch, t, nthr);
     if (owns_pos) rope_head(krow, hs, cr_s, ci_s, a.arch, t, nthr);
     __syncthreads();
-    if (owns_pos && t < hs) {                    // KV write, InferenceCore.java:92-93
-        a.kcache[(size_t)pos * a.kv_dim + kvh * hs + t] = krow[t];
-        a.vcache[(size_t)pos * a.kv_dim + kvh * hs + t] = vraw;
+    if (owns_pos) {                              // KV write, InferenceCore.java:92-93 (strided: head_size may exceed 64 * kvMul)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = t + u * nthr;
+            if (i < hs) {
+                a.kcache[(size_t)pos * a.kv_dim + kvh * hs + i] = krow[i];
+                a.vcache[(size_t)pos * a.kv_dim + kvh * hs + i] = vraw[u];
+            }
+        }
     }
     const int hq = t >> 6, r = t & 63;           // wavefront = query head of the group, lane = timestep
     if (hq < kvmul && t0 + r < t1) {
@@ -507,154 +517,136 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // Short-context decode attention in ONE launch (positions < AF_MAXN): RoPE + KV write + scores + softmax + weighted V
-// sum for one kv head and its kvMul query heads.  Same arithmetic and order as the two kernels above/below; what it
-// saves is a launch and three dependent global round trips (scores -> HBM -> softmax, V after the softmax), which is
-// most of the time at tg128 depth 0.  Grid = n_kv_heads, block = 128 x kvMul (kvMul <= 4): wavefront = (query head,
-// score tile); after the scores one wavefront per query head does softmax and the V sum.
-//   LDS: q[kvMul][hs] | K[AF_MAXN][hs+4] | V[AF_MAXN][hs] | e[kvMul][AF_MAXN] | rope row
+// sum.  Same arithmetic and order as the two-kernel path above/below; what it saves is a launch, two kernel boundaries
+// and three dependent global round trips (scores -> HBM -> softmax, V after the softmax), which is most of the decode
+// attention time at tg128 depth 0.
+// Grid = n_heads (one workgroup per QUERY head), block = 256.  The kvMul query heads of a group each stage their own
+// copy of the group's K / V rows (<= 64 KB each at 128 positions, L2 / Infinity-Cache hits after the first): a workgroup's
+// load rate is bounded per CU (~10 B/clk), so 32 workgroups x 128 KB beat 8 workgroups x 135 KB + 4 heads each (the first
+// version of this kernel, one workgroup per kv head, lost to the two-kernel path for head_size 128 for that reason).
+// RoPE of k is recomputed by every head of the group (128 elements); only the group's first head writes the KV row.
+//   LDS: q[hs] | K[AF_MAXN][hs+4] | V[AF_MAXN][hs] | e[AF_MAXN] | rope row | red[16]
 constexpr int AF_MAXN = 128;
-__host__ __device__ inline size_t attn_fused_smem(int hs, int kvmul) {
-    return ((size_t)kvmul * hs + (size_t)AF_MAXN * (hs + 4) + (size_t)AF_MAXN * hs + (size_t)kvmul * AF_MAXN + hs) * 4;
+__host__ __device__ inline size_t attn_head_smem(int hs) {
+    return ((size_t)hs + (size_t)AF_MAXN * (hs + 4) + (size_t)AF_MAXN * hs + (size_t)AF_MAXN + hs + 16) * 4;
 }
 
-static __global__ __launch_bounds__(512) void attn_fused_kernel(const AttnArgs a) {
+static __global__ __launch_bounds__(256) void attn_head_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads, half = hs >> 1, pitch = hs + 4, q4 = hs >> 2;
+    const int q4sh = __ffs(q4) - 1;                  // head sizes are powers of two
     float* q_s = sm;
-    float* kt = q_s + kvmul * hs;
+    float* kt = q_s + hs;
     float* vt = kt + AF_MAXN * pitch;
     float* e_s = vt + AF_MAXN * hs;
-    float* cr_s = e_s + kvmul * AF_MAXN;
+    float* cr_s = e_s + AF_MAXN;
     float* ci_s = cr_s + half;
-    const int t = threadIdx.x, nthr = blockDim.x, kvh = blockIdx.x;
+    float* red = ci_s + half;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int h = blockIdx.x, kvh = h / kvmul;
+    const bool owner = (h % kvmul) == 0;
     const int pos = a.dyn[1], n = pos + 1;
-    // ---- one global round trip: cached K / V rows, raw q / k / v of this token, the RoPE row
+    ATT_STAMP(0);
+    // ---- one global round trip: cached K / V rows (both in flight at once), raw q / k / v of this token, the RoPE row
     const int nk4 = pos * q4;
-    constexpr int KMAX = 8;
+    constexpr int KMAX = 16;                         // 127 rows x 32 float4 / 256 threads (head_size 128)
     float4 kreg[KMAX], vreg[KMAX];
-    const int per = (nk4 + nthr - 1) / nthr;
-    if (per <= KMAX) {
+    const bool in_regs = nk4 <= KMAX * 256;
+    if (in_regs) {
 #pragma unroll
         for (int u = 0; u < KMAX; ++u) {
-            const int i = t + u * nthr;
-            if (u < per && i < nk4) {
-                const size_t off = (size_t)(i / q4) * a.kv_dim + kvh * hs + 4 * (i % q4);
+            const int i = t + u * 256;
+            if (i < nk4) {
+                const size_t off = (size_t)(i >> q4sh) * a.kv_dim + kvh * hs + 4 * (i & (q4 - 1));
                 kreg[u] = *reinterpret_cast<const float4*>(a.kcache + off);
                 vreg[u] = *reinterpret_cast<const float4*>(a.vcache + off);
             }
         }
     }
-    for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.bq ? a.qkv[(kvh * kvmul) * hs + i] + a.bq[(kvh * kvmul) * hs + i] : a.qkv[(kvh * kvmul) * hs + i];
-    for (int i = t; i < half; i += nthr) { cr_s[i] = a.rope_cr[(size_t)pos * half + i]; ci_s[i] = a.rope_ci[(size_t)pos * half + i]; }
+    for (int i = t; i < hs; i += 256) q_s[i] = a.bq ? a.qkv[h * hs + i] + a.bq[h * hs + i] : a.qkv[h * hs + i];
+    for (int i = t; i < half; i += 256) { cr_s[i] = a.rope_cr[(size_t)pos * half + i]; ci_s[i] = a.rope_ci[(size_t)pos * half + i]; }
     float* krow = kt + pos * pitch;
-    for (int i = t; i < hs; i += nthr) {
+    for (int i = t; i < hs; i += 256) {
         krow[i] = a.bk ? a.qkv[a.q_dim + kvh * hs + i] + a.bk[kvh * hs + i] : a.qkv[a.q_dim + kvh * hs + i];
         vt[pos * hs + i] = a.bv ? a.qkv[a.q_dim + a.kv_dim + kvh * hs + i] + a.bv[kvh * hs + i] : a.qkv[a.q_dim + a.kv_dim + kvh * hs + i];
     }
-    if (per <= KMAX) {
+    if (in_regs) {
 #pragma unroll
         for (int u = 0; u < KMAX; ++u) {
-            const int i = t + u * nthr;
-            if (u < per && i < nk4) {
-                *reinterpret_cast<float4*>(kt + (i / q4) * pitch + 4 * (i % q4)) = kreg[u];
-                *reinterpret_cast<float4*>(vt + (i / q4) * hs + 4 * (i % q4)) = vreg[u];
+            const int i = t + u * 256;
+            if (i < nk4) {
+                *reinterpret_cast<float4*>(kt + (i >> q4sh) * pitch + 4 * (i & (q4 - 1))) = kreg[u];
+                *reinterpret_cast<float4*>(vt + (i >> q4sh) * hs + 4 * (i & (q4 - 1))) = vreg[u];
             }
         }
-    } else {
-        for (int i = t; i < nk4; i += nthr) {
-            const size_t off = (size_t)(i / q4) * a.kv_dim + kvh * hs + 4 * (i % q4);
-            *reinterpret_cast<float4*>(kt + (i / q4) * pitch + 4 * (i % q4)) = *reinterpret_cast<const float4*>(a.kcache + off);
-            *reinterpret_cast<float4*>(vt + (i / q4) * hs + 4 * (i % q4)) = *reinterpret_cast<const float4*>(a.vcache + off);
+    } else {                                         // head_size 256: straight to LDS
+        for (int i = t; i < nk4; i += 256) {
+            const size_t off = (size_t)(i >> q4sh) * a.kv_dim + kvh * hs + 4 * (i & (q4 - 1));
+            *reinterpret_cast<float4*>(kt + (i >> q4sh) * pitch + 4 * (i & (q4 - 1))) = *reinterpret_cast<const float4*>(a.kcache + off);
+            *reinterpret_cast<float4*>(vt + (i >> q4sh) * hs + 4 * (i & (q4 - 1))) = *reinterpret_cast<const float4*>(a.vcache + off);
         }
     }
     __syncthreads();
-    if (a.arch == 1) {
-        if (t < kvmul) head_rmsnorm_1t(q_s + t * hs, a.qnorm, hs, a.eps);
-        if (t == kvmul) head_rmsnorm_1t(krow, a.knorm, hs, a.eps);
+    ATT_STAMP(1);
+    if (a.arch == 1) {                               // qwen3: per-head RMSNorm of q and k (one thread each, strict order)
+        if (t == 0) head_rmsnorm_1t(q_s, a.qnorm, hs, a.eps);
+        if (t == 64) head_rmsnorm_1t(krow, a.knorm, hs, a.eps);
         __syncthreads();
     }
-    for (int h = 0; h < kvmul; ++h) rope_head(q_s + h * hs, hs, cr_s, ci_s, a.arch, t, nthr);
-    rope_head(krow, hs, cr_s, ci_s, a.arch, t, nthr);
+    rope_head(q_s, hs, cr_s, ci_s, a.arch, t, 256);
+    rope_head(krow, hs, cr_s, ci_s, a.arch, t, 256);
     __syncthreads();
-    if (t < hs) {                                    // KV write, InferenceCore.java:92-93
-        a.kcache[(size_t)pos * a.kv_dim + kvh * hs + t] = krow[t];
-        a.vcache[(size_t)pos * a.kv_dim + kvh * hs + t] = vt[pos * hs + t];
-    }
-    // wavefront w: query head w % kvMul, score tile w / kvMul (two tiles of 64 timesteps run side by side)
-    const int wv = t >> 6, hq = wv % kvmul, mytile = wv / kvmul, r = t & 63;
-    float* e = e_s + hq * AF_MAXN;
-    const float sqrt_hs = (float)sqrt((double)hs);
-    {
-        const int tt = mytile * 64 + r;
-        if (tt < n) {
-            const float* q = q_s + hq * hs;
-            const float* kk = kt + tt * pitch;
-            float score = 0.f;                       // strict j order, mul then add (FloatTensor.scalarDot)
-            float4 qv = *reinterpret_cast<const float4*>(q), kv = *reinterpret_cast<const float4*>(kk);
-            for (int j = 4; j < hs; j += 4) {
-                const float4 qn = *reinterpret_cast<const float4*>(q + j), kn = *reinterpret_cast<const float4*>(kk + j);
-                score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
-                qv = qn; kv = kn;
-            }
-            score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
-            e[tt] = score / sqrt_hs;
+    if (owner) {                                     // KV write, InferenceCore.java:92-93
+        for (int i = t; i < hs; i += 256) {
+            a.kcache[(size_t)pos * a.kv_dim + kvh * hs + i] = krow[i];
+            a.vcache[(size_t)pos * a.kv_dim + kvh * hs + i] = vt[pos * hs + i];
         }
     }
-    __syncthreads();
-    if (mytile != 0) return;                         // the first kvMul wavefronts carry on: one per query head
-    float sc[AF_MAXN / 64];
-#pragma unroll
-    for (int tile = 0; tile < AF_MAXN / 64; ++tile) {
-        const int tt = tile * 64 + r;
-        sc[tile] = tt < n ? e[tt] : -INFINITY;
+    ATT_STAMP(2);
+    // ---- scores: thread = timestep; strict j order, mul then add (FloatTensor.scalarDot)
+    float sc = -INFINITY;
+    if (t < n) {
+        const float* kk = kt + t * pitch;
+        float score = 0.f;
+        float4 qv = *reinterpret_cast<const float4*>(q_s), kv = *reinterpret_cast<const float4*>(kk);
+        for (int j = 4; j < hs; j += 4) {
+            const float4 qn = *reinterpret_cast<const float4*>(q_s + j), kn = *reinterpret_cast<const float4*>(kk + j);
+            score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
+            qv = qn; kv = kn;
+        }
+        score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
+        sc = score / (float)sqrt((double)hs);
     }
-    // softmax (FloatTensor.softmaxInPlace :211-219): max, exp in double, strict sum, divide
-    float mx = sc[0];
-#pragma unroll
-    for (int tile = 1; tile < AF_MAXN / 64; ++tile) mx = fmaxf(mx, sc[tile]);
-    mx = wave_max(mx);
-#pragma unroll
-    for (int tile = 0; tile < AF_MAXN / 64; ++tile) {
-        const int tt = tile * 64 + r;
-        if (tt < n) { sc[tile] = (float)exp((double)(sc[tile] - mx)); e[tt] = sc[tile]; }
-    }
-    __syncthreads();
-    const float sum = seq_sum_lds<false>(e, n);
-    __syncthreads();
-#pragma unroll
-    for (int tile = 0; tile < AF_MAXN / 64; ++tile) {
-        const int tt = tile * 64 + r;
-        if (tt < n) e[tt] = sc[tile] / sum;
+    ATT_STAMP(3);
+    // ---- softmax (FloatTensor.softmaxInPlace :211-219): max, exp in double, strict sum, divide
+    {
+        const float wm = wave_max(sc);
+        if (lane == 0) red[wave] = wm;
     }
     __syncthreads();
-    // weighted V sum, t ascending: xb[j] = a_t * v[t][j] + xb[j] (saxpyInPlace :221-227); lane = 1 or 2 columns
-    const int nc = hs > 64 ? 2 : 1;
-    const int c0 = r * nc;
-    float acc0 = 0.f, acc1 = 0.f;
-    if (c0 < hs) {
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float ex = 0.f;
+    if (t < n) { ex = (float)exp((double)(sc - mx)); e_s[t] = ex; }
+    __syncthreads();
+    ATT_STAMP(4);
+    if (wave == 0) { const float sum = seq_sum_lds<false>(e_s, n); if (lane == 0) red[4] = sum; }
+    __syncthreads();
+    if (t < n) e_s[t] = ex / red[4];
+    __syncthreads();
+    ATT_STAMP(5);
+    // ---- weighted V sum, t ascending: xb[j] = a_t * v[t][j] + xb[j] (saxpyInPlace :221-227); thread = output column
+    if (t < hs) {
+        float acc = 0.f;
         int tt = 0;
         for (; tt + 4 <= n; tt += 4) {
-            const float4 a4 = *reinterpret_cast<const float4*>(e + tt);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (nc == 2) {
-                    const float2 v = *reinterpret_cast<const float2*>(vt + (tt + i) * hs + c0);
-                    acc0 = av[i] * v.x + acc0; acc1 = av[i] * v.y + acc1;
-                } else acc0 = av[i] * vt[(tt + i) * hs + c0] + acc0;
-            }
+            const float4 a4 = *reinterpret_cast<const float4*>(e_s + tt);
+            const float v0 = vt[tt * hs + t], v1 = vt[(tt + 1) * hs + t], v2 = vt[(tt + 2) * hs + t], v3 = vt[(tt + 3) * hs + t];
+            acc = a4.x * v0 + acc; acc = a4.y * v1 + acc; acc = a4.z * v2 + acc; acc = a4.w * v3 + acc;
         }
-        for (; tt < n; ++tt) {
-            const float at = e[tt];
-            if (nc == 2) {
-                const float2 v = *reinterpret_cast<const float2*>(vt + tt * hs + c0);
-                acc0 = at * v.x + acc0; acc1 = at * v.y + acc1;
-            } else acc0 = at * vt[tt * hs + c0] + acc0;
-        }
-        float* o = a.xb + (size_t)(kvh * kvmul + hq) * hs + c0;
-        o[0] = acc0;
-        if (nc == 2) o[1] = acc1;
+        for (; tt < n; ++tt) acc = e_s[tt] * vt[tt * hs + t] + acc;
+        a.xb[(size_t)h * hs + t] = acc;
     }
+    ATT_STAMP(6);
 }
 
 // Decode attention, part 2: softmax + weighted V sum.   Grid = n_heads x hs/16, block = 256.

@@ -174,24 +174,36 @@ int32_t gl3_gguf_open(const char* path, gl3_gguf** out) {
         g->meta[key] = v;
     }
     double al;
-    if (meta_num(g, "general.alignment", &al) && al >= 1) g->alignment = (uint64_t)al;
+    if (meta_num(g, "general.alignment", &al)) {
+        // a power of two between 1 and 1 MiB (GGUF default 32); anything else is a corrupt or hostile file
+        if (!(al >= 1 && al <= 1048576.0) || ((uint64_t)al & ((uint64_t)al - 1))) return bail(GL3_E_ARG, "general.alignment is not a sane power of two");
+        g->alignment = (uint64_t)al;
+    }
     g->tensors.resize((size_t)n_tensors);
     for (auto& t : g->tensors) {
         t.name = c.str();
         t.n_dims = (int)c.get<uint32_t>();
         if (!c.ok || t.n_dims < 1 || t.n_dims > 4) return bail(GL3_E_ARG, "corrupt GGUF tensor info");
         uint64_t n = 1;
-        for (int d = 0; d < t.n_dims; ++d) { t.ne[d] = c.get<uint64_t>(); n *= t.ne[d]; }
+        bool overflow = false;
+        for (int d = 0; d < t.n_dims; ++d) {
+            t.ne[d] = c.get<uint64_t>();
+            if (t.ne[d] != 0 && n > (UINT64_MAX / 8) / t.ne[d]) overflow = true;      // n * 4 bytes must not wrap either
+            else n *= t.ne[d];
+        }
         t.type = (int)c.get<uint32_t>();
         t.offset = c.get<uint64_t>();
-        if (!c.ok) return bail(GL3_E_ARG, "corrupt GGUF tensor info");
+        if (!c.ok || overflow) return bail(GL3_E_ARG, "corrupt GGUF tensor info");
         t.bytes = type_bytes(t.type, n);
     }
     const uint64_t pos = (uint64_t)(c.p - g->base);
     g->data_off = (pos + g->alignment - 1) / g->alignment * g->alignment;        // GGUF.java:105-137
+    if (g->data_off > g->size) return bail(GL3_E_ARG, "GGUF tensor-data section starts past the end of the file");
+    const uint64_t data_size = g->size - g->data_off;
     for (size_t i = 0; i < g->tensors.size(); ++i) {
         const TensorInfo& t = g->tensors[i];
-        if (t.bytes && (g->data_off + t.offset + t.bytes > g->size || t.offset % g->alignment))
+        // overflow-safe: offset and offset + bytes are compared against the remaining size, never added to data_off
+        if (t.bytes && (t.offset > data_size || t.bytes > data_size - t.offset || t.offset % g->alignment))
             return bail(GL3_E_ARG, "tensor '" + t.name + "' lies outside the file or is misaligned");
         g->by_name[t.name] = (int)i;
     }
@@ -238,12 +250,17 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
     else if (a == "qwen2") d->arch = GL3_ARCH_QWEN2;
     else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, qwen3, qwen2)");
     auto need = [&](const char* k, double* v) { return meta_num(g, a + "." + k, v); };
-    double dim, hid, nl, nh, nkv, eps, theta = 10000.0, ctx, kl;
+    // defaults as the reference loaders: rms epsilon 1e-5, rope theta 10000 (LlamaModelLoader.java:62-63)
+    double dim, hid, nl, nh, nkv, eps = 1e-5, theta = 10000.0, ctx, kl;
     if (!need("embedding_length", &dim) || !need("feed_forward_length", &hid) || !need("block_count", &nl) ||
-        !need("attention.head_count", &nh) || !need("attention.layer_norm_rms_epsilon", &eps) || !need("context_length", &ctx))
+        !need("attention.head_count", &nh) || !need("context_length", &ctx))
         return fail(g, GL3_E_ARG, "model shape keys missing from the metadata");
+    need("attention.layer_norm_rms_epsilon", &eps);
     if (!need("attention.head_count_kv", &nkv)) nkv = nh;
     need("rope.freq_base", &theta);
+    if (!(dim >= 1 && dim <= (1 << 20)) || !(hid >= 1 && hid <= (1 << 24)) || !(nl >= 1 && nl <= 4096) || !(nh >= 1 && nh <= 4096) ||
+        !(nkv >= 1 && nkv <= nh) || !(ctx >= 1 && ctx <= 2147483647.0))
+        return fail(g, GL3_E_ARG, "model shape keys out of range (head_count / block_count / lengths must be positive)");
     auto te = g->by_name.find("token_embd.weight");
     if (te == g->by_name.end()) return fail(g, GL3_E_ARG, "token_embd.weight missing");
     const TensorInfo& emb = g->tensors[te->second];
@@ -251,7 +268,11 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
     d->dim = (int32_t)dim; d->hidden = (int32_t)hid; d->n_layers = (int32_t)nl; d->n_heads = (int32_t)nh; d->n_kv_heads = (int32_t)nkv;
     d->head_size = need("attention.key_length", &kl) ? (int32_t)kl : d->dim / d->n_heads;
     d->vocab = (int32_t)emb.ne[1];
-    if (d->ctx <= 0 || d->ctx > (int32_t)ctx) d->ctx = (int32_t)ctx;      // caller may ask for a shorter KV cache
+    // The caller may ask for a shorter KV cache.  ctx = 0 means "default": min(context_length, 4096) — the reference always
+    // clamps through Configuration.withContextLength(maxTokens); <arch>.context_length itself (131072 for Llama-3.1/3.2)
+    // would allocate tens of GB of f32 KV cache and is beyond the decode attention kernel's limit.
+    if (d->ctx <= 0) d->ctx = ctx < 4096 ? (int32_t)ctx : 4096;
+    else if (d->ctx > (int32_t)ctx) d->ctx = (int32_t)ctx;
     d->rms_eps = (float)eps;
     d->weight_type = emb.type;
     if (rope_theta) *rope_theta = (float)theta;

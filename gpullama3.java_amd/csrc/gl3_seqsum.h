@@ -236,11 +236,13 @@ __device__ float exact_sumsq_lds(const float* x, int n, uint8_t* scratch, const 
             }
         }
     }
-    sync();
-    if (seg0 > 0 && seg0 < nseg && !(ev[0] >> 31)) {                      // first segment of the thread vs its left neighbour
+    // first segment of the thread vs its left neighbour: es[] was complete at the previous sync(), and the flag must be
+    // set BEFORE the next one — wave 0 reads misc[0] right after it
+    if (seg0 > 0 && seg0 < nseg && !(ev[0] >> 31)) {
         const uint32_t ep = es[seg0 - 1];
         if (!(ep >> 31) && ep != ev[0]) misc[0] = 1;
     }
+    sync();
     SS_STAMP(4);
     // ---- replay the hard segments in order (one wavefront), see replay_events
     if (wave == 0) {

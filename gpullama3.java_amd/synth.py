@@ -62,6 +62,14 @@ CONFIGS = {
     # Qwen2 / Qwen2.5 / DeepSeek-R1-Distill-Qwen shape: q/k/v bias, NeoX RoPE, head_size = dim / heads (forwardJavaQwen2)
     "tiny-qwen2": ModelConfig("tiny-qwen2-random", ARCH_QWEN2, 256, 512, 2, 8, 2, 32, 512, 64, 1e-6, 1000000.0, True),
     "mid-qwen2": ModelConfig("mid-qwen2-random", ARCH_QWEN2, 1536, 4480, 2, 12, 2, 128, 2048, 160, 1e-6, 1000000.0, False),
+    # multi-head attention (n_heads == n_kv_heads, kvMul = 1) with head_size 128: Llama-2-7B-style head layout
+    "mha-llama": ModelConfig("mha-llama-random", ARCH_LLAMA, 1024, 2048, 2, 8, 8, 128, 1024, 160, 1e-5, 10000.0, False),
+    # full-size SHAPES of the BASELINE models with few layers / a small vocabulary, so that the CPU oracle finishes in seconds:
+    # one Llama-3-8B layer (K = 14336: 112 tile groups, activation quads == 14 * 256 exactly), the 128256-row vocabulary
+    # projection on dim 4096, and two Qwen3-4B layers (K = 2560 ragged, head_size 128 != dim / heads, tied wcls)
+    "8b-layer": ModelConfig("Llama-3-8B-1layer-random", ARCH_LLAMA, 4096, 14336, 1, 32, 8, 128, 2048, 648, 1e-5, 500000.0, False),
+    "8b-vocab": ModelConfig("Llama-3-8B-vocab-random", ARCH_LLAMA, 4096, 1024, 1, 32, 8, 128, 128256, 64, 1e-5, 500000.0, False),
+    "qwen3-4b-2l": ModelConfig("Qwen3-4B-2layer-random", ARCH_QWEN3, 2560, 9728, 2, 32, 8, 128, 4096, 64, 1e-6, 1000000.0, True),
 }
 
 

@@ -222,7 +222,8 @@ GL3_API int32_t gl3_gguf_tensor_info(const gl3_gguf* g, int32_t i, const char** 
 GL3_API int32_t gl3_gguf_meta_number(const gl3_gguf* g, const char* key, double* out);   /* any scalar numeric / bool key */
 GL3_API int32_t gl3_gguf_meta_string(const gl3_gguf* g, const char* key, const char** out);
 /* Shape fields of desc (arch, dim, hidden, layers, heads, head_size, vocab, rms_eps, weight_type) from the metadata; desc->ctx is
- * kept if it is > 0 and not larger than <arch>.context_length; the other fields are left as the caller set them. */
+ * kept if it is > 0 and not larger than <arch>.context_length, desc->ctx = 0 selects min(context_length, 4096) (the reference
+ * always clamps with Configuration.withContextLength(maxTokens)); the other fields are left as the caller set them. */
 GL3_API int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* desc, float* rope_theta);
 /* RoPE.precomputeFreqsCis with ropeScaling = false: cr / ci are f32[ctx * head_size/2]. */
 GL3_API void gl3_rope_table(int32_t ctx, int32_t head_size, float theta, float* cr, float* ci);

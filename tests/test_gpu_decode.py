@@ -50,9 +50,10 @@ def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed, wtype):
     plan.freeTornadoExecutionPlan()
 
 
-@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "tiny-llama-tied", "tiny-qwen2", "mid-qwen2"])
+@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "tiny-llama-tied", "tiny-qwen2", "mid-qwen2", "mha-llama"])
 def test_decode_matches_c_oracle_live(pkg, orc, planmod, cfg):
-    """Shapes with full 64-block chunks, ragged chunk tails (K = 2560), head sizes 32/64/128, tied wcls."""
+    """Shapes with full 64-block chunks, ragged chunk tails (K = 2560), head sizes 32/64/128, tied wcls, and multi-head
+    attention (kvMul = 1 with head_size 128: the KV write must cover head_size > 64 * kvMul)."""
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], seed=21)
     plan = plan_mod.HipMasterPlan(m, flags=hip.FLAG_LAYER_TAPS)
@@ -94,34 +95,34 @@ def test_f16_and_q4_0_decode_match_c_oracle_live(pkg, orc, planmod, cfg, wtype):
     plan.freeTornadoExecutionPlan()
 
 
-def test_graph_and_eager_launches_agree_bitwise(pkg, planmod):
+def test_graph_and_eager_launches_agree_bitwise(pkg, orc, planmod):
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS["mid-llama"], seed=3)
     a = plan_mod.HipMasterPlan(m)
     b = plan_mod.HipMasterPlan(m, flags=hip.FLAG_NO_GRAPH)
+    o = orc.COracle(m)
     for pos, t in enumerate(pkg.javarand.bench_tokens(m.cfg.vocab, 6)):
-        assert np.array_equal(a.forward_decode(t, pos), b.forward_decode(t, pos))
+        ref = o.forward(t, pos)
+        assert np.array_equal(a.forward_decode(t, pos), ref) and np.array_equal(b.forward_decode(t, pos), ref)
     # replaying the same position is idempotent (KV row is overwritten with the same values)
     l1 = a.forward_decode(5, 6)
     assert np.array_equal(l1, a.forward_decode(5, 6))
     a.freeTornadoExecutionPlan(); b.freeTornadoExecutionPlan()
 
 
-@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3"])        # head sizes 64 and 128 (qwen3: per-head norms, NeoX RoPE)
+@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "mid-qwen2", "mha-llama"])   # head sizes 64 / 128, kvMul 4 / 6 / 1
 def test_fused_short_context_attention_and_the_handover_at_128(pkg, orc, planmod, cfg):
-    """Positions < 128 run attn_fused_kernel (one launch per layer), later ones the scores + softmax/PV pair; both must
-    reproduce the oracle bit for bit, also across the handover, and agree with each other."""
+    """Positions < 128 run attn_head_kernel (one launch per layer, one workgroup per query head), later ones the scores +
+    softmax/PV pair; both must reproduce the oracle bit for bit, also across the handover, and agree with each other."""
     plan_mod, hip = planmod
     base = pkg.synth.CONFIGS[cfg]
     m = pkg.synth.make_numpy(pkg.synth.ModelConfig(**{**base.__dict__, "ctx": 160}), seed=29)
-    os.environ["GL3_FUSED_ATTN_HS"] = "128"          # default: head sizes <= 64 only (where it is faster)
+    plan = plan_mod.HipMasterPlan(m)
+    os.environ["GL3_NO_FUSED_ATTN"] = "1"
     try:
-        plan = plan_mod.HipMasterPlan(m)
-        os.environ["GL3_NO_FUSED_ATTN"] = "1"
         plain = plan_mod.HipMasterPlan(m)
     finally:
         os.environ.pop("GL3_NO_FUSED_ATTN", None)
-        del os.environ["GL3_FUSED_ATTN_HS"]
     o = orc.COracle(m)
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 134)
     for pos in range(122):
@@ -242,7 +243,7 @@ def test_static_batched_decode_matches_independent_cpu_runs(pkg, orc, planmod, c
 
 
 @pytest.mark.parametrize("cfg,wtype", [("tiny-llama", 8), ("tiny-qwen3", 8), ("tiny-llama-tied", 1), ("tiny-qwen2", 8)])
-def test_native_gguf_loader_builds_the_same_plan(pkg, planmod, tmp_path, cfg, wtype):
+def test_native_gguf_loader_builds_the_same_plan(pkg, orc, planmod, tmp_path, cfg, wtype):
     """gl3_load_gguf (mmap + native config / tensor-name map / RoPE table) vs the per-tensor upload path driven from Python."""
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=13)
@@ -251,18 +252,20 @@ def test_native_gguf_loader_builds_the_same_plan(pkg, planmod, tmp_path, cfg, wt
     a = plan_mod.HipMasterPlan(m)
     b = plan_mod.HipMasterPlan.from_gguf(path, prefill_batch_size=8)
     assert (b.cfg.dim, b.cfg.n_layers, b.cfg.vocab, b.cfg.head_size) == (m.cfg.dim, m.cfg.n_layers, m.cfg.vocab, m.cfg.head_size)
+    o = orc.COracle(pkg.synth.SynthModel.from_gguf(path))      # the oracle reads the SAME file through the Python GGUF reader
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 10)
     b.prefill(toks[:5], 0)
     for pos, t in enumerate(toks):
-        la = a.forward_decode(t, pos)
+        ref = o.forward(t, pos)
+        assert np.array_equal(a.forward_decode(t, pos), ref), pos
         if pos >= 5:
-            assert np.array_equal(b.forward_decode(t, pos), la), pos
+            assert np.array_equal(b.forward_decode(t, pos), ref), pos
     a.freeTornadoExecutionPlan(); b.freeTornadoExecutionPlan()
     with pytest.raises(hip.Gl3Error):
         plan_mod.HipMasterPlan.from_gguf(str(tmp_path / "missing.gguf"))
 
 
-def test_native_bench_host_over_the_c_abi(pkg, planmod, tmp_path):
+def test_native_bench_host_over_the_c_abi(pkg, orc, planmod, tmp_path):
     """tools/gl3_bench (plain C++, links only the C-ABI): loads a GGUF natively, runs the LlamaBench protocol and must produce
     the same greedy ids as the Python host for the java.util.Random(42) token stream."""
     import subprocess
@@ -275,10 +278,9 @@ def test_native_bench_host_over_the_c_abi(pkg, planmod, tmp_path):
     assert out.returncode == 0, out.stderr
     assert "| tiny-llama-random | pp16 -b 8 |" in out.stdout and "| tiny-llama-random | tg12 |" in out.stdout
     ids = [int(x) for x in out.stdout.split("greedy ids:")[1].split()]
-    plan = plan_mod.HipMasterPlan(m)
+    o = orc.COracle(pkg.synth.SynthModel.from_gguf(path))
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 16)
-    assert ids == [plan.forward_decode_argmax(toks[i], i) for i in range(12)]
-    plan.freeTornadoExecutionPlan()
+    assert ids == [orc.argmax(o.forward(toks[i], i)) for i in range(12)]          # greedy ids of the CPU oracle on the same file
 
 
 @pytest.mark.parametrize("cfg", ["tiny-llama", "tiny-qwen3"])

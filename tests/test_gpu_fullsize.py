@@ -1,0 +1,117 @@
+"""Parity at the SHAPES of the BASELINE.json configurations (the round-1 tests stopped at "mid" shapes):
+
+* one Llama-3-8B-shaped layer (dim 4096, hidden 14336, 32 / 8 heads, head_size 128): K = 14336 gives 112 tile groups per
+  strip and exactly 14 * 256 activation quads in the matvec prologue; a 512-token batched prefill (the pp512 -b 512 shape:
+  128-token GEMM tiles, 8-wavefront wo / down variant) and decode steps on both attention paths;
+* the 128256-row vocabulary projection on dim 4096 (501 strips per workgroup slot, full logits compared);
+* BASELINE configs[4]: static-batched decode on two Qwen3-4B-shaped layers (K = 2560 -> 80 blocks, ragged tile group;
+  head_size 128 != dim / heads; tied wcls) at B = 32 (bd_gemm_kernel with every column live), B = 33 and B = 64
+  (the 32-token-tile pf_gemm variant) against one independent CPU oracle per sequence.
+
+All comparisons are np.array_equal against oracle/gl3_oracle.c on the same weights.
+"""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def planmod():
+    from importlib import import_module
+    ge.load_package()
+    return import_module(ge.PKG_NAME + ".plan"), import_module(ge.PKG_NAME + ".hip")
+
+
+def _model(pkg, name, seed, wtype=8, **over):
+    """Weights are generated on the GPU (seconds for 230 M parameters) and handed to BOTH the plan and the oracle."""
+    import torch
+    cfg = pkg.synth.CONFIGS[name]
+    if over:
+        cfg = pkg.synth.ModelConfig(**{**cfg.__dict__, **over})
+    return pkg.synth.make_torch(cfg, wtype=wtype, seed=seed, device="cuda" if torch.cuda.is_available() else "cpu")
+
+
+def test_llama3_8b_shaped_layer_prefill512_and_decode(pkg, orc, planmod):
+    plan_mod, hip = planmod
+    m = _model(pkg, "8b-layer", 101)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 518)
+    # ---- decode from position 0 (attn_head_kernel path), logits + per-layer x + device argmax
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=512, flags=hip.FLAG_LAYER_TAPS)
+    o = orc.COracle(m)
+    for pos in range(5):
+        ref, lx = o.forward(toks[pos], pos, layer_x=True)
+        got = plan.tornadoVMForwardDecode(toks[pos], pos)
+        assert np.array_equal(got, ref), pos
+        assert np.array_equal(plan.layer_x(0), lx[0]), pos
+        assert plan.forward_decode_argmax(toks[pos], pos) == orc.argmax(ref)
+    # ---- pp512 -b 512 shape: one 512-token chunk, then decode at depth 512 (scores + softmax/PV pair, 9 score tiles)
+    plan.reset_kv()
+    o2 = orc.COracle(m)
+    plan.tornadoVMForwardBatchPrefill(toks[:512], 0)
+    o2.prefill(toks[:512], 0)
+    assert np.array_equal(plan.x(), o2.x())
+    for p in (0, 1, 127, 128, 300, 511):
+        k, v = plan.kv(0, p)
+        ko, vo = o2.kv(0, p)
+        assert np.array_equal(k, ko) and np.array_equal(v, vo), p
+    for pos in range(512, 516):
+        ref = o2.forward(toks[pos], pos)
+        assert np.array_equal(plan.tornadoVMForwardDecode(toks[pos], pos), ref), pos
+    # ---- a ragged second chunk on top (non-zero start, 128-token tile with 2 live tokens)
+    plan.tornadoVMForwardBatchPrefill(toks[516:518], 516)
+    o2.prefill(toks[516:518], 516)
+    assert np.array_equal(plan.x(), o2.x())
+    plan.freeTornadoExecutionPlan()
+
+
+def test_vocab_128256_projection(pkg, orc, planmod):
+    plan_mod, hip = planmod
+    m = _model(pkg, "8b-vocab", 103)
+    plan = plan_mod.HipMasterPlan(m)
+    o = orc.COracle(m)
+    for pos, t in enumerate([128000, 7, 128255]):            # begin-of-text id, a low id, the last row of the embedding
+        ref = o.forward(t, pos)
+        got = plan.tornadoVMForwardDecode(t, pos)
+        assert got.shape == (128256,)
+        assert np.array_equal(got, ref), pos
+        assert plan.forward_decode_argmax(t, pos) == orc.argmax(ref)
+    plan.freeTornadoExecutionPlan()
+
+
+def test_static_batched_decode_b32_b33_b64_qwen3_4b_shape(pkg, orc, planmod):
+    plan_mod, hip = planmod
+    m = _model(pkg, "qwen3-4b-2l", 107)
+    nseq = 64
+    plan = plan_mod.HipMasterPlan(m, prefill_batch_size=64, n_seqs=nseq)
+    oracles = [orc.COracle(m) for _ in range(nseq)]
+    rng = np.random.default_rng(11)
+    lens = [1 + (s % 5) for s in range(nseq)]
+    cur, pos = [], []
+    for s in range(nseq):
+        prompt = rng.integers(0, m.cfg.vocab, lens[s]).tolist()
+        plan.prefill_seq(s, prompt, 0)
+        oracles[s].prefill(prompt, 0)
+        cur.append(int(rng.integers(0, m.cfg.vocab)))
+        pos.append(lens[s])
+
+    def step(seqs):
+        logits, ids = plan.forward_decode_batch([cur[s] for s in seqs], seqs, [pos[s] for s in seqs])
+        for row, s in enumerate(seqs):
+            ref = oracles[s].forward(cur[s], pos[s])
+            assert np.array_equal(logits[row], ref), (len(seqs), row, s)
+            assert int(ids[row]) == orc.argmax(ref)
+            cur[s], pos[s] = int(ids[row]), pos[s] + 1          # greedy continuation per sequence
+
+    step(list(range(32)))                    # B = 32: the configs[4] batch, every MFMA column live
+    step(list(range(31, -1, -1)))            # same sequences, reversed batch rows
+    step(list(range(20, 53)))                # B = 33: 32-token-tile GEMM, second tile has one live token
+    step(list(range(nseq)))                  # B = 64: two full 32-token tiles
+    step(list(range(5)))                     # and back to a small batch
+    for s in (0, 31, 52, 63):
+        k, v = plan.kv_seq(s, 1, pos[s] - 1)
+        ko, vo = oracles[s].kv(1, pos[s] - 1)
+        assert np.array_equal(k, ko) and np.array_equal(v, vo), s
+    plan.freeTornadoExecutionPlan()

@@ -33,7 +33,8 @@ def test_c_oracle_matches_golden_bitwise(pkg, orc, fx, cfg, wt, seed):
 
 
 def test_numpy_and_c_agree_on_fresh_seed(pkg, orc):
-    for cfg, wt in [("tiny-llama-tied", 8), ("tiny-qwen3", 1), ("tiny-qwen2", 8), ("tiny-qwen2", 2)]:     # qwen2: q/k/v bias + NeoX RoPE
+    # qwen2: q/k/v bias + NeoX RoPE; mha-llama: n_heads == n_kv_heads (kvMul = 1), head_size 128
+    for cfg, wt in [("tiny-llama-tied", 8), ("tiny-qwen3", 1), ("tiny-qwen2", 8), ("tiny-qwen2", 2), ("mha-llama", 8)]:
         m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wt, seed=1234)
         co = orc.COracle(m)
         no = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope)

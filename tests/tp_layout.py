@@ -1,4 +1,5 @@
-"""Tensor-parallel partition of the forward pass (host-side description of what gl3_create / gl3_upload_tensor do).
+"""TEST HELPER — tensor-parallel partition of the forward pass (a Python description of what gl3_create / gl3_upload_tensor do,
+used only by tests/test_tp_gloo.py to check the scheme on CPU over gloo; the product code is csrc/gl3_api.hip).
 
 Every matrix is split by OUTPUT rows so that each dot product stays whole and in the reference's order on one
 rank (bit-identical results); activations are re-assembled with all-gathers.  The same table drives the C++
