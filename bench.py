@@ -13,12 +13,19 @@ growing KV cache, each returning the full logits to host memory (the reference's
 logits D2H, LlamaBench.java:234-254).  `value` = tokens / wall over exactly K steps (weights already in HBM).
 pp512 (batched prefill, -b 512, no logits) is timed the same way and reported beside it.
 
-N > 1 runs ONE model tensor-parallel over N GPUs (row/col split + one RCCL all-reduce per block), one process
-per GPU: total work is fixed, so "scaling": "strong".
+pp512 is also reported at -b 128 and at -b 1 (LlamaBench: with -b 1 every prompt token is a full decode step
+with logits + D2H).
 
-Extra objects: `roofline` — the dominant kernel (fused gate/up Q8_0 matvec) from an instrumented pass with HIP
-events around every launch; `cpu_baseline` — the C oracle (oracle/gl3_oracle.c, kind "port") on the host cores,
-bounded sample, rank 0 at N=1 only.
+N > 1 runs ONE model tensor-parallel over N GPUs, one process per GPU: every matrix is split by OUTPUT rows (heads /
+hidden units / dim rows / vocab rows) so each dot product stays whole and in the reference's order on one rank
+(bit-identical results), and the activations are re-assembled by 4 all-gathers per layer + 1 for the logits (DESIGN.md
+section 7).  Total work is fixed, so "scaling": "strong".
+
+Extra objects: `roofline` — the dominant decode kernel (fused gate/up Q8_0 matvec): `avg_us` = the kernel's own begin /
+end timestamps (hipExtLaunchKernel start / stop events: what rocprofv3 --kernel-trace reports) averaged over instrumented
+decode steps, `avg_us_back_to_back` = one HIP event pair around back-to-back launches over all layers; `roofline_pp` —
+the dominant batched-prefill kernel (gate/up int8-MFMA GEMM at 512 tokens); `cpu_baseline` — the C oracle
+(oracle/gl3_oracle.c, kind "port") on the host cores, bounded sample, rank 0 at N=1 only.
 """
 from __future__ import annotations
 
@@ -32,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X spec sheet (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured achievable)
+INT8_MFMA_PEAK_TOPS = 5000.0 # dense int8 MFMA (same rate class as FP8, ~5 P(FL)OP/s spec; micro-benchmark ceiling 3944 TOP/s)
 
 
 def main():
@@ -108,8 +116,12 @@ def main():
         for i in range(args.n_gen):
             plan.forward_decode(toks[i], i, copy=False)
 
-    def pp_rep():
-        plan.prefill(toks[:args.n_prompt], 0)
+    def pp_rep(batch=None):
+        if batch == 1:                      # LlamaBench -b 1: every prompt token is a full decode step (logits + D2H)
+            for i in range(args.n_prompt):
+                plan.forward_decode(toks[i], i, copy=False)
+        else:
+            plan.prefill(toks[:args.n_prompt], 0, batch=batch)
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -131,14 +143,18 @@ def main():
 
     tg_total, tg_samples = timed(tg_rep, args.steps, args.warmup)
     tg_tok_s = args.steps * args.n_gen / tg_total
-    pp = None
+    pp, pp_rows = None, []
     if not args.no_pp:
-        try:
-            pp_total, pp_samples = timed(pp_rep, args.steps, args.warmup)
-            pp = dict(tok_s=args.steps * args.n_prompt / pp_total, batch=args.batch,
-                      samples_tok_s=[args.n_prompt / s for s in pp_samples])
-        except hip.Gl3Error as e:
-            pp = dict(error=str(e))
+        for b in [args.batch] + [x for x in (128, 1) if x < args.batch]:
+            try:
+                steps_b = args.steps if b > 1 else max(1, min(args.steps, 2))          # -b 1 is 512 decode steps per repetition
+                pp_total, pp_samples = timed(lambda: pp_rep(b), steps_b, args.warmup if b > 1 else min(args.warmup, 1))
+                row = dict(tok_s=round(steps_b * args.n_prompt / pp_total, 2), batch=b, steps=steps_b,
+                           samples_tok_s=[round(args.n_prompt / s, 2) for s in pp_samples])
+            except hip.Gl3Error as e:
+                row = dict(batch=b, error=str(e))
+            pp_rows.append(row)
+        pp = pp_rows[0]
 
     # ---- roofline of the dominant kernel: instrumented (eager, HIP events per launch) decode steps mid-sequence
     acc = None
@@ -164,13 +180,37 @@ def main():
         r = plan.profile_kernel(name, iters=20 if name != "matvec_logits" else 200)
         kclass[name] = dict(avg_us=round(r["avg_us"], 3), bytes_per_launch=r["bytes_per_launch"], gbs=round(r["gbs"], 1),
                             frac_of_hbm_peak=round(r["gbs"] / HBM_PEAK_GBS, 4))
-    dom = kclass["matvec_gateup"]
+    dom = dict(kclass["matvec_gateup"])
+    dom["avg_us_back_to_back"] = dom["avg_us"]
+    if "matvec_gateup" in kern and args.wtype == "q8_0":      # kernel begin / end timestamps inside real decode steps
+        dom["avg_us"] = kern["matvec_gateup"]["avg_us"]
+        dom["gbs"] = kern["matvec_gateup"]["gbs"]
     kname = "matvec_q8t_kernel<PRO_RMS,EPI_SWIGLU> (fused RMSNorm + gate/up Q8_0 matvec + SwiGLU, %dx%d x2)" if args.wtype == "q8_0" else \
         "rmsnorm_f32_kernel + matvec_rl_kernel<" + WT + ",EPI_SWIGLU> (gate/up element-wise-chain matvec + SwiGLU, %dx%d x2)"
     roofline = dict(bound="hbm", kernel=kname % (cfg.hidden // world, cfg.dim),
                     achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(dom["gbs"] / HBM_PEAK_GBS, 4),
-                    traffic=None, avg_us=dom["avg_us"], bytes_per_launch=dom["bytes_per_launch"],
-                    method="HIP event pair around 20 sweeps x %d layers of back-to-back launches on the plan's stream" % cfg.n_layers)
+                    traffic=None, avg_us=dom["avg_us"], avg_us_back_to_back=dom["avg_us_back_to_back"], bytes_per_launch=dom["bytes_per_launch"],
+                    method="avg_us: start/stop events passed into each dispatch (hipExtLaunchKernel) = the kernel's own begin/end "
+                           "timestamps, mean over %d launches in %d instrumented decode steps at positions 64.. on the plan's stream; "
+                           "avg_us_back_to_back: one HIP event pair around 20 sweeps x %d layers of back-to-back launches (includes the "
+                           "inter-kernel boundary, activations L2-warm)" % (n_prof * cfg.n_layers, n_prof, cfg.n_layers))
+
+    # ---- batched prefill: the dominant GEMM (gate/up, int8 MFMA) and the other three, at the pp chunk size
+    roofline_pp = None
+    if pp is not None and "tok_s" in pp and args.wtype == "q8_0" and args.batch > 1:
+        pk = {}
+        for name in ("matvec_qkv", "matvec_wo", "matvec_gateup", "matvec_down"):
+            r = plan.profile_prefill_kernel(name, min(args.batch, args.n_prompt), iters=3)
+            pk[name.replace("matvec_", "gemm_")] = dict(avg_us=round(r["avg_us"], 2), int8_ops_per_launch=r["int8_ops_per_launch"], tops=round(r["tops"], 1),
+                                                        frac_of_int8_mfma_peak=round(r["tops"] / INT8_MFMA_PEAK_TOPS, 4))
+        g = pk["gemm_gateup"]
+        roofline_pp = dict(bound="mfma", kernel="pf_gemm_kernel<EPI_SWIGLU> (gate/up Q8_0 x int8-activation GEMM + SwiGLU, 2 x %dx%d x %d tokens)" %
+                           (cfg.hidden // world, cfg.dim, min(args.batch, args.n_prompt)),
+                           achieved=g["tops"], peak=INT8_MFMA_PEAK_TOPS, unit="TOP/s", frac=g["frac_of_int8_mfma_peak"], traffic=None,
+                           avg_us=g["avg_us"], int8_ops_per_launch=g["int8_ops_per_launch"], dtype="i8 x i8 -> i32 MFMA, f32 per-block scale-accumulate on the VALU",
+                           note="VALU-bound by construction: the reference's per-32-block f32 scale-and-accumulate needs >= 4 VALU lane-ops per "
+                                "output per block beside each 32-cycle MFMA; MfmaUtil from rocprofv3 --pmc is in profiles/ (separate pass)",
+                           gemms=pk, method="one HIP event pair around 3 sweeps x %d layers per GEMM class" % cfg.n_layers)
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read in-process; take the FETCH_SIZE figure of the
     # committed rocprofv3 --pmc pass of this same command (profiles/rNN_pmc_fetch_summary.csv, x2 gfx950 correction)
@@ -231,8 +271,8 @@ def main():
                                    (cfg.name, WT, args.n_gen, args.n_gen, args.n_prompt, args.batch),
                        "parallelism": "tp%d" % world if world > 1 else "single GPU", "ctx": cfg.ctx, "tokens": "java.util.Random(42)"},
             "tg_tok_s_mean": round(float(mean), 3), "tg_tok_s_stddev": round(sd, 3),
-            "pp": pp,
-            "roofline": roofline,
+            "pp": pp, "pp_rows": pp_rows,
+            "roofline": roofline, "roofline_pp": roofline_pp,
             "token_level": {"algorithmic_bytes_per_token": int(token_bytes), "achieved_gbs": round(token_gbs, 1),
                             "frac_of_hbm_peak": round(token_gbs / HBM_PEAK_GBS / max(world, 1), 4),
                             "roofline_tok_s": round(HBM_PEAK_GBS * 1e9 * world / token_bytes, 1)},

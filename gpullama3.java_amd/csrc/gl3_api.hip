@@ -41,10 +41,20 @@ static size_t matvec_smem(int pro, int epi, const Q8Mat& w) {
     return (size_t)w.ng * 4 * 32 + (size_t)w.ng * 4 * 4 + (pro == PRO_RMS ? (size_t)(w.k + 32) * 4 : 0) + (size_t)2 * nm * w.ng * 64 * 4 + 64;
 }
 
+// Instrumented steps (gl3_profile_decode) pass a start / stop event pair INTO the dispatch (hipExtLaunchKernel): the events
+// then carry the kernel's own begin / end timestamps — the quantity rocprofv3 --kernel-trace reports — instead of the
+// stream-order time between two recorded events, which also contains the host's launch latency in eager mode.
+#include <hip/hip_ext.h>
+template <typename K>
+static void launch_mv(gl3_ctx* ctx, K kernel, int wgs, int threads, size_t smem, const MatvecArgs& a) {
+    if (ctx->prof_ev0) hipExtLaunchKernelGGL(kernel, dim3(wgs), dim3(threads), (uint32_t)smem, ctx->stream, ctx->prof_ev0, ctx->prof_ev1, 0, a);
+    else hipLaunchKernelGGL(kernel, dim3(wgs), dim3(threads), smem, ctx->stream, a);
+}
+
 template <int PRO, int EPI>
-static void launch_matvec_t(const MatvecArgs& a, int wgs, size_t smem, hipStream_t s, bool nt) {
-    if (nt) hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, true>), dim3(wgs), dim3(mv_threads(4)), smem, s, a);
-    else hipLaunchKernelGGL((matvec_q8t_kernel<PRO, EPI, false>), dim3(wgs), dim3(mv_threads(4)), smem, s, a);
+static void launch_matvec_t(gl3_ctx* ctx, const MatvecArgs& a, int wgs, size_t smem, bool nt) {
+    if (nt) launch_mv(ctx, matvec_q8t_kernel<PRO, EPI, true>, wgs, mv_threads(4), smem, a);
+    else launch_mv(ctx, matvec_q8t_kernel<PRO, EPI, false>, wgs, mv_threads(4), smem, a);
 }
 
 template <int PRO, int EPI>
@@ -85,29 +95,38 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
     a.x = x; a.norm_w = norm_w; a.eps = ctx->d.rms_eps; a.out = out; a.resid_in = resid_in;
     const int wgs = w.nstrips < max_wgs ? w.nstrips : max_wgs;
     const size_t smem = matvec_smem(pro, epi, w);
-    if (pro == PRO_RMS && epi == EPI_STORE) launch_matvec_t<PRO_RMS, EPI_STORE>(a, wgs, smem, ctx->stream, nt);
+    if (pro == PRO_RMS && epi == EPI_STORE) launch_matvec_t<PRO_RMS, EPI_STORE>(ctx, a, wgs, smem, nt);
     else if (pro == PRO_QUANT && epi == EPI_RESID) {
         static const int wide_max = getenv("GL3_WIDE_STRIPS") ? atoi(getenv("GL3_WIDE_STRIPS")) : 256;
         if (w.nstrips <= wide_max && nt)      // one workgroup per CU: 8 producer wavefronts
-            hipLaunchKernelGGL((matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 8>), dim3(wgs), dim3(mv_threads(8)), smem, ctx->stream, a);
-        else launch_matvec_t<PRO_QUANT, EPI_RESID>(a, wgs, smem, ctx->stream, nt);
+            launch_mv(ctx, matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 8>, wgs, mv_threads(8), smem, a);
+        else launch_matvec_t<PRO_QUANT, EPI_RESID>(ctx, a, wgs, smem, nt);
     }
-    else launch_matvec_t<PRO_RMS, EPI_SWIGLU>(a, wgs, smem, ctx->stream, nt);
+    else launch_matvec_t<PRO_RMS, EPI_SWIGLU>(ctx, a, wgs, smem, nt);
 }
 
 // ------------------------------------------------------------------------------------------------ decode step
 struct Prof {
     gl3_ctx* ctx; gl3_kernel_times* kt; size_t n = 0; std::vector<int> klass;
-    void begin(int k, uint64_t bytes) {
+    bool ext = false;
+    // single_kernel: the class is exactly one Q8_0 matvec launch -> kernel begin / end timestamps (see launch_mv)
+    void begin(int k, uint64_t bytes, bool single_kernel = false) {
         if (!kt) return;
         if (ctx->ev.size() < 2 * (n + 1)) {
             ctx->ev.resize(2 * (n + 1));
             hipEventCreate(&ctx->ev[2 * n]); hipEventCreate(&ctx->ev[2 * n + 1]);
         }
-        hipEventRecord(ctx->ev[2 * n], ctx->stream);
+        ext = single_kernel;
+        if (ext) { ctx->prof_ev0 = ctx->ev[2 * n]; ctx->prof_ev1 = ctx->ev[2 * n + 1]; }
+        else hipEventRecord(ctx->ev[2 * n], ctx->stream);
         klass.push_back(k); kt->launches[k]++; kt->bytes[k] += bytes;
     }
-    void end() { if (kt) { hipEventRecord(ctx->ev[2 * n + 1], ctx->stream); ++n; } }
+    void end() {
+        if (!kt) return;
+        if (ext) ctx->prof_ev0 = ctx->prof_ev1 = nullptr;
+        else hipEventRecord(ctx->ev[2 * n + 1], ctx->stream);
+        ++n;
+    }
     void collect() {
         if (!kt) return;
         hipStreamSynchronize(ctx->stream);
@@ -195,6 +214,7 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
     hipStream_t s = ctx->stream;
     Prof pr{ctx, kt};
     const int rank = d.tp_rank;
+    const bool q8 = d.weight_type == GL3_TYPE_Q8_0;
     int32_t r;
 
     pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
@@ -205,7 +225,7 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
 
     for (int l = 0; l < d.n_layers; ++l) {
         gl3_layer& L = ctx->layers[l];
-        pr.begin(GL3_K_MATVEC_QKV, mv_bytes(L.wqkv) + d.dim * 4);
+        pr.begin(GL3_K_MATVEC_QKV, mv_bytes(L.wqkv) + d.dim * 4, q8);
         launch_matvec(ctx, PRO_RMS, EPI_STORE, L.wqkv, nullptr, ctx->x, L.attn_norm, ctx->qkv, nullptr);
         pr.end();
 
@@ -215,18 +235,18 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         if ((r = all_gather(ctx, GB_XB, ctx->q_dim_l, pr)) != GL3_OK) return r;
 
         // x[rows of this rank] += Wo[rows, :] . xb
-        pr.begin(GL3_K_MATVEC_WO, mv_bytes(L.wo));
+        pr.begin(GL3_K_MATVEC_WO, mv_bytes(L.wo), q8);
         launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->x + (size_t)rank * ctx->dim_l,
                       ctx->x + (size_t)rank * ctx->dim_l);
         pr.end();
         if ((r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
 
-        pr.begin(GL3_K_MATVEC_GATEUP, mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4);
+        pr.begin(GL3_K_MATVEC_GATEUP, mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4, q8);
         launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr);
         pr.end();
         if ((r = all_gather(ctx, GB_HB, ctx->hidden_l, pr)) != GL3_OK) return r;
 
-        pr.begin(GL3_K_MATVEC_DOWN, mv_bytes(L.w2));
+        pr.begin(GL3_K_MATVEC_DOWN, mv_bytes(L.w2), q8);
         launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->x + (size_t)rank * ctx->dim_l,
                       ctx->x + (size_t)rank * ctx->dim_l);
         pr.end();
@@ -234,7 +254,7 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         if (ctx->taps) hipMemcpyAsync(ctx->taps + (size_t)l * d.dim, ctx->x, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, s);
     }
     if (want_logits) {
-        pr.begin(GL3_K_MATVEC_LOGITS, mv_bytes(ctx->wcls) + d.dim * 4);
+        pr.begin(GL3_K_MATVEC_LOGITS, mv_bytes(ctx->wcls) + d.dim * 4, q8);
         launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm,
                       ctx->logits + (size_t)rank * ctx->vocab_l, nullptr);
         pr.end();
@@ -778,6 +798,13 @@ int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* o
         }
     }
     return GL3_OK;
+}
+
+int32_t gl3_profile_prefill_kernel(gl3_ctx* ctx, int32_t klass, int32_t n_tokens, int32_t iters, double* out_us, uint64_t* int8_ops_per_launch) {
+    if (!ctx || !out_us || iters <= 0) return GL3_E_ARG;
+    if (!ctx->finalized) GL3_FAIL(GL3_E_STATE, "profile before gl3_finalize");
+    if (klass < GL3_K_MATVEC_QKV || klass > GL3_K_MATVEC_DOWN) GL3_FAIL(GL3_E_ARG, "kernel class is not a batched-prefill GEMM");
+    return gl3_prefill_profile(ctx, klass, n_tokens, iters, out_us, int8_ops_per_launch);
 }
 
 int32_t gl3_get_x(gl3_ctx* ctx, float* out) {

@@ -95,6 +95,7 @@ struct gl3_ctx {
     gl3_local_group* lgrp = nullptr;
     bool use_rccl = false;                        // tensor-parallel gathers are active (RCCL or local group)
     std::vector<hipEvent_t> ev;
+    hipEvent_t prof_ev0 = nullptr, prof_ev1 = nullptr;   // non-null: the next matvec launch carries them as start / stop events
     // metrics
     double plan_ms = 0, copy_in_ms = 0;
     std::string err;
@@ -135,5 +136,6 @@ float* gl3_prefill_buf(gl3_ctx* ctx, int which);
 int32_t gl3_prefill_alloc(gl3_ctx* ctx);
 void gl3_prefill_free(gl3_ctx* ctx);
 int32_t gl3_prefill_run(gl3_ctx* ctx, int32_t seq, const int32_t* tokens, int32_t n, int32_t start_pos);
+int32_t gl3_prefill_profile(gl3_ctx* ctx, int klass, int n, int iters, double* out_us, uint64_t* int8_ops);
 int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t* seq_ids, const int32_t* positions, int32_t n,
                              float* logits_out, int32_t* argmax_out);

@@ -448,13 +448,19 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
     const int q4 = hs >> 2;
     const int nrows_cache = owns_pos ? (t1 - 1 - t0) : (t1 - t0);
     const int nk4 = nrows_cache * q4;                         // float4s of the K tile that come from the cache
+    // Staging registers: every element is initialised, the load condition is wave-uniform and the index is clamped — a
+    // lane-predicated `if (i < nk4) kreg[u] = load` leaves the array in scratch memory and serialises the loads behind
+    // one s_waitcnt each (seen in the ISA: private_segment 272 B, 14 us instead of 5 for a 128-row tile).
     constexpr int KMAX = 16;
     float4 kreg[KMAX];
     const int per = (nk4 + nthr - 1) / nthr;
 #pragma unroll
     for (int u = 0; u < KMAX; ++u) {
-        const int i = t + u * nthr;
-        if (u < per && i < nk4) kreg[u] = *reinterpret_cast<const float4*>(a.kcache + (size_t)(t0 + i / q4) * a.kv_dim + kvh * hs + 4 * (i % q4));
+        kreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < per) {
+            const int i = min(t + u * nthr, nk4 - 1);
+            kreg[u] = *reinterpret_cast<const float4*>(a.kcache + (size_t)(t0 + i / q4) * a.kv_dim + kvh * hs + 4 * (i % q4));
+        }
     }
     for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.bq ? a.qkv[(kvh * kvmul) * hs + i] + a.bq[(kvh * kvmul) * hs + i] : a.qkv[(kvh * kvmul) * hs + i];
     for (int i = t; i < half; i += nthr) { cr_s[i] = a.rope_cr[(size_t)pos * half + i]; ci_s[i] = a.rope_ci[(size_t)pos * half + i]; }
@@ -531,7 +537,7 @@ __host__ __device__ inline size_t attn_head_smem(int hs) {
     return ((size_t)hs + (size_t)AF_MAXN * (hs + 4) + (size_t)AF_MAXN * hs + (size_t)AF_MAXN + hs + 16) * 4;
 }
 
-static __global__ __launch_bounds__(256) void attn_head_kernel(const AttnArgs a) {
+static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads, half = hs >> 1, pitch = hs + 4, q4 = hs >> 2;
     const int q4sh = __ffs(q4) - 1;                  // head sizes are powers of two
@@ -550,17 +556,18 @@ static __global__ __launch_bounds__(256) void attn_head_kernel(const AttnArgs a)
     // ---- one global round trip: cached K / V rows (both in flight at once), raw q / k / v of this token, the RoPE row
     const int nk4 = pos * q4;
     constexpr int KMAX = 16;                         // 127 rows x 32 float4 / 256 threads (head_size 128)
-    float4 kreg[KMAX], vreg[KMAX];
+    float4 kreg[KMAX], vreg[KMAX];                   // initialised + uniform condition + clamped index: stays in VGPRs (see attn_scores_kernel)
     const bool in_regs = nk4 <= KMAX * 256;
-    if (in_regs) {
+    const int per = in_regs ? (nk4 + 255) >> 8 : 0;
 #pragma unroll
-        for (int u = 0; u < KMAX; ++u) {
-            const int i = t + u * 256;
-            if (i < nk4) {
-                const size_t off = (size_t)(i >> q4sh) * a.kv_dim + kvh * hs + 4 * (i & (q4 - 1));
-                kreg[u] = *reinterpret_cast<const float4*>(a.kcache + off);
-                vreg[u] = *reinterpret_cast<const float4*>(a.vcache + off);
-            }
+    for (int u = 0; u < KMAX; ++u) {
+        kreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        vreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < per) {
+            const int i = min(t + u * 256, nk4 - 1);
+            const size_t off = (size_t)(i >> q4sh) * a.kv_dim + kvh * hs + 4 * (i & (q4 - 1));
+            kreg[u] = *reinterpret_cast<const float4*>(a.kcache + off);
+            vreg[u] = *reinterpret_cast<const float4*>(a.vcache + off);
         }
     }
     for (int i = t; i < hs; i += 256) q_s[i] = a.bq ? a.qkv[h * hs + i] + a.bq[h * hs + i] : a.qkv[h * hs + i];
@@ -670,11 +677,15 @@ static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnA
     const float* vbase = a.vcache + kvh * hs + j0;
     constexpr int SU = PV_ROWS * 4 / 256;         // thread = (row t>>2 + 64u, column quad t&3)
     float4 sreg[SU];
-    auto stage_issue = [&](int r0, int nr) {
+#pragma unroll
+    for (int u = 0; u < SU; ++u) sreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto stage_issue = [&](int r0, int nr) {         // uniform condition + clamped row: sreg stays in VGPRs, loads issue back to back
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
-            const int row = (t >> 2) + 64 * u;
-            if (row < nr) sreg[u] = *reinterpret_cast<const float4*>(vbase + (size_t)(r0 + row) * a.kv_dim + 4 * (t & 3));
+            if (64 * u < nr) {
+                const int row = min((t >> 2) + 64 * u, nr - 1);
+                sreg[u] = *reinterpret_cast<const float4*>(vbase + (size_t)(r0 + row) * a.kv_dim + 4 * (t & 3));
+            }
         }
     };
     auto stage_commit = [&](int nr) {

@@ -1137,3 +1137,44 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
     GL3_HIP(hipStreamSynchronize(s));
     return GL3_OK;
 }
+
+
+// Average device time of one batched-prefill GEMM class at n tokens: one HIP event pair around `iters` sweeps over every
+// layer's weights (GEMMs are 70-250 us, the ~1.5 us boundary is noise).  int8_ops = 2 * rows * K * n per launch (MFMA work
+// only; the f32 scale-and-accumulate epilogue the reference arithmetic needs is not counted).
+int32_t gl3_prefill_profile(gl3_ctx* ctx, int klass, int n, int iters, double* out_us, uint64_t* int8_ops) {
+    gl3_prefill_state* p = ctx->pf;
+    const gl3_model_desc& d = ctx->d;
+    if (!p) GL3_FAIL(GL3_E_UNSUPPORTED, "batched prefill needs max_batch > 1 and Q8_0 weights");
+    if (n < 1 || n > p->max_batch) GL3_FAIL(GL3_E_ARG, "token count outside 1..max_batch");
+    GL3_HIP(hipSetDevice(d.device));
+    const int qkv_dim = ctx->q_dim_l + 2 * ctx->kv_dim_l;
+    auto sweep = [&]() {
+        for (int l = 0; l < d.n_layers; ++l) {
+            gl3_layer& L = ctx->layers[l];
+            switch (klass) {
+            case GL3_K_MATVEC_QKV: launch_gemm<EPI_STORE>(ctx, L.wqkv, nullptr, n, p->QKV, qkv_dim); break;
+            case GL3_K_MATVEC_WO: launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, p->X, ctx->dim_l); break;
+            case GL3_K_MATVEC_GATEUP: launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, p->HB, ctx->hidden_l); break;
+            default: launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, p->X, ctx->dim_l); break;
+            }
+        }
+    };
+    hipEvent_t e0, e1;
+    GL3_HIP(hipEventCreate(&e0)); GL3_HIP(hipEventCreate(&e1));
+    sweep();
+    GL3_HIP(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters; ++i) sweep();
+    GL3_HIP(hipEventRecord(e1, ctx->stream));
+    GL3_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    GL3_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *out_us = (double)ms * 1e3 / ((double)iters * d.n_layers);
+    if (int8_ops) {
+        const gl3_layer& L = ctx->layers[0];
+        const Q8Mat& w = klass == GL3_K_MATVEC_QKV ? L.wqkv : klass == GL3_K_MATVEC_WO ? L.wo : klass == GL3_K_MATVEC_GATEUP ? L.w1 : L.w2;
+        *int8_ops = (uint64_t)2 * w.rows * w.k * n * (klass == GL3_K_MATVEC_GATEUP ? 2 : 1);
+    }
+    return GL3_OK;
+}

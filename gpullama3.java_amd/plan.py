@@ -165,10 +165,10 @@ class HipMasterPlan:
         hip.check(hip.lib().gl3_forward_decode(self._ctx, token, position, None, C.byref(self._arg)), self._ctx)
         return int(self._arg.value)
 
-    def prefill(self, tokens, start_pos: int = 0):
-        """LlamaBench.prefill (J/bench/LlamaBench.java:258-273): chunks of max_batch."""
+    def prefill(self, tokens, start_pos: int = 0, batch: int | None = None):
+        """LlamaBench.prefill (J/bench/LlamaBench.java:258-273): chunks of `batch` (llama-bench -b; default max_batch)."""
         tokens = list(tokens)
-        b = max(1, self.max_batch)
+        b = max(1, min(batch or self.max_batch, max(1, self.max_batch)))
         for off in range(0, len(tokens), b):
             self.tornadoVMForwardBatchPrefill(tokens[off:off + b], start_pos + off)
 
@@ -206,6 +206,12 @@ class HipMasterPlan:
         us, nb = C.c_double(), C.c_uint64()
         hip.check(hip.lib().gl3_profile_kernel(self._ctx, hip.K_NAMES.index(klass), iters, C.byref(us), C.byref(nb)), self._ctx)
         return dict(avg_us=us.value, bytes_per_launch=nb.value, gbs=nb.value / us.value / 1e3)
+
+    def profile_prefill_kernel(self, klass: str, n_tokens: int, iters: int = 3) -> dict:
+        """One batched-prefill GEMM class at n_tokens tokens (see gl3_profile_prefill_kernel): device time and int8 TOP/s."""
+        us, ops = C.c_double(), C.c_uint64()
+        hip.check(hip.lib().gl3_profile_prefill_kernel(self._ctx, hip.K_NAMES.index(klass), n_tokens, iters, C.byref(us), C.byref(ops)), self._ctx)
+        return dict(avg_us=us.value, int8_ops_per_launch=ops.value, tops=ops.value / us.value / 1e6)
 
     def init_ms(self):
         a, b = C.c_double(), C.c_double()

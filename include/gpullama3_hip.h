@@ -201,6 +201,13 @@ GL3_API int32_t gl3_profile_decode(gl3_ctx* ctx, int32_t token, int32_t position
  * klass: GL3_K_MATVEC_*; out_us = mean per launch (includes the ~1.5 us inter-kernel boundary). */
 GL3_API int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* out_us, uint64_t* bytes_per_launch);
 
+/* The batched-prefill GEMM of one class (GL3_K_MATVEC_QKV / WO / GATEUP / DOWN) at n_tokens <= max_batch tokens: mean device
+ * time per launch over `iters` sweeps of all layers, and the int8 multiply-add work of one launch (2 * rows * K * n_tokens
+ * operations; the activations are whatever the last prefill left in the plan's buffers — timing only, the residual stream
+ * is clobbered). */
+GL3_API int32_t gl3_profile_prefill_kernel(gl3_ctx* ctx, int32_t klass, int32_t n_tokens, int32_t iters, double* out_us,
+                                           uint64_t* int8_ops_per_launch);
+
 /* RunMetrics slots (TornadoVMMasterPlanSingleToken.java:40-54): plan creation and weight copy-in, ms. */
 GL3_API int32_t gl3_get_init_ms(gl3_ctx* ctx, double* plan_ms, double* copy_in_ms);
 

@@ -6,6 +6,7 @@
 #include <vector>
 #include <string>
 #define GL3_MV_TIMING 1
+#define GL3_SS_TIMING 1
 #include "gl3_decode_kernels.h"
 using namespace gl3;
 
@@ -72,6 +73,7 @@ int main(int argc, char** argv) {
             else if (sh.pro == PRO_QUANT) us = run<PRO_QUANT, EPI_RESID>(a, g, smem, iters, wb, w2b);
             else us = run<PRO_RMS, EPI_SWIGLU>(a, g, smem, iters, wb, w2b);
             { long long st[32]; hipMemcpyFromSymbol(st, HIP_SYMBOL(gl3::gl3_mv_stamp), sizeof(st)); printf("   WG0 cycles: xload %lld sumsq %lld quant %lld | prod0 %lld bar %lld | chain0 wait->start %lld chain %lld\n", st[1]-st[0], st[2]-st[1], st[3]-st[2], st[4]-st[3], st[5]-st[4], st[16]-st[3], st[17]-st[16]); }
+            if (sh.pro == PRO_RMS) { long long ss[16]; hipMemcpyFromSymbol(ss, HIP_SYMBOL(gl3::gl3_ss_stamp), sizeof(ss)); printf("   exact-sum phases (cycles): predictor %lld | translations %lld | scan %lld | lists %lld | replay-gather %lld | replay %lld | bcast %lld\n", ss[1]-ss[0], ss[2]-ss[1], ss[3]-ss[2], ss[4]-ss[3], ss[5]-ss[4], ss[6]-ss[5], ss[7]-ss[6]); }
             printf("%s rows %6d k %5d wgs %4d : %8.2f us  %7.1f GB/s (%.1f%% of 8 TB/s)\n", sh.name, sh.rows, sh.k, g, us, algo / us / 1e3, algo / us / 1e3 / 80.0);
         }
         for (auto p : wb) hipFree(p);
