@@ -75,11 +75,16 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
     dist = None
+    transport = os.environ.get("GL3_TP_TRANSPORT", "p2p")        # p2p: peer-write all-gather over xGMI (csrc/gl3_tp.hip); rccl: fall-back
+    if os.environ.get("GL3_BENCH_SHARE_GPU"):                    # test hook: every rank on device 0 of a one-GPU box (IPC between processes)
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # control plane only (handle / id exchange, barriers, max-over-ranks of the timing): gloo.  The data path between the
+        # GPUs is the library's own transport; RCCL is initialised inside the library when GL3_TP_TRANSPORT=rccl.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -89,11 +94,16 @@ def main():
         return bench_decode_batch(args, cfg, synth, plan_mod, pkg, torch, np, dev)
     t0 = time.time()
     keep_host = (world == 1 and not args.no_cpu_baseline)
-    uid = None
-    if world > 1:
+    uid, exchange = None, None
+    if world > 1 and transport == "rccl":
         obj = [plan_mod.make_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(obj, src=0)
         uid = obj[0]
+    elif world > 1:
+        def exchange(handle):
+            out = [None] * world
+            dist.all_gather_object(out, handle)
+            return out
     wtype = {"q8_0": synth.GGML_Q8_0, "f16": synth.GGML_F16, "q4_0": synth.GGML_Q4_0}[args.wtype]
     WT = args.wtype.upper()
     bpe = {"q8_0": 34 / 32, "f16": 2.0, "q4_0": 18 / 32}[args.wtype]          # weight bytes per element
@@ -102,7 +112,9 @@ def main():
     else:
         model = synth.StreamModel(cfg, wtype, synth.iter_torch(cfg, wtype=wtype, seed=args.seed, device=dev))
     plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(model, prefill_batch_size=args.batch, device=local_rank,
-                                                           tp_rank=rank, tp_size=world, unique_id=uid)
+                                                           tp_rank=rank, tp_size=world, unique_id=uid, p2p_exchange=exchange)
+    if dist is not None:
+        dist.barrier()                      # every rank's plan exists and is attached before the first gather
     torch.cuda.empty_cache()
     setup_s = time.time() - t0
     toks = pkg.javarand.bench_tokens(cfg.vocab, args.n_prompt + args.n_gen)
@@ -136,7 +148,7 @@ def main():
         barrier()
         total = time.perf_counter() - t_start
         if dist is not None:
-            t = torch.tensor([total], device=dev, dtype=torch.float64)
+            t = torch.tensor([total], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             total = float(t.item())
         return total, samples
@@ -269,7 +281,8 @@ def main():
             "config": {"workload": "%s %s random-weight GGUF-layout model, tg%d at depth 0 (one step = %d decode tokens, logits D2H "
                                    "inside the timed region); pp%d -b %d reported beside it" %
                                    (cfg.name, WT, args.n_gen, args.n_gen, args.n_prompt, args.batch),
-                       "parallelism": "tp%d" % world if world > 1 else "single GPU", "ctx": cfg.ctx, "tokens": "java.util.Random(42)"},
+                       "parallelism": ("tp%d (row split, %s all-gathers)" % (world, "peer-write xGMI" if transport != "rccl" else "RCCL")) if world > 1 else "single GPU",
+                       "ctx": cfg.ctx, "tokens": "java.util.Random(42)"},
             "tg_tok_s_mean": round(float(mean), 3), "tg_tok_s_stddev": round(sd, 3),
             "pp": pp, "pp_rows": pp_rows,
             "roofline": roofline, "roofline_pp": roofline_pp,

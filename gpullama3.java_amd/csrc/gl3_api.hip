@@ -139,47 +139,10 @@ struct Prof {
 
 static uint64_t mv_bytes(const Q8Mat& w) { return w.algo_bytes() + (uint64_t)w.k * 4 + (uint64_t)w.rows * 4; }
 
-// Tensor parallelism keeps the reference's arithmetic bit for bit: every matrix is split by OUTPUT rows (heads /
-// hidden units / dim rows / vocab rows), so each dot product is still evaluated in full, in order, by one rank;
-// the activations are re-assembled with an in-place all-gather (4 per layer + 1 for the logits).
-float* gl3_gather_buf(gl3_ctx* c, int which) {
-    if (which >= GB_PF_X) return gl3_prefill_buf(c, which);
-    return which == GB_XB ? c->xb : which == GB_X ? c->x : which == GB_HB ? c->hb : c->logits;
-}
-
-static int32_t all_gather_impl(gl3_ctx* ctx, int which, size_t count_per_rank) {
-    float* buf = gl3_gather_buf(ctx, which);
-    if (ctx->lgrp) {                                   // in-process test transport (see gl3_local_group)
-        gl3_local_group* g = ctx->lgrp;
-        const int me = ctx->d.tp_rank;
-        GL3_HIP(hipEventRecord(g->ready[me], ctx->stream));
-        g->barrier();                                  // every rank's slice is enqueued
-        for (int p = 0; p < g->n; ++p) {
-            if (p == me) continue;
-            GL3_HIP(hipStreamWaitEvent(ctx->stream, g->ready[p], 0));
-            GL3_HIP(hipMemcpyAsync(buf + (size_t)p * count_per_rank, gl3_gather_buf(g->ranks[p], which) + (size_t)p * count_per_rank,
-                                   count_per_rank * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        }
-        GL3_HIP(hipEventRecord(g->done[me], ctx->stream));
-        g->barrier();                                  // nobody overwrites a slice a peer is still copying
-        for (int p = 0; p < g->n; ++p)
-            if (p != me) GL3_HIP(hipStreamWaitEvent(ctx->stream, g->done[p], 0));
-        g->barrier();                                  // events may be re-recorded from here on
-    } else {
-        GL3_NCCL(ncclAllGather(buf + (size_t)ctx->d.tp_rank * count_per_rank, buf, count_per_rank, ncclFloat, ctx->comm, ctx->stream));
-    }
-    return GL3_OK;
-}
-
-int32_t gl3_all_gather(gl3_ctx* ctx, int which, size_t count_per_rank) {
-    if (!ctx->use_rccl) return GL3_OK;
-    return all_gather_impl(ctx, which, count_per_rank);
-}
-
 static int32_t all_gather(gl3_ctx* ctx, int which, int count_per_rank, Prof& pr) {
     if (!ctx->use_rccl) return GL3_OK;
     pr.begin(GL3_K_COLLECTIVE, 0);
-    const int32_t r = all_gather_impl(ctx, which, (size_t)count_per_rank);
+    const int32_t r = gl3_all_gather(ctx, which, (size_t)count_per_rank);
     if (r != GL3_OK) return r;
     pr.end();
     return GL3_OK;
@@ -368,12 +331,19 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRY(dmalloc(ctx, &ctx->vcache, kvn));
     TRYHIP(hipMemset(ctx->kcache, 0, kvn * 4));
     TRYHIP(hipMemset(ctx->vcache, 0, kvn * 4));
-    TRY(dmalloc(ctx, &ctx->x, d.dim));
     TRY(dmalloc(ctx, &ctx->xn, d.dim));
     TRY(dmalloc(ctx, &ctx->qkv, ctx->q_dim_l + 2 * ctx->kv_dim_l));
-    TRY(dmalloc(ctx, &ctx->xb, ctx->q_dim));
-    TRY(dmalloc(ctx, &ctx->hb, d.hidden));
-    TRY(dmalloc(ctx, &ctx->logits, d.vocab));
+    if (ctx->use_rccl) {          // gathered buffers live in the tensor-parallel arena (one allocation the peers map, gl3_tp.hip)
+        if (tp > GL3_MAX_TP) return bail(GL3_E_UNSUPPORTED, "tp_size above 16");
+        TRY(gl3_tp_arena_alloc(ctx));
+        ctx->x = (float*)(ctx->arena.base + ctx->arena.off[GB_X]); ctx->xb = (float*)(ctx->arena.base + ctx->arena.off[GB_XB]);
+        ctx->hb = (float*)(ctx->arena.base + ctx->arena.off[GB_HB]); ctx->logits = (float*)(ctx->arena.base + ctx->arena.off[GB_LOGITS]);
+    } else {
+        TRY(dmalloc(ctx, &ctx->x, d.dim));
+        TRY(dmalloc(ctx, &ctx->xb, ctx->q_dim));
+        TRY(dmalloc(ctx, &ctx->hb, d.hidden));
+        TRY(dmalloc(ctx, &ctx->logits, d.vocab));
+    }
     TRY(dmalloc(ctx, &ctx->att, (size_t)ctx->heads_l * d.ctx));
     TRYHIP((allow_big_lds<PRO_RMS, EPI_STORE>()));
     TRYHIP((allow_big_lds<PRO_QUANT, EPI_RESID>()));
@@ -427,8 +397,10 @@ void gl3_destroy(gl3_ctx* ctx) {
         f(L.wqkv.w); f(L.wo.w); f(L.w1.w); f(L.w3.w); f(L.w2.w);
         f(L.attn_norm); f(L.ffn_norm); f(L.qnorm); f(L.knorm); f(L.bq); f(L.bk); f(L.bv);
     }
-    f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->x); f(ctx->xn); f(ctx->qkv);
-    f(ctx->xb); f(ctx->hb); f(ctx->logits); f(ctx->att); f(ctx->dyn); f(ctx->dyn_seq); f(ctx->argmax); f(ctx->taps); f(ctx->staging);
+    f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->xn); f(ctx->qkv);
+    if (!ctx->arena.base) { f(ctx->x); f(ctx->xb); f(ctx->hb); f(ctx->logits); }
+    gl3_tp_arena_free(ctx);
+    f(ctx->att); f(ctx->dyn); f(ctx->dyn_seq); f(ctx->argmax); f(ctx->taps); f(ctx->staging);
     if (ctx->h_dyn) hipHostFree(ctx->h_dyn);
     if (ctx->h_logits) hipHostFree(ctx->h_logits);
     if (ctx->h_argmax) hipHostFree(ctx->h_argmax);
@@ -553,56 +525,6 @@ int32_t gl3_upload_rope(gl3_ctx* ctx, const float* cr, const float* ci, uint64_t
     return GL3_OK;
 }
 
-int32_t gl3_tp_unique_id(void* out, uint64_t bytes) {
-    if (!out || bytes < sizeof(ncclUniqueId)) return GL3_E_ARG;
-    ncclUniqueId id;
-    if (ncclGetUniqueId(&id) != ncclSuccess) return GL3_E_RCCL;
-    memset(out, 0, bytes);
-    memcpy(out, &id, sizeof(id));
-    return GL3_OK;
-}
-
-int32_t gl3_local_group_create(int32_t n, gl3_local_group** out) {
-    if (n < 1 || !out) return GL3_E_ARG;
-    gl3_local_group* g = new gl3_local_group();
-    g->n = n; g->ranks.assign(n, nullptr); g->ready.resize(n); g->done.resize(n);
-    for (int i = 0; i < n; ++i) {
-        if (hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming) != hipSuccess) { delete g; return GL3_E_HIP; }
-    }
-    *out = g;
-    return GL3_OK;
-}
-
-void gl3_local_group_destroy(gl3_local_group* g) {
-    if (!g) return;
-    for (auto e : g->ready) hipEventDestroy(e);
-    for (auto e : g->done) hipEventDestroy(e);
-    delete g;
-}
-
-int32_t gl3_tp_attach_local(gl3_ctx* ctx, gl3_local_group* g) {
-    if (!ctx || !g) return GL3_E_ARG;
-    if (ctx->finalized) GL3_FAIL(GL3_E_STATE, "attach after finalize");
-    if (g->n != ctx->d.tp_size) GL3_FAIL(GL3_E_ARG, "local group size differs from tp_size");
-    std::lock_guard<std::mutex> lk(g->mu);
-    g->ranks[ctx->d.tp_rank] = ctx;
-    ctx->lgrp = g;
-    ctx->use_rccl = true;
-    return GL3_OK;
-}
-
-int32_t gl3_tp_init(gl3_ctx* ctx, const void* unique_id, uint64_t bytes) {
-    if (!ctx) return GL3_E_ARG;
-    if (!unique_id || bytes < sizeof(ncclUniqueId)) GL3_FAIL(GL3_E_ARG, "bad RCCL unique id");
-    if (ctx->finalized) GL3_FAIL(GL3_E_STATE, "tp_init after finalize");
-    GL3_HIP(hipSetDevice(ctx->d.device));
-    ncclUniqueId id;
-    memcpy(&id, unique_id, sizeof(id));
-    GL3_NCCL(ncclCommInitRank(&ctx->comm, ctx->d.tp_size, id, ctx->d.tp_rank));
-    return GL3_OK;
-}
-
 static int32_t capture(gl3_ctx* ctx, bool want_logits, bool short_ctx, hipGraph_t* g, hipGraphExec_t* ge) {
     GL3_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     int32_t r = enqueue_decode(ctx, want_logits, nullptr, short_ctx);
@@ -627,7 +549,9 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
     for (int l = 0; l < d.n_layers; ++l)
         if ((ctx->layers[l].have & need_l) != need_l) GL3_FAIL(GL3_E_STATE, "layer " + std::to_string(l) + ": tensors missing");
     if (!ctx->rope_cr) GL3_FAIL(GL3_E_STATE, "rope tables not uploaded");
-    if (ctx->use_rccl && !ctx->comm && !ctx->lgrp) GL3_FAIL(GL3_E_STATE, "tensor parallel plan without gl3_tp_init");
+    if (ctx->use_rccl && ctx->transport == GL3_TP_NONE)
+        GL3_FAIL(GL3_E_STATE, "tensor parallel plan without gl3_tp_p2p_attach / gl3_tp_init / gl3_tp_attach_local");
+    { int32_t r = gl3_tp_local_resolve(ctx); if (r != GL3_OK) return r; }
     if (!(ctx->have_global & (1u << GL3_T_OUTPUT))) {   // tied: wcls = this rank's vocab rows of token_embd
         ctx->wcls = ctx->emb;
         ctx->wcls.rows = ctx->vocab_l;
@@ -638,7 +562,7 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
     }
     if (ctx->staging) { hipFree(ctx->staging); ctx->staging = nullptr; ctx->staging_bytes = 0; }
     ctx->finalized = true;
-    if (!(d.flags & GL3_FLAG_NO_GRAPH) && !env_flag("GL3_NO_GRAPH", false) && !ctx->lgrp) {
+    if (!(d.flags & GL3_FLAG_NO_GRAPH) && !env_flag("GL3_NO_GRAPH", false)) {
         const double t0 = now_ms();
         int32_t r = capture(ctx, true, false, &ctx->graph, &ctx->graph_exec);
         if (r == GL3_OK && ctx->fused_attn_ok) r = capture(ctx, true, true, &ctx->graph_s, &ctx->graph_exec_s);
@@ -678,6 +602,7 @@ int32_t gl3_forward_decode(gl3_ctx* ctx, int32_t token, int32_t pos, float* logi
     }
     if (logits_out) GL3_HIP(hipMemcpyAsync(ctx->h_logits, ctx->logits, (size_t)ctx->d.vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
     GL3_HIP(hipStreamSynchronize(ctx->stream));
+    if ((r = gl3_tp_check(ctx)) != GL3_OK) return r;
     if (logits_out) memcpy(logits_out, ctx->h_logits, (size_t)ctx->d.vocab * 4);
     if (argmax_out) *argmax_out = *ctx->h_argmax;
     return GL3_OK;
@@ -720,7 +645,7 @@ int32_t gl3_forward_prefill_seq(gl3_ctx* ctx, int32_t seq, const int32_t* tokens
     ctx->dyn_cur = ctx->dyn;
     if (r != GL3_OK) return r;
     GL3_HIP(hipStreamSynchronize(ctx->stream));
-    return GL3_OK;
+    return gl3_tp_check(ctx);
 }
 
 int32_t gl3_forward_prefill(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t start_pos) {

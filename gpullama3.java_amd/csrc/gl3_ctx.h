@@ -35,14 +35,15 @@ struct gl3_layer {
     uint32_t have = 0;       // bit per tensor id
 };
 
-// test-only tensor-parallel transport: ranks are host threads of one process sharing one device
+// In-process tensor-parallel group (tests): ranks are host threads of one process sharing one device.  The ranks run the
+// SAME peer-write gather kernel as separate processes do over xGMI; only the way a rank learns its peers' arena addresses
+// differs (plain pointers here, hipIpcOpenMemHandle there).
 struct gl3_local_group {
     int n = 0;
     std::mutex mu;
     std::condition_variable cv;
     int arrived = 0, generation = 0;
     std::vector<struct gl3_ctx*> ranks;
-    std::vector<hipEvent_t> ready, done;
     void barrier() {
         std::unique_lock<std::mutex> lk(mu);
         const int gen = generation;
@@ -50,6 +51,21 @@ struct gl3_local_group {
         else cv.wait(lk, [&] { return generation != gen; });
     }
 };
+
+constexpr int GL3_MAX_TP = 16;
+enum { GL3_TP_NONE = 0, GL3_TP_RCCL = 1, GL3_TP_P2P = 2 };
+
+// Tensor-parallel arena: ONE device allocation per rank that holds every gathered activation buffer plus the transport's
+// header, at the same offsets on every rank, so a peer addresses "rank p's copy of buffer b" as peer_base[p] + off[b].
+//   header: u32 flags[GL3_MAX_TP] (flags[p] = number of gathers rank p has pushed into this arena; written by the peers),
+//           u32 seq (gathers completed by this rank), u32 arrive (workgroup ticket of the running gather kernel)
+struct gl3_tp_arena {
+    uint8_t* base = nullptr;
+    size_t bytes = 0;
+    size_t off[8] = {};                           // byte offset of buffer GB_*; 0 = not allocated
+    int pf_logits_rows = 0;                       // capacity of the batched-decode logits buffer (rows)
+};
+constexpr size_t GL3_ARENA_HDR = 256, GL3_ARENA_SEQ = 64, GL3_ARENA_ARRIVE = 68;
 
 struct gl3_ctx {
     gl3_model_desc d{};
@@ -93,7 +109,12 @@ struct gl3_ctx {
     bool fused_attn_ok = false;                   // shape admits attn_head_kernel (one launch per layer for positions < AF_MAXN)
     ncclComm_t comm = nullptr;
     gl3_local_group* lgrp = nullptr;
-    bool use_rccl = false;                        // tensor-parallel gathers are active (RCCL or local group)
+    bool use_rccl = false;                        // tensor-parallel gathers are active (any transport)
+    int transport = GL3_TP_NONE;                  // GL3_TP_RCCL (gl3_tp_init) or GL3_TP_P2P (gl3_tp_p2p_attach / gl3_tp_attach_local)
+    gl3_tp_arena arena;
+    uint8_t* peer_base[GL3_MAX_TP] = {};          // arena of every rank as mapped into this process (peer_base[tp_rank] = arena.base)
+    void* ipc_opened[GL3_MAX_TP] = {};            // mappings to close (hipIpcCloseMemHandle)
+    uint32_t* h_tp_err = nullptr;                 // pinned, device-visible: set by a gather kernel whose peers never arrived
     std::vector<hipEvent_t> ev;
     hipEvent_t prof_ev0 = nullptr, prof_ev1 = nullptr;   // non-null: the next matvec launch carries them as start / stop events
     // metrics
@@ -130,6 +151,10 @@ struct gl3_ctx {
 enum { GB_XB = 0, GB_X = 1, GB_HB = 2, GB_LOGITS = 3, GB_PF_X = 4, GB_PF_AO = 5, GB_PF_HB = 6, GB_PF_LOGITS = 7 };
 float* gl3_gather_buf(gl3_ctx* c, int which);
 int32_t gl3_all_gather(gl3_ctx* ctx, int which, size_t count_per_rank);
+int32_t gl3_tp_arena_alloc(gl3_ctx* ctx);
+void gl3_tp_arena_free(gl3_ctx* ctx);
+int32_t gl3_tp_local_resolve(gl3_ctx* ctx);
+int32_t gl3_tp_check(gl3_ctx* ctx);      // after a stream sync: GL3_E_RCCL if a gather timed out
 
 // gl3_prefill.hip
 float* gl3_prefill_buf(gl3_ctx* ctx, int which);

@@ -31,6 +31,7 @@ struct gl3_prefill_state {
     int32_t* seqpos = nullptr;          // [2][M]: sequence id, position of every token of the step
     float* LOGITS = nullptr;            // [rows][vocab], grown on demand (batched decode)
     int logits_rows = 0;
+    bool in_arena = false;              // X / AO / HB / LOGITS are slices of the tensor-parallel arena (not freed here)
     int32_t* amax = nullptr;            // [M]
     int maxk = 0;
 };
@@ -911,12 +912,19 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     if (d.dim > p->maxk) p->maxk = d.dim;
     p->maxk = (p->maxk + 127) & ~127;
     GL3_HIP(hipMalloc((void**)&p->tokens, M * sizeof(int32_t)));
-    GL3_HIP(hipMalloc((void**)&p->X, M * d.dim * 4));
+    if (ctx->arena.base && ctx->arena.off[GB_PF_X]) {      // tensor parallel: the gathered activations live in the arena the peers map
+        uint8_t* b = ctx->arena.base;
+        p->X = (float*)(b + ctx->arena.off[GB_PF_X]); p->AO = (float*)(b + ctx->arena.off[GB_PF_AO]); p->HB = (float*)(b + ctx->arena.off[GB_PF_HB]);
+        p->LOGITS = (float*)(b + ctx->arena.off[GB_PF_LOGITS]); p->logits_rows = ctx->arena.pf_logits_rows;
+        p->in_arena = true;
+    } else {
+        GL3_HIP(hipMalloc((void**)&p->X, M * d.dim * 4));
+        GL3_HIP(hipMalloc((void**)&p->AO, M * ctx->q_dim * 4));
+        GL3_HIP(hipMalloc((void**)&p->HB, M * d.hidden * 4));
+    }
     GL3_HIP(hipMalloc((void**)&p->XQ, M * p->maxk));
     GL3_HIP(hipMalloc((void**)&p->XS, M * (p->maxk / 32) * 4));
     GL3_HIP(hipMalloc((void**)&p->QKV, M * (ctx->q_dim + 2 * ctx->kv_dim) * 4));
-    GL3_HIP(hipMalloc((void**)&p->AO, M * ctx->q_dim * 4));
-    GL3_HIP(hipMalloc((void**)&p->HB, M * d.hidden * 4));
     GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
     GL3_HIP(hipMalloc((void**)&p->seqpos, 2 * M * sizeof(int32_t)));
     GL3_HIP(hipMalloc((void**)&p->amax, M * sizeof(int32_t)));
@@ -940,7 +948,8 @@ void gl3_prefill_free(gl3_ctx* ctx) {
     gl3_prefill_state* p = ctx->pf;
     if (!p) return;
     auto f = [](void* q) { if (q) hipFree(q); };
-    f(p->tokens); f(p->X); f(p->XQ); f(p->XS); f(p->QKV); f(p->AO); f(p->HB); f(p->ATT); f(p->seqpos); f(p->LOGITS); f(p->amax);
+    f(p->tokens); f(p->XQ); f(p->XS); f(p->QKV); f(p->ATT); f(p->seqpos); f(p->amax);
+    if (!p->in_arena) { f(p->X); f(p->AO); f(p->HB); f(p->LOGITS); }
     delete p;
     ctx->pf = nullptr;
 }
@@ -1096,7 +1105,7 @@ int32_t gl3_prefill_run(gl3_ctx* ctx, int32_t seq, const int32_t* tokens, int32_
     // keep the decode path's x in step with the last prefilled token (parity tap gl3_get_x)
     hipLaunchKernelGGL(pf_unchunk_row_kernel, dim3(4), dim3(256), 0, ctx->stream, p->X, n - 1, d.dim, ctx->dim_l, n, ctx->x);
     GL3_HIP(hipStreamSynchronize(ctx->stream));
-    return GL3_OK;
+    return gl3_tp_check(ctx);
 }
 
 // One decode step of n independent sequences = the prefill machinery over (token, sequence, position) triples +
@@ -1106,6 +1115,7 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
     gl3_prefill_state* p = ctx->pf;
     const gl3_model_desc& d = ctx->d;
     GL3_HIP(hipSetDevice(d.device));
+    if (p->logits_rows < n && p->in_arena) GL3_FAIL(GL3_E_UNSUPPORTED, "tensor-parallel static-batched decode is limited to 64 sequences per step");
     if (p->logits_rows < n) {
         if (p->LOGITS) hipFree(p->LOGITS);
         p->LOGITS = nullptr; p->logits_rows = 0;
@@ -1135,7 +1145,7 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
     }
     GL3_HIP(hipGetLastError());
     GL3_HIP(hipStreamSynchronize(s));
-    return GL3_OK;
+    return gl3_tp_check(ctx);
 }
 
 

@@ -1,0 +1,254 @@
+// gl3_tp.hip — tensor parallelism over the 8 GPUs of one node: the per-rank arena of gathered buffers, the
+// peer-write all-gather over xGMI, its set-up (IPC handles between processes, plain pointers inside one process) and the RCCL
+// fall-back.
+//
+// The reference has no multi-GPU path (docs/TORNADOVM_TRANSFORMER_OPTIMIZATIONS.md:70 lists it as open), so this is the
+// north star's extension.  Every matrix is split by OUTPUT rows (heads / hidden units / dim rows / vocab rows): each dot
+// product stays whole and in the reference's order on one rank, so tensor-parallel results are bit-identical to the
+// single-GPU / CPU result; the activations are re-assembled by in-place all-gathers (buf = [tp][count_per_rank], rank r owns
+// chunk r): xb, x, hb, x per layer (+ the logits), the same points in batched prefill and static-batched decode.
+//
+// Transport (GL3_TP_P2P).  xGMI is point-to-point (7 links per GPU), and at decode the gathered slices are 2-7 KB per rank:
+// the cost is latency, not bandwidth.  RCCL's all-gather costs 10-20 us per call at this size (protocol hand-shakes, one
+// launch per collective, channel set-up); here one small kernel per gather
+//   1. PUSHES this rank's slice straight into every peer's copy of the buffer (16-byte stores through the peer mapping,
+//      targets rotated so the 7 links are used at once),
+//   2. makes the stores visible system-wide (__threadfence_system) and bumps a per-source flag in every peer's arena
+//      (one 4-byte system-scope store per peer: "rank me has completed its k-th gather"),
+//   3. polls its OWN arena's flags until all peers have completed their k-th gather, then ends — the consumer is the next
+//      kernel on the stream, so the kernel boundary orders the peers' data before its loads.
+// k counts gathers since plan creation in device memory (replay-safe: nothing about the step is baked into a captured
+// graph).  No acknowledgement is needed: a rank can run at most one gather ahead of a peer's push, and consecutive gathers
+// never target the same buffer (xb, x, hb, x, ...), so a slice is never overwritten while a slower rank still reads it.
+// The kernel is an ordinary launch: it is captured into the decode hipGraph like any other node.
+// Expected cost: ~1.5 us boundary + ~3-5 us (store round trip over xGMI + flag propagation), 4 per layer + 1 per token.
+// No hardware curve exists until the driver's 8-GPU run (SCALE_rNN.json); in CI the SAME kernel runs between ranks that are
+// host threads of one process on one GPU (gl3_local_group) and between processes sharing one GPU over IPC handles.
+#include <cstring>
+
+#include "gl3_ctx.h"
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ------------------------------------------------------------------------------------------------ arena
+int32_t gl3_tp_arena_alloc(gl3_ctx* ctx) {
+    const gl3_model_desc& d = ctx->d;
+    gl3_tp_arena& A = ctx->arena;
+    size_t o = GL3_ARENA_HDR;
+    auto put = [&](int which, size_t floats) { A.off[which] = o; o += align256(floats * 4); };
+    put(GB_X, d.dim); put(GB_XB, (size_t)d.n_heads * d.head_size); put(GB_HB, d.hidden); put(GB_LOGITS, d.vocab);
+    if (d.max_batch > 1 && d.weight_type == GL3_TYPE_Q8_0) {
+        const size_t M = d.max_batch;
+        A.pf_logits_rows = d.max_batch < 64 ? d.max_batch : 64;
+        put(GB_PF_X, M * d.dim); put(GB_PF_AO, M * d.n_heads * d.head_size); put(GB_PF_HB, M * d.hidden);
+        put(GB_PF_LOGITS, (size_t)A.pf_logits_rows * d.vocab);
+    }
+    A.bytes = o;
+    // Uncached device memory (what RCCL uses for its own peer buffers): a peer's writes arrive over xGMI behind the owner's
+    // L2, so the owner must never hold a stale line.  GL3_TP_ARENA=cached selects plain hipMalloc (kernel-boundary
+    // invalidation only) for experiments.
+    const char* mode = getenv("GL3_TP_ARENA");
+    hipError_t e = (mode && !strcmp(mode, "cached")) ? hipMalloc((void**)&A.base, A.bytes)
+                                                     : hipExtMallocWithFlags((void**)&A.base, A.bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { A.base = nullptr; ctx->err = std::string("tensor-parallel arena: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? GL3_E_OOM : GL3_E_HIP; }
+    GL3_HIP(hipMemset(A.base, 0, A.bytes));
+    GL3_HIP(hipHostMalloc((void**)&ctx->h_tp_err, sizeof(uint32_t)));
+    *ctx->h_tp_err = 0;
+    ctx->peer_base[d.tp_rank] = A.base;
+    return GL3_OK;
+}
+
+void gl3_tp_arena_free(gl3_ctx* ctx) {
+    for (int p = 0; p < GL3_MAX_TP; ++p)
+        if (ctx->ipc_opened[p]) { hipIpcCloseMemHandle(ctx->ipc_opened[p]); ctx->ipc_opened[p] = nullptr; }
+    if (ctx->arena.base) hipFree(ctx->arena.base);
+    ctx->arena.base = nullptr;
+    if (ctx->h_tp_err) hipHostFree(ctx->h_tp_err);
+    ctx->h_tp_err = nullptr;
+}
+
+float* gl3_gather_buf(gl3_ctx* c, int which) {
+    if (which >= GB_PF_X) return gl3_prefill_buf(c, which);
+    return which == GB_XB ? c->xb : which == GB_X ? c->x : which == GB_HB ? c->hb : c->logits;
+}
+
+// ------------------------------------------------------------------------------------------------ peer-write all-gather
+struct TpGatherArgs {
+    uint8_t* peer[GL3_MAX_TP];   // arena of every rank as mapped here; peer[me] = own arena
+    size_t buf_off;              // byte offset of the gathered buffer inside every arena
+    size_t n4;                   // float4s per rank slice
+    int me, tp;
+    unsigned spin_limit;         // polls before giving up
+    uint32_t* err;               // host-pinned word: set to 1 on a timeout
+};
+
+typedef float v4f_tp __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(1024) void tp_gather_kernel(const TpGatherArgs a) {
+    const int t = threadIdx.x;
+    uint8_t* own = a.peer[a.me];
+    uint32_t* seq = reinterpret_cast<uint32_t*>(own + GL3_ARENA_SEQ);
+    uint32_t* arrive = reinterpret_cast<uint32_t*>(own + GL3_ARENA_ARRIVE);
+    // ---- 1. push my slice into every peer's buffer (peer order rotated by rank: all links busy at once)
+    const v4f_tp* src = reinterpret_cast<const v4f_tp*>(own + a.buf_off) + (size_t)a.me * a.n4;
+    for (size_t i = (size_t)blockIdx.x * 1024 + t; i < a.n4; i += (size_t)gridDim.x * 1024) {
+        const v4f_tp v = src[i];
+        for (int j = 1; j < a.tp; ++j) {
+            const int p = (a.me + j) % a.tp;
+            reinterpret_cast<v4f_tp*>(a.peer[p] + a.buf_off)[(size_t)a.me * a.n4 + i] = v;
+        }
+    }
+    __threadfence_system();                  // my stores have reached the peers' memory
+    __syncthreads();
+    if (t != 0) return;
+    // ---- 2. the last workgroup to finish publishes the flag, 3. and waits for the peers
+    const unsigned ticket = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket != gridDim.x - 1) return;
+    __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t k = __hip_atomic_load(seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    __threadfence_system();
+    for (int j = 1; j < a.tp; ++j) {
+        const int p = (a.me + j) % a.tp;
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.peer[p]) + a.me, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const uint32_t* flags = reinterpret_cast<const uint32_t*>(own);
+    bool ok = true;
+    for (int j = 1; j < a.tp && ok; ++j) {
+        const int p = (a.me + j) % a.tp;
+        unsigned spins = 0;
+        // signed distance: a peer may already be one gather ahead
+        while ((int32_t)(__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - k) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > a.spin_limit) { ok = false; break; }
+        }
+    }
+    if (!ok) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(seq, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: drop anything cached before the peers' data landed
+}
+
+static int32_t all_gather_p2p(gl3_ctx* ctx, int which, size_t count_per_rank) {
+    const gl3_model_desc& d = ctx->d;
+    if (!ctx->arena.off[which]) GL3_FAIL(GL3_E_STATE, "gathered buffer is not part of the tensor-parallel arena");
+    if (count_per_rank % 4) GL3_FAIL(GL3_E_UNSUPPORTED, "tensor-parallel slice must be a multiple of 4 floats");
+    TpGatherArgs a{};
+    for (int p = 0; p < d.tp_size; ++p) a.peer[p] = ctx->peer_base[p];
+    a.buf_off = ctx->arena.off[which]; a.n4 = count_per_rank / 4; a.me = d.tp_rank; a.tp = d.tp_size;
+    static const unsigned limit = getenv("GL3_TP_SPIN_LIMIT") ? (unsigned)atol(getenv("GL3_TP_SPIN_LIMIT")) : 20000000u;   // x ~0.5 us: ~10 s
+    a.spin_limit = limit; a.err = ctx->h_tp_err;
+    size_t wgs = (a.n4 * 16 + 65535) / 65536;           // 64 KB of slice per workgroup
+    wgs = wgs < 1 ? 1 : wgs > 64 ? 64 : wgs;
+    hipLaunchKernelGGL(tp_gather_kernel, dim3((unsigned)wgs), dim3(1024), 0, ctx->stream, a);
+    return GL3_OK;
+}
+
+int32_t gl3_all_gather(gl3_ctx* ctx, int which, size_t count_per_rank) {
+    if (!ctx->use_rccl) return GL3_OK;
+    if (ctx->transport == GL3_TP_P2P) return all_gather_p2p(ctx, which, count_per_rank);
+    float* buf = gl3_gather_buf(ctx, which);
+    GL3_NCCL(ncclAllGather(buf + (size_t)ctx->d.tp_rank * count_per_rank, buf, count_per_rank, ncclFloat, ctx->comm, ctx->stream));
+    return GL3_OK;
+}
+
+int32_t gl3_tp_check(gl3_ctx* ctx) {
+    if (ctx->h_tp_err && *ctx->h_tp_err) {
+        *ctx->h_tp_err = 0;
+        GL3_FAIL(GL3_E_RCCL, "tensor-parallel all-gather timed out waiting for a peer rank");
+    }
+    return GL3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ set-up (C-ABI)
+extern "C" {
+
+int32_t gl3_tp_unique_id(void* out, uint64_t bytes) {
+    if (!out || bytes < sizeof(ncclUniqueId)) return GL3_E_ARG;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return GL3_E_RCCL;
+    memset(out, 0, bytes);
+    memcpy(out, &id, sizeof(id));
+    return GL3_OK;
+}
+
+int32_t gl3_tp_init(gl3_ctx* ctx, const void* unique_id, uint64_t bytes) {
+    if (!ctx) return GL3_E_ARG;
+    if (!unique_id || bytes < sizeof(ncclUniqueId)) GL3_FAIL(GL3_E_ARG, "bad RCCL unique id");
+    if (ctx->finalized) GL3_FAIL(GL3_E_STATE, "tp_init after finalize");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    GL3_NCCL(ncclCommInitRank(&ctx->comm, ctx->d.tp_size, id, ctx->d.tp_rank));
+    ctx->transport = GL3_TP_RCCL;
+    return GL3_OK;
+}
+
+int32_t gl3_tp_p2p_handle(gl3_ctx* ctx, void* out, uint64_t bytes) {
+    if (!ctx) return GL3_E_ARG;
+    if (!out || bytes < sizeof(hipIpcMemHandle_t)) GL3_FAIL(GL3_E_ARG, "handle buffer shorter than 64 bytes");
+    if (!ctx->arena.base) GL3_FAIL(GL3_E_STATE, "plan has no tensor-parallel arena (tp_size == 1)");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    hipIpcMemHandle_t h;
+    GL3_HIP(hipIpcGetMemHandle(&h, ctx->arena.base));
+    memset(out, 0, bytes);
+    memcpy(out, &h, sizeof(h));
+    return GL3_OK;
+}
+
+int32_t gl3_tp_p2p_attach(gl3_ctx* ctx, const void* handles, uint64_t bytes) {
+    if (!ctx) return GL3_E_ARG;
+    const int tp = ctx->d.tp_size;
+    if (!handles || bytes < (uint64_t)tp * sizeof(hipIpcMemHandle_t)) GL3_FAIL(GL3_E_ARG, "need tp_size x 64 bytes of IPC handles in rank order");
+    if (ctx->finalized) GL3_FAIL(GL3_E_STATE, "attach after finalize");
+    if (!ctx->arena.base) GL3_FAIL(GL3_E_STATE, "plan has no tensor-parallel arena");
+    if (tp > GL3_MAX_TP) GL3_FAIL(GL3_E_UNSUPPORTED, "tp_size above 16");
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    for (int p = 0; p < tp; ++p) {
+        if (p == ctx->d.tp_rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const uint8_t*)handles + (size_t)p * sizeof(h), sizeof(h));
+        void* ptr = nullptr;
+        GL3_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+        ctx->ipc_opened[p] = ptr;
+        ctx->peer_base[p] = (uint8_t*)ptr;
+    }
+    ctx->transport = GL3_TP_P2P;
+    return GL3_OK;
+}
+
+int32_t gl3_local_group_create(int32_t n, gl3_local_group** out) {
+    if (n < 1 || n > GL3_MAX_TP || !out) return GL3_E_ARG;
+    gl3_local_group* g = new gl3_local_group();
+    g->n = n; g->ranks.assign(n, nullptr);
+    *out = g;
+    return GL3_OK;
+}
+
+void gl3_local_group_destroy(gl3_local_group* g) { delete g; }
+
+int32_t gl3_tp_attach_local(gl3_ctx* ctx, gl3_local_group* g) {
+    if (!ctx || !g) return GL3_E_ARG;
+    if (ctx->finalized) GL3_FAIL(GL3_E_STATE, "attach after finalize");
+    if (g->n != ctx->d.tp_size) GL3_FAIL(GL3_E_ARG, "local group size differs from tp_size");
+    if (!ctx->arena.base) GL3_FAIL(GL3_E_STATE, "plan has no tensor-parallel arena");
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->ranks[ctx->d.tp_rank] = ctx;
+    ctx->lgrp = g;
+    ctx->use_rccl = true;
+    ctx->transport = GL3_TP_P2P;
+    return GL3_OK;
+}
+
+}  // extern "C"
+
+// gl3_finalize: every rank of a local group has attached once all have passed this barrier; resolve the peers' arenas
+int32_t gl3_tp_local_resolve(gl3_ctx* ctx) {
+    gl3_local_group* g = ctx->lgrp;
+    if (!g) return GL3_OK;
+    g->barrier();
+    for (int p = 0; p < g->n; ++p) {
+        if (!g->ranks[p]) GL3_FAIL(GL3_E_STATE, "local group: a rank never attached");
+        if (g->ranks[p]->arena.bytes != ctx->arena.bytes) GL3_FAIL(GL3_E_STATE, "local group: ranks were created with different shapes");
+        ctx->peer_base[p] = g->ranks[p]->arena.base;
+    }
+    return GL3_OK;
+}

@@ -30,8 +30,12 @@ def _p(a: np.ndarray):
 
 class HipMasterPlan:
     def __init__(self, model, prefill_batch_size: int = 1, device: int = 0, tp_rank: int = 0, tp_size: int = 1,
-                 flags: int = 0, unique_id: bytes | None = None, local_group=None, n_seqs: int = 1):
-        """model: synth.SynthModel-like — cfg, tensors {gguf name: (raw uint8, ggml_type, rows, cols)}, rope (cr, ci)."""
+                 flags: int = 0, unique_id: bytes | None = None, local_group=None, n_seqs: int = 1, p2p_exchange=None):
+        """model: synth.SynthModel-like — cfg, tensors {gguf name: (raw uint8, ggml_type, rows, cols)}, rope (cr, ci).
+
+        Tensor parallel (tp_size > 1), one of: ``p2p_exchange`` — a callable that takes this rank's 64-byte IPC handle and
+        returns the handles of ALL ranks in rank order (e.g. torch.distributed.all_gather_object): peer-write all-gathers over
+        xGMI, the default transport; ``unique_id`` — RCCL fall-back; ``local_group`` — ranks are threads of this process (tests)."""
         L = hip.lib()
         c = model.cfg
         self.cfg = c
@@ -45,6 +49,13 @@ class HipMasterPlan:
         try:
             if local_group is not None:
                 hip.check(L.gl3_tp_attach_local(self._ctx, local_group), self._ctx)
+            elif p2p_exchange is not None:
+                mine = C.create_string_buffer(64)
+                hip.check(L.gl3_tp_p2p_handle(self._ctx, mine, 64), self._ctx)
+                every = list(p2p_exchange(mine.raw))
+                assert len(every) == tp_size and all(len(h) == 64 for h in every), "p2p_exchange must return tp_size 64-byte handles"
+                blob = C.create_string_buffer(b"".join(every), 64 * tp_size)
+                hip.check(L.gl3_tp_p2p_attach(self._ctx, blob, 64 * tp_size), self._ctx)
             elif tp_size > 1 or flags & hip.FLAG_FORCE_RCCL:
                 assert unique_id is not None, "tensor parallel plan needs the RCCL unique id from rank 0"
                 buf = C.create_string_buffer(unique_id, len(unique_id))

@@ -141,14 +141,22 @@ GL3_API int32_t gl3_upload_tensor(gl3_ctx* ctx, int32_t tensor_id, int32_t layer
  * n = rows * head_size/2 floats, rows >= ctx. */
 GL3_API int32_t gl3_upload_rope(gl3_ctx* ctx, const float* cr, const float* ci, uint64_t n);
 
-/* Join a tensor-parallel group: `unique_id` is the RCCL id made by gl3_tp_unique_id on rank 0 and
- * broadcast by the host (torch.distributed / any side channel).  Must precede gl3_finalize. */
+/* Join a tensor-parallel group (one process per GPU; must precede gl3_finalize).  Two transports for the in-place
+ * all-gathers of the row-split plan:
+ *   peer-write over xGMI (default): every rank exports the IPC handle of its arena of gathered buffers
+ *     (gl3_tp_p2p_handle, 64 bytes), the host exchanges the handles through any side channel (torch.distributed
+ *     all_gather_object, a file, a socket) and hands all tp_size of them, in rank order, to gl3_tp_p2p_attach; one small
+ *     kernel per gather then stores this rank's slice straight into the peers' buffers (csrc/gl3_tp.hip);
+ *   RCCL (fall-back): `unique_id` is the id made by gl3_tp_unique_id on rank 0 and broadcast by the host. */
+GL3_API int32_t gl3_tp_p2p_handle(gl3_ctx* ctx, void* out, uint64_t bytes);                  /* bytes >= 64 */
+GL3_API int32_t gl3_tp_p2p_attach(gl3_ctx* ctx, const void* handles, uint64_t bytes);        /* tp_size x 64 bytes */
 GL3_API int32_t gl3_tp_unique_id(void* out, uint64_t bytes);   /* bytes >= 128 */
 GL3_API int32_t gl3_tp_init(gl3_ctx* ctx, const void* unique_id, uint64_t bytes);
 
-/* In-process tensor-parallel group for TESTS on one GPU: `n` plans (one host thread each, same device) exchange their
- * slices with device-to-device copies instead of RCCL, exercising exactly the same row split, kernel arguments and
- * gather points.  Create once, pass to every rank's gl3_tp_attach_local before gl3_finalize, destroy after the plans. */
+/* In-process tensor-parallel group for TESTS on one GPU: `n` plans (one host thread each, same device) run the same
+ * peer-write gather kernel, row split, kernel arguments and gather points as `n` processes on `n` GPUs; only the peers'
+ * arena addresses are exchanged as plain pointers instead of IPC handles.  Create once, pass to every rank's
+ * gl3_tp_attach_local before gl3_finalize (which waits for all ranks), destroy after the plans. */
 typedef struct gl3_local_group gl3_local_group;
 GL3_API int32_t gl3_local_group_create(int32_t n, gl3_local_group** out);
 GL3_API void gl3_local_group_destroy(gl3_local_group* g);

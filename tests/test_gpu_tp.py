@@ -144,3 +144,66 @@ def test_static_batched_decode_under_row_split(pkg, orc, planmod):
             for s in range(nseq):
                 assert np.array_equal(lg[s], ref[s][i]), (r, i, s)
                 assert int(ids[s]) == orc.argmax(ref[s][i])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The production transport between PROCESSES: every rank exports the IPC handle of its arena, the handles travel over
+# torch.distributed (gloo), peers are mapped with hipIpcOpenMemHandle and the gather kernel stores into them.  On the
+# one-GPU test box all ranks share device 0 (on the 8-GPU node the same code path maps the peers over xGMI).
+def _p2p_worker(rank, world, port, cfg_name, wtype, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from importlib import import_module
+    pkg = ge.load_package()
+    plan_mod = import_module(ge.PKG_NAME + ".plan")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def exchange(handle):
+        out = [None] * world
+        dist.all_gather_object(out, handle)
+        return out
+
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg_name], wtype=wtype, seed=17)
+    plan = plan_mod.HipMasterPlan(m, prefill_batch_size=16 if wtype == 8 else 1, tp_rank=rank, tp_size=world, p2p_exchange=exchange)
+    dist.barrier()
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 12)
+    plan.prefill(toks[:5], 0)                                     # batched (Q8_0) or token-by-token prefill under TP
+    out = [plan.forward_decode(toks[p], p) for p in range(5, 12)]
+    ids = [plan.forward_decode_argmax(toks[11], 11)]
+    dist.barrier()                                                # nobody unmaps an arena a peer may still be writing
+    plan.freeTornadoExecutionPlan()
+    q.put((rank, out, ids))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg,world,wtype", [("mid-llama", 2, 8), ("mid-llama", 4, 2)])
+def test_peer_write_transport_between_processes(pkg, orc, cfg, world, wtype):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_p2p_worker, args=(r, world, port, cfg, wtype, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = {}
+    for _ in range(world):
+        r, out, ids = q.get(timeout=600)
+        got[r] = (out, ids)
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=17)
+    o = orc.COracle(m)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 12)
+    o.prefill(toks[:5], 0)
+    ref = [o.forward(toks[p], p) for p in range(5, 12)]
+    for r in range(world):
+        for i in range(7):
+            assert np.array_equal(got[r][0][i], ref[i]), (r, i)
+        assert got[r][1][0] == orc.argmax(ref[6])
