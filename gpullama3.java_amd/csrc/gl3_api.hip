@@ -20,6 +20,7 @@
 #include "gl3_ctx.h"
 #include "gl3_decode_kernels.h"
 #include "gl3_rowlane_kernels.h"
+#include "gl3_veclane_kernels.h"
 
 using namespace gl3;
 
@@ -73,6 +74,21 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
             const size_t sm = (size_t)(w.k + 32) * 4 + ss_scratch_bytes(w.k) + 64;
             hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3(1), dim3(256), sm, s, x, w.k, norm_w, ctx->d.rms_eps, ctx->xn);
             x = ctx->xn;
+        }
+        if (w.vl) {                   // Vector-API order (8 accumulator lanes per row): lane = (row, accumulator), HBM-bound
+            VlArgs v{};
+            v.w = w.w; v.w2 = w2 ? w2->w : nullptr; v.rows = w.rows; v.k = w.k; v.x = x; v.out = out; v.resid_in = resid_in;
+            const dim3 vg(((w.rows + 7) / 8 + VL_WAVES - 1) / VL_WAVES), vb(64 * VL_WAVES);
+            const size_t vs = vl_smem_bytes(w.k);
+#define GL3_VL(WT_) \
+            do { \
+                if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_STORE>), vg, vb, vs, s, v); \
+                else if (epi == EPI_RESID) hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_RESID>), vg, vb, vs, s, v); \
+                else hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_SWIGLU>), vg, vb, vs, s, v); \
+            } while (0)
+            if (w.fmt == GL3_TYPE_F16) GL3_VL(WT_F16); else GL3_VL(WT_Q4_0);
+#undef GL3_VL
+            return;
         }
         RlArgs a{};
         a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.k = w.k; a.x = x; a.out = out; a.resid_in = resid_in;
@@ -182,6 +198,8 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
 
     pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
     if (ctx->emb.fmt == GL3_TYPE_Q8_0) hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn_cur, ctx->x);
+    else if (ctx->emb.vl && ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_vl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x);
+    else if (ctx->emb.vl) hipLaunchKernelGGL((embed_vl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x);
     else if (ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_rl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x);
     else hipLaunchKernelGGL((embed_rl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x);
     pr.end();
@@ -237,6 +255,7 @@ static int32_t dmalloc(gl3_ctx* ctx, T** p, size_t n) {
 
 static int32_t alloc_mat(gl3_ctx* ctx, Q8Mat& m, int rows, int k) {
     m.rows = rows; m.k = k; m.ng = ((k / 32) + 3) / 4; m.nstrips = (rows + 15) / 16; m.fmt = ctx->d.weight_type;
+    m.vl = m.fmt != GL3_TYPE_Q8_0 && !(ctx->d.flags & GL3_FLAG_SCALAR_DOT);
     GL3_HIP(hipMalloc((void**)&m.w, m.bytes()));
     if (m.fmt != GL3_TYPE_Q8_0) GL3_HIP(hipMemset(m.w, 0, m.bytes()));      // padded rows of the last 64-row group
     return GL3_OK;
@@ -287,6 +306,8 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
         return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0 matrices need inner dimensions that are multiples of 64");
     if (d.weight_type != GL3_TYPE_Q8_0 && rl_smem_bytes(d.hidden > d.dim ? d.hidden : d.dim, EPI_STORE) > 150 * 1024)
         return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0: activation vector does not fit in LDS");
+    if (d.weight_type == GL3_TYPE_Q4_0 && !(d.flags & GL3_FLAG_SCALAR_DOT) && (d.dim % 256 || d.hidden % 256 || (d.n_heads * d.head_size) % 256))
+        return bail(GL3_E_UNSUPPORTED, "Q4_0 in Vector-API order needs inner dimensions that are multiples of 256 (or GL3_FLAG_SCALAR_DOT)");
     if (d.weight_type != GL3_TYPE_Q8_0 && d.tp_size > 1 && (d.vocab / d.tp_size) % 64)
         return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0 tensor parallel needs vocab/tp_size to be a multiple of 64");
     if (d.dim <= 0 || d.dim % 32 || d.hidden % 32 || d.n_layers <= 0 || d.n_heads <= 0 || d.n_kv_heads <= 0 ||
@@ -433,6 +454,14 @@ static int32_t upload_q8(gl3_ctx* ctx, Q8Mat& m, int dst_row0, int sub_rows, con
     if (m.fmt != GL3_TYPE_Q8_0) {
         int32_t r = stage(ctx, h, (size_t)sub_rows * row_bytes);
         if (r != GL3_OK) return r;
+        if (m.vl) {
+            const long total = (long)sub_rows * (m.fmt == GL3_TYPE_F16 ? k_full / 64 : k_full / 256) * 8;
+            const dim3 grid((unsigned)((total + 255) / 256));
+            if (m.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((repack_vl_kernel<WT_F16>), grid, dim3(256), 0, ctx->stream, ctx->staging, m.w, sub_rows, k_full, dst_row0);
+            else hipLaunchKernelGGL((repack_vl_kernel<WT_Q4_0>), grid, dim3(256), 0, ctx->stream, ctx->staging, m.w, sub_rows, k_full, dst_row0);
+            GL3_HIP(hipStreamSynchronize(ctx->stream));
+            return GL3_OK;
+        }
         const long total = (long)sub_rows * (m.fmt == GL3_TYPE_F16 ? k_full / 8 : nb_full);
         const dim3 grid((unsigned)((total + 255) / 256));
         if (m.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((repack_rl_kernel<WT_F16>), grid, dim3(256), 0, ctx->stream, ctx->staging, m.w, sub_rows, k_full, dst_row0);
@@ -557,6 +586,7 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
         ctx->wcls.rows = ctx->vocab_l;
         ctx->wcls.nstrips = (ctx->vocab_l + 15) / 16;
         if (ctx->emb.fmt == GL3_TYPE_Q8_0) ctx->wcls.w = ctx->emb.w + (size_t)(d.tp_rank * ctx->vocab_l / 16) * ctx->emb.ng * TILE_BYTES;
+        else if (ctx->emb.vl) ctx->wcls.w = ctx->emb.w + (size_t)(d.tp_rank * ctx->vocab_l / 8) * ctx->emb.vl_group_bytes();
         else ctx->wcls.w = ctx->emb.w + (size_t)(d.tp_rank * ctx->vocab_l / 64) * ctx->emb.rl_group_bytes();
         ctx->wcls_owned = false;
     }

@@ -18,8 +18,11 @@ struct Q8Mat {               // one repacked matrix: Q8T tiles (gl3_decode_kerne
     int ng = 0;              // Q8T: tile groups per strip = ceil(k/32 / 4)
     int nstrips = 0;         // Q8T: ceil(rows / 16)
     int fmt = 8;             // GL3_TYPE_* of the source tensor (8 = Q8_0, 1 = F16, 2 = Q4_0)
+    bool vl = false;         // F16 / Q4_0: "VL" layout of the Vector-API-order kernels (gl3_veclane_kernels.h); false = row-lane
     size_t rl_group_bytes() const { return fmt == 1 ? (size_t)(k / 8) * 1024 : (size_t)(k / 32) * 1152; }
+    size_t vl_group_bytes() const { return fmt == 1 ? (size_t)(k / 64) * 1024 : (size_t)(k / 256) * 1152; }
     size_t bytes() const {
+        if (fmt != 8 && vl) return (size_t)((rows + 7) / 8) * vl_group_bytes();
         if (fmt != 8) return (size_t)((rows + 63) / 64) * rl_group_bytes();
         return (size_t)(nstrips + (nstrips & 1)) * ng * 2176;            // even #strips: the prefill GEMM reads 32-row groups
     }

@@ -1,0 +1,254 @@
+// gl3_veclane_kernels.h — decode matvec for F16 and Q4_0 weights in the order of the reference's VECTOR-API dot products
+// (the reference's default for these types: FloatTensor.USE_VECTOR_API, J/tensor/standard/FloatTensor.java:21-22) with a
+// 256-bit species = 8 float lanes:
+//   F16  : FP16FloatTensor.vectorDot (J/tensor/standard/FP16FloatTensor.java:63-110)
+//              val[l] = fma(w[8 i + l], x[8 i + l], val[l]),  i ascending;  w via the DAZ bit trick (subnormals -> +-0)
+//   Q4_0 : Q4_0FloatTensor.vectorDot, 256-bit branch (J/tensor/standard/Q4_0FloatTensor.java:82-133), per 32-element block j:
+//              s[l]   = ((x[j+l] * lo[l] + x[j+8+l] * lo[8+l]) + x[j+16+l] * hi[l]) + x[j+24+l] * hi[8+l]
+//              val[l] = fma(s[l], wScale, val[l])        lo / hi = (low / high nibbles of the 16 quant bytes) - 8 as floats
+//   result = reduceLanes(ADD) = ((((0 + val[0]) + val[1]) + ...) + val[7])     (lane order from 0: HotSpot evaluates float add reductions strictly in order on x86)
+// Eight independent accumulator chains per row make the row's K-long sum 8-way parallel, and that is also the natural GPU
+// mapping: lane = (row, accumulator lane), a wavefront = 8 rows x 8 accumulators.  Every lane runs a K/8-long chain of
+// FMAs, all lanes of the chip in parallel -> the kernel is bound by the weight stream (HBM), not by a serial chain as the
+// scalar-order kernels in gl3_rowlane_kernels.h are (those stay available behind GL3_FLAG_SCALAR_DOT).
+//
+// Weight layout in HBM ("VL", built once at upload, same byte count as GGUF): rows in groups of 8; per group and chunk a
+// wavefront's loads are contiguous and each lane's 16 bytes are exactly what its chain consumes next:
+//   F16  chunk = 64 elements : [lane (r, l)][8 halfs w[r][64 c + 8 k + l], k = 0..7]                       1024 B
+//   Q4_0 chunk = 8 blocks    : [lane (r, l)][A_0..A_7 | B_0..B_7]  (A_k = quant byte l of block 8c+k: nibbles of elements
+//                              l and 16+l; B_k = byte 8+l: elements 8+l and 24+l)  then [row r][8 x f16 d]   1024 + 128 B
+// The activation is staged in LDS transposed the same way (F16: xT[c][l][k]; Q4_0: xT[block][l][4]) so a lane reads its
+// operands with one or two conflict-free ds_read_b128.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gl3_rowlane_kernels.h"
+
+namespace gl3 {
+
+__host__ __device__ inline size_t vl_group_bytes(int wt, int k) {       // bytes of one 8-row group
+    return wt == WT_F16 ? (size_t)(k / 64) * 1024 : (size_t)(k / 256) * 1152;
+}
+
+// GGUF row-major -> VL.  One thread per destination lane slot (row, chunk, l).
+template <int WT>
+static __global__ __launch_bounds__(256) void repack_vl_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int k,
+                                                               int dst_row0) {
+    const int nch = WT == WT_F16 ? k / 64 : k / 256;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * nch * 8) return;
+    const int l = (int)(i & 7), c = (int)((i >> 3) % nch), r = (int)((i >> 3) / nch);
+    const int row = dst_row0 + r, g = row >> 3, rr = row & 7;
+    uint8_t* gb = dst + (size_t)g * vl_group_bytes(WT, k);
+    if (WT == WT_F16) {
+        const uint16_t* s = reinterpret_cast<const uint16_t*>(src + (size_t)r * k * 2) + 64 * c + l;
+        uint16_t* d = reinterpret_cast<uint16_t*>(gb + (size_t)c * 1024 + (rr * 8 + l) * 16);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) d[kk] = s[8 * kk];
+    } else {
+        const uint8_t* s = src + ((size_t)r * (k / 32) + 8 * c) * 18;        // 8 consecutive blocks of this row
+        uint8_t* d = gb + (size_t)c * 1152 + (rr * 8 + l) * 16;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) { d[kk] = s[kk * 18 + 2 + l]; d[8 + kk] = s[kk * 18 + 2 + 8 + l]; }
+        // the row's 8 block scales of this chunk: written by its l-th lane (one f16 each)
+        reinterpret_cast<uint16_t*>(gb + (size_t)c * 1152 + 1024 + rr * 16)[l] = *reinterpret_cast<const uint16_t*>(s + l * 18);
+    }
+}
+
+// token_embedding_table.copyTo -> getFloat per element (InferenceCore.java:61): SCALAR semantics (IEEE f16 -> f32)
+template <int WT>
+static __global__ __launch_bounds__(256) void embed_vl_kernel(const uint8_t* __restrict__ emb, int dim, const int* __restrict__ dyn,
+                                                              float* __restrict__ x) {
+    const int token = dyn[0], g = token >> 3, rr = token & 7;
+    const uint8_t* gb = emb + (size_t)g * vl_group_bytes(WT, dim);
+    for (int i = threadIdx.x; i < dim; i += 256) {
+        if (WT == WT_F16) {
+            const int c = i >> 6, e = i & 63, l = e & 7, kk = e >> 3;
+            x[i] = h2f(reinterpret_cast<const uint16_t*>(gb + (size_t)c * 1024 + (rr * 8 + l) * 16)[kk]);
+        } else {
+            const int b = i >> 5, j = i & 31, c = b >> 3, kk = b & 7, l = j & 7;
+            const uint8_t* cb = gb + (size_t)c * 1152;
+            const uint8_t byte = cb[(rr * 8 + l) * 16 + ((j & 8) ? 8 : 0) + kk];       // j in [8,16) or [24,32): byte 8 + l
+            const int q = j < 16 ? (byte & 0x0F) : (byte >> 4);
+            x[i] = (float)(q - 8) * h2f(reinterpret_cast<const uint16_t*>(cb + 1024 + rr * 16)[kk]);
+        }
+    }
+}
+
+struct VlArgs {
+    const uint8_t* w; const uint8_t* w2;    // VL matrices (w2: the "up" matrix of the SwiGLU pair)
+    int rows, k;
+    const float* x;                         // f32[k] activation (normalised where the reference normalises)
+    float* out; const float* resid_in;      // EPI_RESID: out[i] = resid_in[i] + result
+};
+
+constexpr int VL_WAVES = 2;                 // 16 rows per workgroup: 4096-row matrices still give one workgroup per CU
+__host__ __device__ inline size_t vl_smem_bytes(int k) { return (size_t)k * 4; }
+
+// F16 -> f32 with subnormal inputs flushed to signed zero = the reference's bit trick (FP16FloatTensor.java:72-100, "emulate
+// DAZ"): the wavefront runs its main loop with MODE.FP_DENORM[3:2] (the f16 / f64 field) = 0 (flush), so one v_cvt_f32_f16
+// per weight is the whole conversion.  hwreg(HW_REG_MODE = 1, offset 6, size 2).
+__device__ __forceinline__ void set_f16_denorm_flush(bool flush) {
+    if (flush) __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);
+    else __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 3);
+}
+__device__ __forceinline__ float cvt_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); }
+__device__ __forceinline__ float cvt_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+
+// Q4_0 is VALU-heavy (~5 instructions per weight: nibble extract, -8, convert, multiply, 3/4 add, 1/4 fma).  Two wavefronts
+// per SIMD (<= 256 VGPRs); capping the registers at 128 for four made the compiler spill 119 VGPRs and was 30 % slower.
+template <int WT, int EPI>
+static __global__ __launch_bounds__(64 * VL_WAVES, WT == WT_Q4_0 ? 2 : 1) void matvec_vl_kernel(const VlArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xT[];
+    constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1;
+    // Chunks in flight per wavefront (4 or 8 VGPRs each; 16 KB / 9 KB of the weight stream per wavefront and matrix)
+    constexpr int D = WT == WT_F16 ? (NM == 1 ? 16 : 8) : (NM == 1 ? 8 : 4);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l = lane & 7, rr = lane >> 3;
+    const int g = blockIdx.x * VL_WAVES + wave;              // 8-row group of this wavefront
+    const int ngroups = (a.rows + 7) >> 3;
+    const int nch = WT == WT_F16 ? a.k / 64 : a.k / 256;
+    const size_t gbytes = vl_group_bytes(WT, a.k);
+    const bool live = g < ngroups;
+    const uint8_t* wb[NM];
+    wb[0] = a.w + (size_t)(live ? g : 0) * gbytes;
+    if (NM == 2) wb[NM - 1] = a.w2 + (size_t)(live ? g : 0) * gbytes;
+
+    // ---- weights first: D chunks per matrix are in flight before the activation is even staged
+    int4 wq[NM][D];
+    int4 wsc[NM][WT == WT_Q4_0 ? D : 1];
+    auto issue = [&](int u, int c) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const uint8_t* cb = wb[m] + (size_t)c * (WT == WT_F16 ? 1024 : 1152);
+            wq[m][u] = ld16<true>(cb + 16 * lane);
+            if (WT == WT_Q4_0) wsc[m][u] = ld16<true>(cb + 1024 + 16 * rr);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { wq[m][u] = make_int4(0, 0, 0, 0); if (WT == WT_Q4_0) wsc[m][u] = make_int4(0, 0, 0, 0); }
+        if (live && u < nch) issue(u, u);
+    }
+    // ---- activation -> LDS, transposed: F16 xT[64 c + 8 l + k] = x[64 c + 8 k + l]; Q4_0 xT[32 b + 4 l + q] = x[32 b + 8 q + l]
+    // 16 float4 per thread are requested at once (one L2 round trip per 32 KB of activation), then scattered
+    {
+        constexpr int XB = 16, NT = 64 * VL_WAVES;
+        const int nq = a.k >> 2;
+        for (int base = 0; base < nq; base += XB * NT) {
+            float4 xr[XB];
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (base + u * NT < nq) xr[u] = *reinterpret_cast<const float4*>(a.x + 4 * min(base + u * NT + t, nq - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int qd = base + u * NT + t;
+                if (qd < nq) {
+                    const float vv[4] = {xr[u].x, xr[u].y, xr[u].z, xr[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * qd + e;
+                        if (WT == WT_F16) xT[(i & ~63) + 8 * (i & 7) + ((i >> 3) & 7)] = vv[e];
+                        else xT[(i & ~31) + 4 * (i & 7) + ((i >> 3) & 3)] = vv[e];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    float acc[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[m] = 0.f;
+    // One chunk of the 8 accumulator chains.  The chunk's activation operands (xa) were fetched from LDS while the previous
+    // chunk was computed; this call fetches the next chunk's (xb).
+    constexpr int XV = 2;                             // F16: float4 operands per chunk and lane (Q4_0 reads its operands per block)
+    auto xload = [&](float4 (&xv)[XV], int c) {
+        if (WT != WT_F16) return;
+#pragma unroll
+        for (int q = 0; q < XV; ++q) xv[q] = *reinterpret_cast<const float4*>(xT + 64 * c + 8 * l + 4 * q);
+    };
+    auto consume = [&](int u, const float4 (&xv)[XV], int cq = 0) {      // cq: chunk index (Q4_0)
+        if (WT == WT_F16) {
+            const float xs[8] = {xv[0].x, xv[0].y, xv[0].z, xv[0].w, xv[1].x, xv[1].y, xv[1].z, xv[1].w};
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const uint32_t wd[4] = {(uint32_t)wq[m][u].x, (uint32_t)wq[m][u].y, (uint32_t)wq[m][u].z, (uint32_t)wq[m][u].w};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)       // thizVector.fma(thatVector, val); the conversion flushes subnormals (MODE)
+                    acc[m] = __builtin_fmaf((kk & 1) ? cvt_hi(wd[kk >> 1]) : cvt_lo(wd[kk >> 1]), xs[kk], acc[m]);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                // quant bytes of the chunk's 8 blocks: A_0..3 | A_4..7 | B_0..3 | B_4..7; nibble planes of four bytes at once
+                const uint32_t aw[2] = {(uint32_t)wq[m][u].x, (uint32_t)wq[m][u].y}, bw[2] = {(uint32_t)wq[m][u].z, (uint32_t)wq[m][u].w};
+                const uint32_t sw[4] = {(uint32_t)wsc[m][u].x, (uint32_t)wsc[m][u].y, (uint32_t)wsc[m][u].z, (uint32_t)wsc[m][u].w};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const uint32_t alo = aw[kk >> 2] & 0x0F0F0F0Fu, ahi = (aw[kk >> 2] >> 4) & 0x0F0F0F0Fu;
+                    const uint32_t blo = bw[kk >> 2] & 0x0F0F0F0Fu, bhi = (bw[kk >> 2] >> 4) & 0x0F0F0F0Fu;
+                    const int sh = 8 * (kk & 3);
+                    const float lo0 = (float)((alo >> sh) & 0xFFu) - 8.0f, hi0 = (float)((ahi >> sh) & 0xFFu) - 8.0f;    // v_cvt_f32_ubyteN; exact
+                    const float lo1 = (float)((blo >> sh) & 0xFFu) - 8.0f, hi1 = (float)((bhi >> sh) & 0xFFu) - 8.0f;
+                    const float ws = (kk & 1) ? cvt_hi(sw[kk >> 1]) : cvt_lo(sw[kk >> 1]);
+                    const float4 xk = *reinterpret_cast<const float4*>(xT + 32 * (8 * cq + kk) + 4 * l);   // x[j+l], x[j+8+l], x[j+16+l], x[j+24+l]
+                    const float s0 = xk.x * lo0, s1 = xk.y * lo1, s2 = xk.z * hi0, s3 = xk.w * hi1;
+                    const float sm = ((s0 + s1) + s2) + s3;                     // sum0.add(sum1).add(sum2).add(sum3)
+                    acc[m] = __builtin_fmaf(sm, ws, acc[m]);                    // .fma(wScale, val)
+                }
+            }
+        }
+    };
+    if (WT == WT_F16) set_f16_denorm_flush(true);
+    float4 xa[XV], xb[XV];
+    xload(xa, 0);
+    int c0 = 0;
+    for (; c0 + 2 * D <= nch; c0 += D) {           // branch-free: the whole next group of D chunks exists
+#pragma unroll
+        for (int u = 0; u < D; u += 2) {
+            xload(xb, c0 + u + 1);
+            consume(u, xa, c0 + u);
+            issue(u, c0 + u + D);
+            xload(xa, c0 + u + 2);                 // c0 + u + 2 <= c0 + D < nch
+            consume(u + 1, xb, c0 + u + 1);
+            issue(u + 1, c0 + u + 1 + D);
+        }
+    }
+    for (; c0 < nch; c0 += D) {                    // last groups: guarded
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int c = c0 + u;
+            if (c < nch) {
+                if (u > 0 || c0 + 2 * D > nch) xload(xa, c);      // (re)load: the fast loop left xa at chunk c0 only
+                consume(u, xa, c);
+                if (c + D < nch) issue(u, c + D);
+            }
+        }
+    }
+    if (WT == WT_F16) set_f16_denorm_flush(false);
+    // ---- reduceLanes(ADD) in lane order from 0, then the epilogue on the row's first lane
+    float res[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        float r = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r = r + __shfl(acc[m], (lane & ~7) + j, 64);
+        res[m] = r;
+    }
+    const int row = g * 8 + rr;
+    if (l == 0 && row < a.rows) {
+        if (EPI == EPI_STORE) a.out[row] = res[0];
+        if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + res[0] : res[0];
+        if (EPI == EPI_SWIGLU) {                               // InferenceCore.java:155-158, exp in double
+            const float gte = res[0] / (float)(1.0 + exp(-(double)res[0]));
+            a.out[row] = gte * res[NM - 1];
+        }
+    }
+}
+
+}  // namespace gl3

@@ -90,7 +90,11 @@ enum {
 /* gl3_model_desc.flags */
 #define GL3_FLAG_NO_GRAPH   0x1u  /* launch the decode step kernel by kernel instead of one hipGraph replay */
 #define GL3_FLAG_LAYER_TAPS 0x2u  /* keep x after every layer for gl3_get_layer_x (parity tap)            */
-#define GL3_FLAG_FORCE_RCCL 0x4u  /* run the per-block all-reduce even when tp_size == 1 (test hook)       */
+#define GL3_FLAG_FORCE_RCCL 0x4u  /* run the tensor-parallel gathers even when tp_size == 1 (test hook)     */
+#define GL3_FLAG_SCALAR_DOT 0x8u  /* F16 / Q4_0 matrices: the reference's SCALAR dot order (-Dllama.VectorBitSize=0,
+                                     FloatTensor.scalarDot) instead of its default Vector-API order with a 256-bit species
+                                     (FP16FloatTensor.vectorDot / Q4_0FloatTensor.vectorDot: 8 fused accumulator lanes).  Q8_0 is
+                                     not affected: dotQ8Activation is scalar in both modes. */
 
 /* Configuration (J/model/Configuration.java via LlamaModelLoader.java:47-63 / Qwen3ModelLoader.java:48-74)
  * plus the plan-selection knobs the reference reads from system properties

@@ -56,6 +56,7 @@ typedef struct { const void* p; int type; } orc_tensor;
 
 typedef struct {
     orc_config c;
+    int vector_bits;                      /* 0: scalar dots (-Dllama.VectorBitSize=0); 256: the Vector-API dots of F16 / Q4_0 */
     orc_tensor global[3];
     orc_tensor* layer[ORC_T_COUNT];       /* per-layer tensors, [id][layer] */
     const float *rope_cr, *rope_ci;       /* freq_cis_real / freq_cis_imag, [ctx * head_size/2] */
@@ -163,8 +164,77 @@ static inline float dot_scalar(const orc_tensor* w, size_t off, const float* x, 
     return result;
 }
 
+/* ---- the Vector-API dots of F16 and Q4_0 with a 256-bit species (8 float lanes) --------------------------------------
+ * These are what the reference computes for F16 / Q4_0 weights unless -Dllama.VectorBitSize=0 (FloatTensor.java:21-22,
+ * LlamaApp.java:14); 256 bits is the preferred shape of an AVX2 host and the widest one Q4_0FloatTensor.vectorDot accepts
+ * (:98-116 throws for 512).  Lane l accumulates elements l, l+8, l+16, ... with FUSED multiply-adds (FloatVector.fma);
+ * reduceLanes(ADD) is evaluated in lane order from 0 (HotSpot's strictly ordered float add reduction on x86 = the Java
+ * fall-back FloatVector.reduceLanesTemplate: ((((0 + v0) + v1) + ...) + v7)); sizes here are multiples of the lane count /
+ * block size, so the scalar tails are empty.  Q8_0 is unaffected (dotQ8Activation is scalar, Q8_0FloatTensor.java:73-76),
+ * and so is attention (ArrayFloatTensor inherits FloatTensor.dot = scalarDot).                                          */
+
+/* FP16FloatTensor.vectorDot  J/tensor/standard/FP16FloatTensor.java:63-110: the f16 -> f32 bit trick flushes subnormal
+ * weights to (signed) zero ("emulate DAZ") and is exact for normal values; infinities / NaNs are not supported there. */
+static inline float f16_to_f32_daz(uint16_t h) {
+    uint32_t b = h;
+    uint32_t mask = (b & 0x7C00u) ? 0xFFFFFFFFu : 0u;
+    uint32_t bits = ((b & 0x8000u) << 16) | ((((b & 0x7FFFu) + 0x1C000u) << 13) & mask);
+    float f; memcpy(&f, &bits, 4); return f;
+}
+
+static inline float reduce_lanes8(const float* v) {
+    float r = 0.f;
+    for (int l = 0; l < 8; l++) r = r + v[l];
+    return r;
+}
+
+static float dot_f16_v256(const uint8_t* wrow, const float* x, int n) {
+    float val[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int ub = n & ~7;
+    for (int i = 0; i < ub; i += 8)
+        for (int l = 0; l < 8; l++) val[l] = fmaf(f16_to_f32_daz(rd16(wrow + 2 * (i + l))), x[i + l], val[l]);     /* thizVector.fma(thatVector, val) */
+    float result = reduce_lanes8(val);
+    if (ub < n) { float t = 0.f; for (int j = ub; j < n; j++) t += orc_f16_to_f32(rd16(wrow + 2 * j)) * x[j]; result += t; }
+    return result;
+}
+
+/* Q4_0FloatTensor.vectorDot  J/tensor/standard/Q4_0FloatTensor.java:82-133, the 256-bit branch :101-106:
+ * val = sum0.add(sum1).add(sum2).add(sum3).fma(wScale, val), sum_i = x-vector * (nibbles - 8) as floats                */
+static float dot_q4_0_v256(const uint8_t* wrow, const float* x, int n) {
+    float val[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int ub = n / 32 * 32;
+    for (int j = 0; j < ub; j += 32) {
+        const uint8_t* blk = wrow + (j / 32) * 18;
+        float ws = orc_f16_to_f32(rd16(blk));
+        for (int l = 0; l < 8; l++) {
+            float lo0 = (float)(int8_t)((blk[2 + l] & 0x0F) - 8), lo1 = (float)(int8_t)((blk[2 + 8 + l] & 0x0F) - 8);
+            float hi0 = (float)(int8_t)((blk[2 + l] >> 4) - 8), hi1 = (float)(int8_t)((blk[2 + 8 + l] >> 4) - 8);
+            float sum0 = x[j + l] * lo0, sum1 = x[j + 8 + l] * lo1, sum2 = x[j + 16 + l] * hi0, sum3 = x[j + 24 + l] * hi1;
+            float s = ((sum0 + sum1) + sum2) + sum3;
+            val[l] = fmaf(s, ws, val[l]);
+        }
+    }
+    float result = 0.f;
+    result += reduce_lanes8(val);
+    if (ub < n) {
+        orc_tensor t = {wrow, ORC_Q4_0};
+        float tl = 0.f;
+        for (int j = ub; j < n; j++) tl += t_get(&t, j) * x[j];
+        result += tl;
+    }
+    return result;
+}
+
 /* FloatTensor.matmul  J/tensor/standard/FloatTensor.java:98-100 (rows in parallel) */
 static void matmul(orc_ctx* o, const orc_tensor* w, const float* x, float* out, int d0, int d1) {
+    if (o->vector_bits == 256 && (w->type == ORC_F16 || w->type == ORC_Q4_0)) {
+        const uint8_t* base = (const uint8_t*)w->p;
+        size_t rb = w->type == ORC_F16 ? (size_t)d1 * 2 : (size_t)(d1 / 32) * 18;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < d0; i++)
+            out[i] = w->type == ORC_F16 ? dot_f16_v256(base + (size_t)i * rb, x, d1) : dot_q4_0_v256(base + (size_t)i * rb, x, d1);
+        return;
+    }
     if (w->type == ORC_Q8_0) {
         quantize_act(x, d1, o->aq, o->ascale);
         const uint8_t* base = (const uint8_t*)w->p;
@@ -402,6 +472,15 @@ ORC_API void orc_rmsnorm(float* out, const float* x, const float* w, int size, f
     orc_tensor t = {w, ORC_F32}; rmsnorm(out, x, &t, 0, size, eps);
 }
 ORC_API void orc_softmax(float* a, int n) { softmax(a, n); }
+/* 0 = scalar dots (the default of this oracle, -Dllama.VectorBitSize=0), 256 = Vector-API dots for F16 / Q4_0 matrices */
+ORC_API int orc_set_vector_bits(orc_ctx* o, int bits) {
+    if (bits != 0 && bits != 256) return -1;
+    o->vector_bits = bits;
+    return 0;
+}
+ORC_API float orc_dot_v256(const void* wrow, int type, const float* x, int n) {
+    return type == ORC_F16 ? dot_f16_v256((const uint8_t*)wrow, x, n) : dot_q4_0_v256((const uint8_t*)wrow, x, n);
+}
 ORC_API int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -63,6 +63,9 @@ def lib():
         L.orc_get_float.argtypes = [C.c_void_p, C.c_int, C.c_long]
         L.orc_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
         L.orc_softmax.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_vector_bits.argtypes = [C.c_void_p, C.c_int]
+        L.orc_dot_v256.restype = C.c_float
+        L.orc_dot_v256.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -74,13 +77,15 @@ def _p(a: np.ndarray):
 class COracle:
     """Same call surface as the HIP plan: forward(token, pos) -> logits, prefill(tokens, start)."""
 
-    def __init__(self, model):
-        """model: gpullama3.java_amd synth.SynthModel-like (cfg, tensors name->(raw, type, ...), rope)."""
+    def __init__(self, model, vector_bits: int = 0):
+        """model: gpullama3.java_amd synth.SynthModel-like (cfg, tensors name->(raw, type, ...), rope).
+        vector_bits: 0 = scalar dots everywhere (-Dllama.VectorBitSize=0), 256 = the Vector-API dots for F16 / Q4_0 matrices."""
         L = lib()
         c = model.cfg
         self.cfg = c
         oc = OrcConfig(c.arch, c.dim, c.hidden, c.n_layers, c.n_heads, c.n_kv_heads, c.head_size, c.vocab, c.ctx, c.rms_eps)
         self._h = L.orc_create(C.byref(oc))
+        assert L.orc_set_vector_bits(self._h, vector_bits) == 0
         self._keep = [model]
         for name, t in model.tensors.items():
             raw, ty = t[0], t[1]

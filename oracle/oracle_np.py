@@ -82,6 +82,61 @@ def matmul(w_raw, ggml_type: int, x: np.ndarray, d0: int, d1: int) -> np.ndarray
     return seq_sum(w * x[None, :], axis=1)
 
 
+def fma32(a: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
+    """Correctly rounded binary32 fused multiply-add (FloatVector.fma = Math.fma per lane), built from float64:
+    the product of two float32 is exact in float64; the sum is rounded TO ODD (exact TwoSum error decides), and a
+    round-to-odd result with >= 2 spare bits rounds to float32 like the infinitely precise value (Boldo & Melquiond)."""
+    a64, b64, c64 = np.asarray(a, F32).astype(np.float64), np.asarray(b, F32).astype(np.float64), np.asarray(c, F32).astype(np.float64)
+    p = a64 * b64
+    s = p + c64
+    bb = s - p
+    err = (p - (s - bb)) + (c64 - bb)                      # exact: p + c64 = s + err
+    odd = (s.view(np.int64) & 1).astype(bool)
+    toward = np.where(err > 0, np.inf, -np.inf)
+    s = np.where((err != 0) & ~odd, np.nextafter(s, toward), s)
+    return s.astype(F32)
+
+
+def f16_to_f32_daz(h: np.ndarray) -> np.ndarray:
+    """FP16FloatTensor.vectorDot's f16 -> f32 bit trick (FP16FloatTensor.java:72-100): exact for normal values, subnormal
+    weights become signed zero ("emulate DAZ")."""
+    b = h.astype(np.uint32)
+    mask = np.where((b & 0x7C00) != 0, np.uint32(0xFFFFFFFF), np.uint32(0))
+    bits = ((b & 0x8000) << 16) | ((((b & 0x7FFF) + 0x1C000) << 13) & mask)
+    return bits.astype(np.uint32).view(F32)
+
+
+def matmul_v256(w_raw, ggml_type: int, x: np.ndarray, d0: int, d1: int) -> np.ndarray:
+    """FloatTensor.matmul with the Vector-API dots of a 256-bit species (8 float lanes):
+    FP16FloatTensor.vectorDot (FP16FloatTensor.java:63-110) / Q4_0FloatTensor.vectorDot, 256-bit branch
+    (Q4_0FloatTensor.java:82-133).  reduceLanes(ADD) in lane order from 0."""
+    x = np.asarray(x, dtype=F32)
+    raw = w_raw.view(np.uint8).reshape(-1)
+    val = np.zeros((d0, 8), F32)
+    if ggml_type == GGML_F16:
+        w = f16_to_f32_daz(raw[: 2 * d0 * d1].view(np.uint16)).reshape(d0, d1 // 8, 8)
+        xv = x.reshape(d1 // 8, 8)
+        for i in range(d1 // 8):
+            val = fma32(w[:, i, :], xv[i][None, :], val)
+    elif ggml_type == GGML_Q4_0:
+        nb = d1 // 32
+        blk = raw[: d0 * nb * 18].reshape(d0, nb, 18)
+        ws = blk[:, :, :2].copy().view(np.float16).astype(F32).reshape(d0, nb)
+        lo = ((blk[:, :, 2:] & 0x0F).astype(np.int8) - 8).astype(F32)          # [d0, nb, 16]
+        hi = ((blk[:, :, 2:] >> 4).astype(np.int8) - 8).astype(F32)
+        xb = x.reshape(nb, 4, 8)
+        for b in range(nb):
+            sum0 = xb[b, 0][None, :] * lo[:, b, 0:8]
+            sum1 = xb[b, 1][None, :] * lo[:, b, 8:16]
+            sum2 = xb[b, 2][None, :] * hi[:, b, 0:8]
+            sum3 = xb[b, 3][None, :] * hi[:, b, 8:16]
+            sm = ((sum0 + sum1) + sum2) + sum3
+            val = fma32(sm, ws[:, b][:, None], val)
+    else:
+        raise ValueError(ggml_type)
+    return seq_sum(val, axis=1)
+
+
 def rmsnorm(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
     """InferenceCore.rmsnorm — J/inference/InferenceCore.java:39-48."""
     x = np.asarray(x, dtype=F32)
@@ -111,7 +166,10 @@ def rope_table(ctx: int, head_size: int, theta: float):
 class NpOracle:
     """Holds config, raw GGUF-layout tensors and the State arrays (LlamaState.java:28-81)."""
 
-    def __init__(self, cfg: dict, tensors: dict, rope):
+    def __init__(self, cfg: dict, tensors: dict, rope, vector_bits: int = 0):
+        """vector_bits: 0 = scalar dots (-Dllama.VectorBitSize=0); 256 = Vector-API dots for F16 / Q4_0 matrices."""
+        assert vector_bits in (0, 256)
+        self.vector_bits = vector_bits
         self.c = cfg
         self.t = tensors          # name -> (raw uint8 ndarray, ggml_type)
         self.cr, self.ci = rope
@@ -123,6 +181,8 @@ class NpOracle:
 
     def _mm(self, name, x, d0, d1):
         raw, ty = self.t[name]
+        if self.vector_bits == 256 and ty in (GGML_F16, GGML_Q4_0):
+            return matmul_v256(raw, ty, x, d0, d1)
         return matmul(raw, ty, x, d0, d1)
 
     def _f32(self, name, n):

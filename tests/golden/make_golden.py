@@ -18,18 +18,20 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 from oracle import oracle_np  # noqa: E402
 
-CASES = [  # (fixture, config, ggml type, seed, prompt tokens, greedy steps)
-    ("tiny_llama_q8_0", "tiny-llama", 8, 7, 6, 24),
-    ("tiny_llama_f16", "tiny-llama", 1, 7, 4, 8),
-    ("tiny_llama_tied_q4_0", "tiny-llama-tied", 2, 11, 4, 8),
-    ("tiny_qwen3_q8_0", "tiny-qwen3", 8, 5, 6, 24),
-    ("tiny_qwen2_q8_0", "tiny-qwen2", 8, 13, 5, 12),
+CASES = [  # (fixture, config, ggml type, seed, prompt tokens, greedy steps, vector bits of the F16 / Q4_0 dots)
+    ("tiny_llama_q8_0", "tiny-llama", 8, 7, 6, 24, 0),
+    ("tiny_llama_f16", "tiny-llama", 1, 7, 4, 8, 0),                 # scalar dots (-Dllama.VectorBitSize=0)
+    ("tiny_llama_tied_q4_0", "tiny-llama-tied", 2, 11, 4, 8, 0),
+    ("tiny_qwen3_q8_0", "tiny-qwen3", 8, 5, 6, 24, 0),
+    ("tiny_qwen2_q8_0", "tiny-qwen2", 8, 13, 5, 12, 0),
+    ("tiny_llama_f16_v256", "tiny-llama", 1, 7, 4, 8, 256),          # Vector-API dots, 256-bit species (the reference's default order)
+    ("tiny_llama_tied_q4_0_v256", "tiny-llama-tied", 2, 11, 4, 8, 256),
 ]
 
 
-def run_case(pkg, cfg_name, wtype, seed, n_prompt, n_greedy):
+def run_case(pkg, cfg_name, wtype, seed, n_prompt, n_greedy, vbits=0):
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg_name], wtype=wtype, seed=seed)
-    o = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope)
+    o = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope, vector_bits=vbits)
     prompt = pkg.javarand.bench_tokens(m.cfg.vocab, n_prompt)
     logits, lx = [], []
     tok_stream = list(prompt)
@@ -47,9 +49,9 @@ def run_case(pkg, cfg_name, wtype, seed, n_prompt, n_greedy):
 if __name__ == "__main__":
     pkg = ge.load_package()
     only = sys.argv[1:]
-    for fx, cfg_name, wt, seed, npmt, ng in CASES:
+    for fx, cfg_name, wt, seed, npmt, ng, vbits in CASES:
         if only and fx not in only:
             continue
-        out = run_case(pkg, cfg_name, wt, seed, npmt, ng)
+        out = run_case(pkg, cfg_name, wt, seed, npmt, ng, vbits)
         np.savez_compressed(os.path.join(os.path.dirname(__file__), fx + ".npz"), **out)
         print(fx, out["tokens"].tolist())

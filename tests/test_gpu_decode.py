@@ -28,14 +28,17 @@ def planmod():
     return import_module(ge.PKG_NAME + ".plan"), import_module(ge.PKG_NAME + ".hip")
 
 
-@pytest.mark.parametrize("fx,cfg,seed,wtype", [("tiny_llama_q8_0", "tiny-llama", 7, 8), ("tiny_qwen3_q8_0", "tiny-qwen3", 5, 8),
-                                               ("tiny_llama_f16", "tiny-llama", 7, 1), ("tiny_llama_tied_q4_0", "tiny-llama-tied", 11, 2),
-                                               ("tiny_qwen2_q8_0", "tiny-qwen2", 13, 8)])
-def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed, wtype):
+@pytest.mark.parametrize("fx,cfg,seed,wtype,scalar", [("tiny_llama_q8_0", "tiny-llama", 7, 8, False), ("tiny_qwen3_q8_0", "tiny-qwen3", 5, 8, False),
+                                                      ("tiny_llama_f16", "tiny-llama", 7, 1, True), ("tiny_llama_tied_q4_0", "tiny-llama-tied", 11, 2, True),
+                                                      ("tiny_qwen2_q8_0", "tiny-qwen2", 13, 8, False),
+                                                      ("tiny_llama_f16_v256", "tiny-llama", 7, 1, False), ("tiny_llama_tied_q4_0_v256", "tiny-llama-tied", 11, 2, False)])
+def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed, wtype, scalar):
+    """F16 / Q4_0: the *_v256 fixtures are the reference's default Vector-API dot order (the plan's default), the others its
+    scalar order (GL3_FLAG_SCALAR_DOT)."""
     plan_mod, hip = planmod
     g = np.load(os.path.join(GOLD, fx + ".npz"))
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=seed)
-    plan = plan_mod.HipMasterPlan(m, flags=hip.FLAG_LAYER_TAPS)
+    plan = plan_mod.HipMasterPlan(m, flags=hip.FLAG_LAYER_TAPS | (hip.FLAG_SCALAR_DOT if scalar else 0))
     toks = g["tokens"]
     n_prompt = len(g["prompt"])
     for pos in range(g["logits"].shape[0]):
@@ -69,15 +72,19 @@ def test_decode_matches_c_oracle_live(pkg, orc, planmod, cfg):
     plan.freeTornadoExecutionPlan()
 
 
-@pytest.mark.parametrize("cfg,wtype", [("mid-llama", 1), ("mid-qwen3", 2), ("tiny-llama-tied", 1), ("mid-llama", 2)])
-def test_f16_and_q4_0_decode_match_c_oracle_live(pkg, orc, planmod, cfg, wtype):
-    """F16 (FP16FloatTensor scalar dot) and Q4_0 (getFloat + scalarDot) weights — element-wise f32
-    chains, no activation quantisation.  Logits, per-layer x and device argmax bit-identical to the oracle; prefill of
-    these types runs token by token (tornadoVMForwardPrefill semantics) and must leave the same KV cache."""
+@pytest.mark.parametrize("cfg,wtype,scalar", [("mid-llama", 1, True), ("mid-qwen3", 2, True), ("tiny-llama-tied", 1, True), ("mid-llama", 2, True),
+                                              ("mid-llama", 1, False), ("mid-qwen3", 2, False), ("tiny-llama-tied", 1, False), ("mid-llama", 2, False),
+                                              ("mid-qwen3", 1, False), ("mha-llama", 2, False)])
+def test_f16_and_q4_0_decode_match_c_oracle_live(pkg, orc, planmod, cfg, wtype, scalar):
+    """F16 and Q4_0 weights (no activation quantisation) in both dot orders of the reference:
+    the default Vector-API order with a 256-bit species (FP16FloatTensor.vectorDot / Q4_0FloatTensor.vectorDot: 8 fused
+    accumulator lanes per row, matvec_vl_kernel) and the scalar order (-Dllama.VectorBitSize=0: one K-long chain per row,
+    matvec_rl_kernel, GL3_FLAG_SCALAR_DOT).  Logits, per-layer x and device argmax bit-identical to the oracle in the
+    same mode; prefill of these types runs token by token and must leave the same KV cache."""
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=17)
-    plan = plan_mod.HipMasterPlan(m, prefill_batch_size=16, flags=hip.FLAG_LAYER_TAPS)
-    o = orc.COracle(m)
+    plan = plan_mod.HipMasterPlan(m, prefill_batch_size=16, flags=hip.FLAG_LAYER_TAPS | (hip.FLAG_SCALAR_DOT if scalar else 0))
+    o = orc.COracle(m, vector_bits=0 if scalar else 256)
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 14)
     plan.prefill(toks[:6], 0)
     o.prefill(toks[:6], 0)
@@ -252,7 +259,7 @@ def test_native_gguf_loader_builds_the_same_plan(pkg, orc, planmod, tmp_path, cf
     a = plan_mod.HipMasterPlan(m)
     b = plan_mod.HipMasterPlan.from_gguf(path, prefill_batch_size=8)
     assert (b.cfg.dim, b.cfg.n_layers, b.cfg.vocab, b.cfg.head_size) == (m.cfg.dim, m.cfg.n_layers, m.cfg.vocab, m.cfg.head_size)
-    o = orc.COracle(pkg.synth.SynthModel.from_gguf(path))      # the oracle reads the SAME file through the Python GGUF reader
+    o = orc.COracle(pkg.synth.SynthModel.from_gguf(path), vector_bits=0 if wtype == 8 else 256)      # the oracle reads the SAME file through the Python GGUF reader
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 10)
     b.prefill(toks[:5], 0)
     for pos, t in enumerate(toks):

@@ -25,7 +25,7 @@ def planmod():
 def test_row_split_ranks_are_bit_identical_to_the_oracle(pkg, orc, planmod, cfg, tp, wtype):
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=17)
-    o = orc.COracle(m)
+    o = orc.COracle(m, vector_bits=0 if wtype == 8 else 256)         # F16 / Q4_0: the plan's default Vector-API dot order
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 6)
     ref = [o.forward(t, p) for p, t in enumerate(toks)]
     grp = plan_mod.make_local_group(tp)
@@ -199,7 +199,7 @@ def test_peer_write_transport_between_processes(pkg, orc, cfg, world, wtype):
     [p.join(timeout=120) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=17)
-    o = orc.COracle(m)
+    o = orc.COracle(m, vector_bits=0 if wtype == 8 else 256)
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 12)
     o.prefill(toks[:5], 0)
     ref = [o.forward(toks[p], p) for p in range(5, 12)]
