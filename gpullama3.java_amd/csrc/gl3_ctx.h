@@ -98,6 +98,7 @@ struct gl3_ctx {
     int dyn_seq_cap = 0;
     float* h_logits = nullptr;                    // pinned f32[vocab]
     int* h_argmax = nullptr;
+    std::vector<std::pair<void*, size_t>> pinned;     // caller buffers registered with gl3_pin_host_buffer (logits land there directly)
     // upload staging
     uint8_t* staging = nullptr;
     size_t staging_bytes = 0;

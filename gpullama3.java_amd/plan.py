@@ -77,6 +77,14 @@ class HipMasterPlan:
             raise
         self._logits = np.empty(c.vocab, np.float32)
         self._arg = C.c_int32()
+        self._pin_logits()
+
+    def _pin_logits(self):
+        # the logits buffer is reused on every step: page-lock it once so the D2H copy lands in it directly
+        try:
+            hip.check(hip.lib().gl3_pin_host_buffer(self._ctx, _p(self._logits), self._logits.nbytes), self._ctx)
+        except hip.Gl3Error:
+            pass                                      # not fatal: the plan falls back to its own staging buffer
 
     @classmethod
     def from_gguf(cls, path: str, prefill_batch_size: int = 1, ctx: int = 0, device: int = 0, flags: int = 0, n_seqs: int = 1):
@@ -112,6 +120,7 @@ class HipMasterPlan:
         self.tp_size, self.tp_rank, self.max_batch = 1, 0, prefill_batch_size
         self._logits = np.empty(self.cfg.vocab, np.float32)
         self._arg = C.c_int32()
+        self._pin_logits()
         return self
 
     # ---- reference-named interface -------------------------------------------------------------

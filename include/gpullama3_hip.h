@@ -175,6 +175,12 @@ GL3_API int32_t gl3_finalize(gl3_ctx* ctx);
 GL3_API int32_t gl3_forward_decode(gl3_ctx* ctx, int32_t token, int32_t position, float* logits_out,
                                    int32_t* argmax_out);
 
+/* Optional: page-lock a caller-owned host buffer (e.g. the MemorySegment the Java shim passes as logits_out on every step) so
+ * that gl3_forward_decode copies the logits straight into it instead of going through the plan's pinned staging buffer and a
+ * host memcpy.  The buffer must stay allocated until gl3_unpin_host_buffer / gl3_destroy. */
+GL3_API int32_t gl3_pin_host_buffer(gl3_ctx* ctx, void* ptr, uint64_t bytes);
+GL3_API int32_t gl3_unpin_host_buffer(gl3_ctx* ctx, void* ptr);
+
 /* Batched prefill of tokens[0..n) at positions start_pos.. (no logits, as the reference skips them).
  * n <= max_batch. */
 GL3_API int32_t gl3_forward_prefill(gl3_ctx* ctx, const int32_t* tokens, int32_t n, int32_t start_pos);

@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
         std::vector<uint8_t*> wb, w2b;
         for (int i = 0; i < nbuf; ++i) { uint8_t* p; CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0x11 + i, bytes)); wb.push_back(p);
             if (nm == 2) { CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0x23 + i, bytes)); w2b.push_back(p); } }
-        const size_t smem = (size_t)a.ng * 4 * 32 + (size_t)a.ng * 4 * 4 + (sh.pro == PRO_RMS ? (size_t)(a.k + 32) * 4 : 0) + (size_t)2 * nm * a.ng * 64 * 4 + 64;
+        const size_t smem = (size_t)a.ng * 4 * 32 + (size_t)a.ng * 4 * 4 + (sh.pro == PRO_RMS ? (size_t)(a.k + 32) * 4 : 0) + (size_t)2 * nm * a.ng * 64 * 4 + 128;
         const double algo = (double)sh.rows * (sh.k / 32) * 34 * nm + sh.k * 4 + sh.rows * 4;
         for (int wgs : wg_list) {
             const int g = std::min(wgs, a.nstrips);
