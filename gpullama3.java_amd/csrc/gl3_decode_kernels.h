@@ -402,6 +402,12 @@ struct AttnArgs {
     int n_heads, n_kv_heads, hs, q_dim, kv_dim, ctx;
     float eps;
     int arch;
+    // static-batched decode (attn_head_kernel with gridDim.y = tokens): token b belongs to sequence seqv[b] at position posv[b]
+    const int* seqv;         // NULL: single-token decode (position = dyn[1], one KV cache)
+    const int* posv;
+    size_t seq_stride;       // floats between the KV caches of consecutive sequences
+    int qkv_stride, xb_stride;   // floats between consecutive tokens' rows of qkv / xb
+    int group;               // attn_head_kernel: query heads per workgroup (0 / 1: one; kvMul: the whole group of a kv head)
 };
 
 __device__ __forceinline__ void rope_head(float* v, int hs, const float* cr, const float* ci, int arch, int t0, int nthreads) {
@@ -533,25 +539,35 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
 // RoPE of k is recomputed by every head of the group (128 elements); only the group's first head writes the KV row.
 //   LDS: q[hs] | K[AF_MAXN][hs+4] | V[AF_MAXN][hs] | e[AF_MAXN] | rope row | red[16]
 constexpr int AF_MAXN = 128;
-__host__ __device__ inline size_t attn_head_smem(int hs) {
-    return ((size_t)hs + (size_t)AF_MAXN * (hs + 4) + (size_t)AF_MAXN * hs + (size_t)AF_MAXN + hs + 16) * 4;
+// group = query heads per workgroup: 1 (single-token decode: one workgroup per query head) or kvMul (static-batched decode:
+// one workgroup per (kv head, token) serves the whole group from one staged K / V tile, so that 32 tokens x 8 kv heads are 256
+// workgroups = one wave of workgroups on the chip instead of four)
+__host__ __device__ inline size_t attn_head_smem(int hs, int group = 1) {
+    return ((size_t)group * hs + (size_t)AF_MAXN * (hs + 4) + (size_t)AF_MAXN * hs + (size_t)group * AF_MAXN + hs + 16) * 4;
 }
 
 static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads, half = hs >> 1, pitch = hs + 4, q4 = hs >> 2;
     const int q4sh = __ffs(q4) - 1;                  // head sizes are powers of two
-    float* q_s = sm;
-    float* kt = q_s + hs;
+    const int G = a.group > 1 ? a.group : 1;
+    float* q_s = sm;                                 // [G][hs]
+    float* kt = q_s + G * hs;
     float* vt = kt + AF_MAXN * pitch;
-    float* e_s = vt + AF_MAXN * hs;
-    float* cr_s = e_s + AF_MAXN;
+    float* e_s = vt + AF_MAXN * hs;                  // [G][AF_MAXN]
+    float* cr_s = e_s + G * AF_MAXN;
     float* ci_s = cr_s + half;
     float* red = ci_s + half;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int h = blockIdx.x, kvh = h / kvmul;
-    const bool owner = (h % kvmul) == 0;
-    const int pos = a.dyn[1], n = pos + 1;
+    const int h0 = blockIdx.x * G, kvh = h0 / kvmul;          // first query head of this workgroup
+    const bool owner = (h0 % kvmul) == 0;
+    // static-batched decode: one grid row per token, each with its own sequence (KV cache) and position
+    const int bt = blockIdx.y;
+    const int pos = a.seqv ? a.posv[bt] : a.dyn[1], n = pos + 1;
+    const size_t kvoff = a.seqv ? (size_t)a.seqv[bt] * a.seq_stride : 0;
+    const float* qkv = a.qkv + (size_t)bt * a.qkv_stride;
+    float* kcache = a.kcache + kvoff;
+    float* vcache = a.vcache + kvoff;
     ATT_STAMP(0);
     // ---- one global round trip: cached K / V rows (both in flight at once), raw q / k / v of this token, the RoPE row
     const int nk4 = pos * q4;
@@ -566,16 +582,16 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
         if (u < per) {
             const int i = min(t + u * 256, nk4 - 1);
             const size_t off = (size_t)(i >> q4sh) * a.kv_dim + kvh * hs + 4 * (i & (q4 - 1));
-            kreg[u] = *reinterpret_cast<const float4*>(a.kcache + off);
-            vreg[u] = *reinterpret_cast<const float4*>(a.vcache + off);
+            kreg[u] = *reinterpret_cast<const float4*>(kcache + off);
+            vreg[u] = *reinterpret_cast<const float4*>(vcache + off);
         }
     }
-    for (int i = t; i < hs; i += 256) q_s[i] = a.bq ? a.qkv[h * hs + i] + a.bq[h * hs + i] : a.qkv[h * hs + i];
+    for (int i = t; i < G * hs; i += 256) q_s[i] = a.bq ? qkv[h0 * hs + i] + a.bq[h0 * hs + i] : qkv[h0 * hs + i];
     for (int i = t; i < half; i += 256) { cr_s[i] = a.rope_cr[(size_t)pos * half + i]; ci_s[i] = a.rope_ci[(size_t)pos * half + i]; }
     float* krow = kt + pos * pitch;
     for (int i = t; i < hs; i += 256) {
-        krow[i] = a.bk ? a.qkv[a.q_dim + kvh * hs + i] + a.bk[kvh * hs + i] : a.qkv[a.q_dim + kvh * hs + i];
-        vt[pos * hs + i] = a.bv ? a.qkv[a.q_dim + a.kv_dim + kvh * hs + i] + a.bv[kvh * hs + i] : a.qkv[a.q_dim + a.kv_dim + kvh * hs + i];
+        krow[i] = a.bk ? qkv[a.q_dim + kvh * hs + i] + a.bk[kvh * hs + i] : qkv[a.q_dim + kvh * hs + i];
+        vt[pos * hs + i] = a.bv ? qkv[a.q_dim + a.kv_dim + kvh * hs + i] + a.bv[kvh * hs + i] : qkv[a.q_dim + a.kv_dim + kvh * hs + i];
     }
     if (in_regs) {
 #pragma unroll
@@ -589,69 +605,95 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
     } else {                                         // head_size 256: straight to LDS
         for (int i = t; i < nk4; i += 256) {
             const size_t off = (size_t)(i >> q4sh) * a.kv_dim + kvh * hs + 4 * (i & (q4 - 1));
-            *reinterpret_cast<float4*>(kt + (i >> q4sh) * pitch + 4 * (i & (q4 - 1))) = *reinterpret_cast<const float4*>(a.kcache + off);
-            *reinterpret_cast<float4*>(vt + (i >> q4sh) * hs + 4 * (i & (q4 - 1))) = *reinterpret_cast<const float4*>(a.vcache + off);
+            *reinterpret_cast<float4*>(kt + (i >> q4sh) * pitch + 4 * (i & (q4 - 1))) = *reinterpret_cast<const float4*>(kcache + off);
+            *reinterpret_cast<float4*>(vt + (i >> q4sh) * hs + 4 * (i & (q4 - 1))) = *reinterpret_cast<const float4*>(vcache + off);
         }
     }
     __syncthreads();
     ATT_STAMP(1);
     if (a.arch == 1) {                               // qwen3: per-head RMSNorm of q and k (one thread each, strict order)
-        if (t == 0) head_rmsnorm_1t(q_s, a.qnorm, hs, a.eps);
-        if (t == 64) head_rmsnorm_1t(krow, a.knorm, hs, a.eps);
+        if ((t & 31) == 0 && (t >> 5) < G) head_rmsnorm_1t(q_s + (t >> 5) * hs, a.qnorm, hs, a.eps);
+        if (t == 255) head_rmsnorm_1t(krow, a.knorm, hs, a.eps);
         __syncthreads();
     }
-    rope_head(q_s, hs, cr_s, ci_s, a.arch, t, 256);
+    for (int g = 0; g < G; ++g) rope_head(q_s + g * hs, hs, cr_s, ci_s, a.arch, t, 256);
     rope_head(krow, hs, cr_s, ci_s, a.arch, t, 256);
     __syncthreads();
     if (owner) {                                     // KV write, InferenceCore.java:92-93
         for (int i = t; i < hs; i += 256) {
-            a.kcache[(size_t)pos * a.kv_dim + kvh * hs + i] = krow[i];
-            a.vcache[(size_t)pos * a.kv_dim + kvh * hs + i] = vt[pos * hs + i];
+            kcache[(size_t)pos * a.kv_dim + kvh * hs + i] = krow[i];
+            vcache[(size_t)pos * a.kv_dim + kvh * hs + i] = vt[pos * hs + i];
         }
     }
     ATT_STAMP(2);
-    // ---- scores: thread = timestep; strict j order, mul then add (FloatTensor.scalarDot)
-    float sc = -INFINITY;
-    if (t < n) {
-        const float* kk = kt + t * pitch;
+    // ---- scores: one (query head, timestep) pair per thread and pass; strict j order, mul then add (FloatTensor.scalarDot)
+    const float sqrt_hs = (float)sqrt((double)hs);
+    float sc = -INFINITY;                            // group == 1: this thread's score (timestep t)
+    for (int idx = t; idx < G * n; idx += 256) {
+        const int g = idx / n, tt = idx - g * n;
+        const float* q = q_s + g * hs;
+        const float* kk = kt + tt * pitch;
         float score = 0.f;
-        float4 qv = *reinterpret_cast<const float4*>(q_s), kv = *reinterpret_cast<const float4*>(kk);
+        float4 qv = *reinterpret_cast<const float4*>(q), kv = *reinterpret_cast<const float4*>(kk);
         for (int j = 4; j < hs; j += 4) {
-            const float4 qn = *reinterpret_cast<const float4*>(q_s + j), kn = *reinterpret_cast<const float4*>(kk + j);
+            const float4 qn = *reinterpret_cast<const float4*>(q + j), kn = *reinterpret_cast<const float4*>(kk + j);
             score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
             qv = qn; kv = kn;
         }
         score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
-        sc = score / (float)sqrt((double)hs);
+        sc = score / sqrt_hs;
+        if (G > 1) e_s[g * AF_MAXN + tt] = sc;
     }
     ATT_STAMP(3);
     // ---- softmax (FloatTensor.softmaxInPlace :211-219): max, exp in double, strict sum, divide
-    {
-        const float wm = wave_max(sc);
-        if (lane == 0) red[wave] = wm;
+    if (G == 1) {                                    // one head: all timesteps in parallel across the workgroup
+        {
+            const float wm = wave_max(t < n ? sc : -INFINITY);
+            if (lane == 0) red[wave] = wm;
+        }
+        __syncthreads();
+        const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float ex = 0.f;
+        if (t < n) { ex = (float)exp((double)(sc - mx)); e_s[t] = ex; }
+        __syncthreads();
+        ATT_STAMP(4);
+        if (wave == 0) { const float sum = seq_sum_lds<false>(e_s, n); if (lane == 0) red[4] = sum; }
+        __syncthreads();
+        if (t < n) e_s[t] = ex / red[4];
+        __syncthreads();
+    } else {                                         // a group: one wavefront per head, everything wave-local (LDS runs a wavefront in order)
+        __syncthreads();
+        for (int g = wave; g < G; g += 4) {
+            float* e = e_s + g * AF_MAXN;
+            const float s0 = lane < n ? e[lane] : -INFINITY, s1 = lane + 64 < n ? e[lane + 64] : -INFINITY;
+            const float mx = wave_max(fmaxf(s0, s1));
+            const float e0 = lane < n ? (float)exp((double)(s0 - mx)) : 0.f, e1 = lane + 64 < n ? (float)exp((double)(s1 - mx)) : 0.f;
+            if (lane < n) e[lane] = e0;
+            if (lane + 64 < n) e[lane + 64] = e1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const float sum = seq_sum_lds<false>(e, n);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < n) e[lane] = e0 / sum;
+            if (lane + 64 < n) e[lane + 64] = e1 / sum;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float ex = 0.f;
-    if (t < n) { ex = (float)exp((double)(sc - mx)); e_s[t] = ex; }
-    __syncthreads();
-    ATT_STAMP(4);
-    if (wave == 0) { const float sum = seq_sum_lds<false>(e_s, n); if (lane == 0) red[4] = sum; }
-    __syncthreads();
-    if (t < n) e_s[t] = ex / red[4];
-    __syncthreads();
     ATT_STAMP(5);
-    // ---- weighted V sum, t ascending: xb[j] = a_t * v[t][j] + xb[j] (saxpyInPlace :221-227); thread = output column
-    if (t < hs) {
+    // ---- weighted V sum, t ascending: xb[j] = a_t * v[t][j] + xb[j] (saxpyInPlace :221-227); one (head, output column) per thread and pass
+    for (int idx = t; idx < G * hs; idx += 256) {
+        const int g = idx / hs, j = idx - g * hs;
+        const float* e = e_s + g * AF_MAXN;
         float acc = 0.f;
         int tt = 0;
         for (; tt + 4 <= n; tt += 4) {
-            const float4 a4 = *reinterpret_cast<const float4*>(e_s + tt);
-            const float v0 = vt[tt * hs + t], v1 = vt[(tt + 1) * hs + t], v2 = vt[(tt + 2) * hs + t], v3 = vt[(tt + 3) * hs + t];
+            const float4 a4 = *reinterpret_cast<const float4*>(e + tt);
+            const float v0 = vt[tt * hs + j], v1 = vt[(tt + 1) * hs + j], v2 = vt[(tt + 2) * hs + j], v3 = vt[(tt + 3) * hs + j];
             acc = a4.x * v0 + acc; acc = a4.y * v1 + acc; acc = a4.z * v2 + acc; acc = a4.w * v3 + acc;
         }
-        for (; tt < n; ++tt) acc = e_s[tt] * vt[tt * hs + t] + acc;
-        a.xb[(size_t)h * hs + t] = acc;
+        for (; tt < n; ++tt) acc = e[tt] * vt[tt * hs + j] + acc;
+        a.xb[(size_t)bt * a.xb_stride + (size_t)(h0 + g) * hs + j] = acc;
     }
     ATT_STAMP(6);
 }

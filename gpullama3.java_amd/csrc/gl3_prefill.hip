@@ -31,6 +31,7 @@ struct gl3_prefill_state {
     int32_t* seqpos = nullptr;          // [2][M]: sequence id, position of every token of the step
     float* LOGITS = nullptr;            // [rows][vocab], grown on demand (batched decode)
     int logits_rows = 0;
+    std::vector<hipGraphExec_t> step_graphs;   // static-batched decode: one captured step per batch size (positions < AF_MAXN)
     bool in_arena = false;              // X / AO / HB / LOGITS are slices of the tensor-parallel arena (not freed here)
     int32_t* amax = nullptr;            // [M]
     int maxk = 0;
@@ -947,6 +948,7 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
 void gl3_prefill_free(gl3_ctx* ctx) {
     gl3_prefill_state* p = ctx->pf;
     if (!p) return;
+    for (auto ge : p->step_graphs) if (ge) hipGraphExecDestroy(ge);
     auto f = [](void* q) { if (q) hipFree(q); };
     f(p->tokens); f(p->XQ); f(p->XS); f(p->QKV); f(p->ATT); f(p->seqpos); f(p->amax);
     if (!p->in_arena) { f(p->X); f(p->AO); f(p->HB); f(p->LOGITS); }
@@ -1010,6 +1012,9 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
     const int hid = ctx->hidden_l, dml = ctx->dim_l;
     const int qkv_dim = qd + 2 * kvd;
     const size_t kv_layer = (size_t)d.ctx * kvd;
+    // one workgroup per (kv head, token) serves the kv head's whole group of query heads when its LDS image fits
+    const int bd_group = (kvmul <= 8 && attn_head_smem(d.head_size, kvmul) <= 150 * 1024) ? kvmul : 1;
+    const bool fused_decode = ctx->fused_attn_ok && max_pos < AF_MAXN && !(getenv("GL3_NO_FUSED_BD_ATTN") && atoi(getenv("GL3_NO_FUSED_BD_ATTN")));
     float* Xr = p->X + (size_t)rank * n * dml;           // this rank's chunk of X / AO / HB
     float* AOr = p->AO + (size_t)rank * n * qd;
     float* HBr = p->HB + (size_t)rank * n * hid;
@@ -1026,13 +1031,24 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         ra.cr = ctx->rope_cr; ra.ci = ctx->rope_ci; ra.qnorm = L.qnorm; ra.knorm = L.knorm; ra.bq = L.bq; ra.bk = L.bk; ra.bv = L.bv; ra.n_heads = H;
         ra.n_kv_heads = KVH; ra.hs = d.head_size; ra.q_dim = qd; ra.kv_dim = kvd;
         ra.arch = d.arch; ra.eps = d.rms_eps; ra.seq = seq; ra.pos = pos; ra.seq_stride = ctx->kv_seq_stride;
-        hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(H + KVH, n), dim3(64), 0, s, ra);
         PfAttnArgs aa{};
         aa.Q = p->QKV; aa.q_stride = qkv_dim; aa.kcache = ra.kcache; aa.vcache = ra.vcache; aa.att = p->ATT; aa.out = AOr;
         aa.out_stride = qd; aa.n_heads = H; aa.n_kv_heads = KVH; aa.hs = d.head_size; aa.kv_dim = kvd;
         aa.ctx = d.ctx; aa.seq = seq; aa.pos = pos; aa.seq_stride = ctx->kv_seq_stride;
         const int nsplit = (max_pos + 1 + ATT_TT - 1) / ATT_TT;
         const int hs = d.head_size;
+        if (one_seq < 0 && fused_decode) {
+            // static-batched decode at positions < AF_MAXN: RoPE + KV write + scores + softmax + weighted V sum of every
+            // (token, head) in ONE launch (attn_head_kernel, grid = heads x tokens) instead of three per-token-grid kernels
+            AttnArgs ha{};
+            ha.qkv = p->QKV; ha.qkv_stride = qkv_dim; ha.kcache = ra.kcache; ha.vcache = ra.vcache; ha.rope_cr = ctx->rope_cr; ha.rope_ci = ctx->rope_ci;
+            ha.qnorm = L.qnorm; ha.knorm = L.knorm; ha.bq = L.bq; ha.bk = L.bk; ha.bv = L.bv; ha.dyn = ctx->dyn; ha.att = nullptr;
+            ha.xb = AOr; ha.xb_stride = qd; ha.n_heads = H; ha.n_kv_heads = KVH; ha.hs = hs; ha.q_dim = qd; ha.kv_dim = kvd; ha.ctx = d.ctx;
+            ha.eps = d.rms_eps; ha.arch = d.arch; ha.seqv = seq; ha.posv = pos; ha.seq_stride = ctx->kv_seq_stride;
+            ha.group = bd_group;
+            hipLaunchKernelGGL(attn_head_kernel, dim3(H / bd_group, n), dim3(256), attn_head_smem(hs, bd_group), s, ha);
+        } else {
+        hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(H + KVH, n), dim3(64), 0, s, ra);
         const bool tiled = one_seq >= 0 && kvmul <= 4 && (hs == 32 || hs == 64 || hs == 128) && (size_t)(max_pos + 1) * 4 <= 60 * 1024;
         if (tiled) {
             const int pos0 = max_pos + 1 - n, ntt = (n + PA_TB - 1) / PA_TB;
@@ -1054,6 +1070,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
             const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
             hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, KVH, n), dim3(64 * kvmul), sm1, s, aa);
             hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(H * ((d.head_size + 63) / 64), n), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
+        }
         }
         if ((r = gl3_all_gather(ctx, GB_PF_AO, (size_t)n * qd)) != GL3_OK) return r;
         hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->AO, ctx->q_dim, qd, (const float*)nullptr,
@@ -1117,6 +1134,7 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
     GL3_HIP(hipSetDevice(d.device));
     if (p->logits_rows < n && p->in_arena) GL3_FAIL(GL3_E_UNSUPPORTED, "tensor-parallel static-batched decode is limited to 64 sequences per step");
     if (p->logits_rows < n) {
+        for (auto& ge : p->step_graphs) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }      // captured steps point at the old buffer
         if (p->LOGITS) hipFree(p->LOGITS);
         p->LOGITS = nullptr; p->logits_rows = 0;
         GL3_HIP(hipMalloc((void**)&p->LOGITS, (size_t)n * d.vocab * 4));
@@ -1126,18 +1144,39 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
     for (int i = 0; i < n; ++i) max_pos = positions[i] > max_pos ? positions[i] : max_pos;
     int32_t r = pf_stage_tokens(ctx, tokens, seq_ids, positions, n);
     if (r != GL3_OK) return r;
-    if ((r = pf_layers(ctx, n, max_pos, -1)) != GL3_OK) return r;
     hipStream_t s = ctx->stream;
-    const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
-    hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk);
-    // vocab rows are split across ranks: this rank's logits are the chunk [n][vocab / tp] of the rank-chunked buffer
     const int vl = ctx->vocab_l;
-    launch_gemm<EPI_STORE>(ctx, ctx->wcls, nullptr, n, p->LOGITS + (size_t)d.tp_rank * n * vl, vl);
-    if ((r = gl3_all_gather(ctx, GB_PF_LOGITS, (size_t)n * vl)) != GL3_OK) return r;
-    if (argmax_out) {
+    // the whole step: layers, final RMSNorm + vocabulary projection of every row, greedy ids
+    auto enqueue_step = [&](int mp) -> int32_t {
+        int32_t rr = pf_layers(ctx, n, mp, -1);
+        if (rr != GL3_OK) return rr;
+        const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
+        hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk);
+        // vocab rows are split across ranks: this rank's logits are the chunk [n][vocab / tp] of the rank-chunked buffer
+        launch_gemm<EPI_STORE>(ctx, ctx->wcls, nullptr, n, p->LOGITS + (size_t)d.tp_rank * n * vl, vl);
+        if ((rr = gl3_all_gather(ctx, GB_PF_LOGITS, (size_t)n * vl)) != GL3_OK) return rr;
         hipLaunchKernelGGL(pf_argmax_rows_kernel, dim3(n), dim3(1024), 0, s, p->LOGITS, d.vocab, p->amax, vl);
-        GL3_HIP(hipMemcpyAsync(argmax_out, p->amax, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    }
+        return GL3_OK;
+    };
+    // ~400 launches per step: replay them as one hipGraph per batch size.  Nothing position-dependent is baked in when every
+    // position is below AF_MAXN (the one-launch attention reads sequence ids / positions from device memory).
+    static const bool graphs_off = getenv("GL3_NO_GRAPH") && atoi(getenv("GL3_NO_GRAPH"));
+    const bool graphable = !graphs_off && !(d.flags & GL3_FLAG_NO_GRAPH) && ctx->fused_attn_ok && max_pos < AF_MAXN && ctx->transport != GL3_TP_RCCL;
+    if (graphable) {
+        if ((int)p->step_graphs.size() <= n) p->step_graphs.resize(n + 1, nullptr);
+        if (!p->step_graphs[n]) {
+            hipGraph_t g = nullptr;
+            GL3_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            r = enqueue_step(0);
+            const hipError_t e = hipStreamEndCapture(s, &g);
+            if (r != GL3_OK) return r;
+            GL3_HIP(e);
+            GL3_HIP(hipGraphInstantiate(&p->step_graphs[n], g, nullptr, nullptr, 0));
+            hipGraphDestroy(g);
+        }
+        GL3_HIP(hipGraphLaunch(p->step_graphs[n], s));
+    } else if ((r = enqueue_step(max_pos)) != GL3_OK) return r;
+    if (argmax_out) GL3_HIP(hipMemcpyAsync(argmax_out, p->amax, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (logits_out) {      // un-chunk on the way out: [tp][n][vl] -> [n][vocab]
         for (int c = 0; c < d.tp_size; ++c)
             GL3_HIP(hipMemcpy2DAsync(logits_out + (size_t)c * vl, (size_t)d.vocab * 4, p->LOGITS + (size_t)c * n * vl, (size_t)vl * 4, (size_t)vl * 4, n,
