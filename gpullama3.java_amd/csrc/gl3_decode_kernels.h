@@ -107,9 +107,11 @@ __device__ __forceinline__ float seq_sum_lds(const float* v, int n) {
 // xq[32*b ..] = int8 quants of block b, xs[b] = f16-rounded activation scale.  v = value already normalised.
 __device__ __forceinline__ void quantize_quad(float4 v, int qd, uint8_t* xq, float* xs) {
     float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    // maximum over the block's 8 lanes with DPP moves (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror) instead of
+    // three dependent ds_bpermute round trips through LDS (__shfl_xor): ~300 cycles less per quad on the prologue's critical path
+    amax = fmaxf(amax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, amax), 0xB1, 0xf, 0xf, false)));
+    amax = fmaxf(amax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, amax), 0x4E, 0xf, 0xf, false)));
+    amax = fmaxf(amax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, amax), 0x141, 0xf, 0xf, false)));
     const float qs = amax / 127.0f;
     const float ainv = qs != 0.f ? 1.0f / qs : 0.f;
     const float s0 = v.x * ainv, s1 = v.y * ainv, s2 = v.z * ainv, s3 = v.w * ainv;
@@ -233,6 +235,8 @@ __global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_
     }
 
     // ---------------------------------------------------------------------- aux waves: prologue
+    // the prologue is the critical path of the kernel; the producers only issue their loads and poll
+    __builtin_amdgcn_s_setprio(3);
     const int ta = t - 64 * MV_PRODUCERS;                // 0..255
     const int nquads = a.k >> 2;
     float scale = 1.0f;
@@ -240,17 +244,14 @@ __global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_
     float4 nwv[5], xv[NXV];                              // this thread's RMSNorm weights and activations
     // all activation loads first: they come from L2, the norm weights behind them from HBM (vmcnt retires in order, and the
     // activation is needed 5 us before the weights)
+    // UNCONDITIONAL loads with clamped indices (quads past the end re-read the last one: an L1 hit that is never used).  With a
+    // lane-predicated `if (qd < nquads) xv[i] = load`, and even with a wave-uniform condition, the compiler waited
+    // (s_waitcnt vmcnt(0)) after every single load: 10 to 14 serial L2 round trips in front of every matvec (seen in the ISA).
 #pragma unroll
-    for (int i = 0; i < NXV; ++i) {
-        const int qd = ta + 256 * i;
-        if (qd < nquads) xv[i] = *reinterpret_cast<const float4*>(a.x + 4 * qd);
-    }
+    for (int i = 0; i < NXV; ++i) xv[i] = *reinterpret_cast<const float4*>(a.x + 4 * min(ta + 256 * i, nquads - 1));
     if (PRO == PRO_RMS) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int qd = ta + 256 * i;
-            if (qd < nquads) nwv[i] = *reinterpret_cast<const float4*>(a.norm_w + 4 * qd);
-        }
+        for (int i = 0; i < 5; ++i) nwv[i] = *reinterpret_cast<const float4*>(a.norm_w + 4 * min(ta + 256 * i, nquads - 1));
     }
     __syncthreads();                                     // activation loads are queued ahead of the weight stream
     SubBarrier aux_sync{&sync_w[0], MV_AUX, 0};

@@ -166,12 +166,17 @@ __device__ float exact_sumsq_lds(const float* x, int n, uint8_t* scratch, const 
     float4 a[SS_MAX_SPT];
     float qs[SS_MAX_SPT];
     float qt = 0.f;
+    // all LDS reads are issued unconditionally (segments past the end read the zero padding behind x[n]): reads under a
+    // lane-dependent condition are waited for one by one
+#pragma unroll
+    for (int i = 0; i < SS_MAX_SPT; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(x + 4 * min(seg0 + i, nseg));
+        a[i].x = v.x * v.x; a[i].y = v.y * v.y; a[i].z = v.z * v.z; a[i].w = v.w * v.w;
+    }
 #pragma unroll
     for (int i = 0; i < SS_MAX_SPT; ++i) {
         qs[i] = 0.f;
-        if (i < spt && seg0 + i < nseg) {
-            const float4 v = *reinterpret_cast<const float4*>(x + 4 * (seg0 + i));
-            a[i].x = v.x * v.x; a[i].y = v.y * v.y; a[i].z = v.z * v.z; a[i].w = v.w * v.w;
+        if (i < spt) {                                   // wave-uniform; the zero padding makes segments >= nseg contribute 0
             qs[i] = (a[i].x + a[i].y) + (a[i].z + a[i].w);
             qt += qs[i];
         }
