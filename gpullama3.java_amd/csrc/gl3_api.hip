@@ -410,6 +410,7 @@ void gl3_destroy(gl3_ctx* ctx) {
     if (ctx->graph) hipGraphDestroy(ctx->graph);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     gl3_prefill_free(ctx);
+    gl3_sample_free(ctx);
     for (auto e : ctx->ev) hipEventDestroy(e);
     auto f = [](void* p) { if (p) hipFree(p); };
     f(ctx->emb.w);
@@ -644,6 +645,27 @@ int32_t gl3_forward_decode(gl3_ctx* ctx, int32_t token, int32_t pos, float* logi
     if (logits_out && !direct) memcpy(logits_out, ctx->h_logits, (size_t)ctx->d.vocab * 4);
     if (argmax_out) *argmax_out = *ctx->h_argmax;
     return GL3_OK;
+}
+
+int32_t gl3_forward_decode_sample(gl3_ctx* ctx, int32_t token, int32_t pos, float temperature, float topp, float coin, int32_t* token_out) {
+    if (!ctx) return GL3_E_ARG;
+    if (!token_out) GL3_FAIL(GL3_E_ARG, "null token_out");
+    if (!(temperature >= 0.f)) GL3_FAIL(GL3_E_ARG, "temperature must be >= 0");
+    if (temperature == 0.f) return gl3_forward_decode(ctx, token, pos, nullptr, token_out);      // Sampler.java:79-81: greedy argmax
+    if (!(coin >= 0.f && coin < 1.f)) GL3_FAIL(GL3_E_ARG, "coin must be rng.nextFloat(1f): in [0, 1)");
+    int32_t r = set_dyn(ctx, token, pos);
+    if (r != GL3_OK) return r;
+    const bool short_ctx = ctx->fused_attn_ok && pos < AF_MAXN;
+    if (ctx->graph_exec) GL3_HIP(hipGraphLaunch(short_ctx && ctx->graph_exec_s ? ctx->graph_exec_s : ctx->graph_exec, ctx->stream));
+    else if ((r = enqueue_decode(ctx, true, nullptr, short_ctx)) != GL3_OK) return r;
+    if ((r = gl3_sample_run(ctx, ctx->logits, temperature, topp, coin, token_out)) != GL3_OK) return r;
+    return gl3_tp_check(ctx);
+}
+
+int32_t gl3_get_sample_probs(gl3_ctx* ctx, float* out) {
+    if (!ctx || !out) return GL3_E_ARG;
+    GL3_HIP(hipSetDevice(ctx->d.device));
+    return gl3_sample_probs(ctx, out);
 }
 
 int32_t gl3_forward_prefill_seq(gl3_ctx* ctx, int32_t seq, const int32_t* tokens, int32_t n, int32_t start_pos) {

@@ -98,6 +98,8 @@ struct gl3_ctx {
     int dyn_seq_cap = 0;
     float* h_logits = nullptr;                    // pinned f32[vocab]
     int* h_argmax = nullptr;
+    float *sm_probs = nullptr, *sm_aux = nullptr, *h_probs = nullptr;   // sampling (gl3_sample.hip): probabilities, scratch, pinned copy
+    std::vector<int> topp_indices;
     std::vector<std::pair<void*, size_t>> pinned;     // caller buffers registered with gl3_pin_host_buffer (logits land there directly)
     // upload staging
     uint8_t* staging = nullptr;
@@ -159,6 +161,11 @@ int32_t gl3_tp_arena_alloc(gl3_ctx* ctx);
 void gl3_tp_arena_free(gl3_ctx* ctx);
 int32_t gl3_tp_local_resolve(gl3_ctx* ctx);
 int32_t gl3_tp_check(gl3_ctx* ctx);      // after a stream sync: GL3_E_RCCL if a gather timed out
+
+// gl3_sample.hip
+int32_t gl3_sample_run(gl3_ctx* ctx, const float* logits_dev, float temperature, float topp, float coin, int32_t* token_out);
+int32_t gl3_sample_probs(gl3_ctx* ctx, float* out);
+void gl3_sample_free(gl3_ctx* ctx);
 
 // gl3_prefill.hip
 float* gl3_prefill_buf(gl3_ctx* ctx, int which);

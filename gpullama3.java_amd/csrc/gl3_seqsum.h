@@ -53,13 +53,15 @@ __device__ __forceinline__ float wave_incl_scan_f32(float v) {                  
 }
 
 // naive chain over x[k0..k1), executed redundantly by all lanes of one wavefront (LDS broadcast reads)
+template <bool SQ = true>
 __device__ __forceinline__ float naive_sumsq_lds(const float* x, int k0, int k1, float s) {
     int k = k0;
     for (; k + 4 <= k1; k += 4) {
         const float4 v = *reinterpret_cast<const float4*>(x + k);
-        s = s + v.x * v.x; s = s + v.y * v.y; s = s + v.z * v.z; s = s + v.w * v.w;
+        if (SQ) { s = s + v.x * v.x; s = s + v.y * v.y; s = s + v.z * v.z; s = s + v.w * v.w; }
+        else { s = s + v.x; s = s + v.y; s = s + v.z; s = s + v.w; }
     }
-    for (; k < k1; ++k) { const float v = x[k]; s = s + v * v; }
+    for (; k < k1; ++k) { const float v = x[k]; s = SQ ? s + v * v : s + v; }
     return s;
 }
 
@@ -83,7 +85,7 @@ __device__ __forceinline__ float ss_chain(const float4 (&buf)[M4], float base) {
     }
     return base;
 }
-template <int M4>
+template <int M4, bool SQ = true>
 __device__ __forceinline__ void replay_events(const float* x, int m, int nseg, int nhard, const uint32_t* es, const uint32_t* pre,
                                               const int* hlist, float& base, int& fail) {
     static_assert(M4 == 1, "segments are one float4");
@@ -104,7 +106,8 @@ __device__ __forceinline__ void replay_events(const float* x, int m, int nseg, i
         float4 sq = {0.f, 0.f, 0.f, 0.f};                  // +0 adds nothing for the trailing event
         if (h < nseg) {
             const float4 v = *reinterpret_cast<const float4*>(x + 4 * h);
-            sq.x = v.x * v.x; sq.y = v.y * v.y; sq.z = v.z * v.z; sq.w = v.w * v.w;
+            if (SQ) { sq.x = v.x * v.x; sq.y = v.y * v.y; sq.z = v.z * v.z; sq.w = v.w * v.w; }
+            else sq = v;
         }
         SS_STAMP(5);
         const int nev = __builtin_amdgcn_readfirstlane(min(64, nhard + 1 - c0));   // scalar loop control (s_cmp, not a VALU compare + vcc branch)
@@ -145,8 +148,10 @@ struct SubBarrier {
 __host__ __device__ constexpr size_t ss_scratch_bytes(int n) { return 128 + (size_t)3 * n; }
 constexpr int SS_MAX_SPT = 5;                      // segments per thread: n <= 4 * 256 * 5 = 5120
 
-template <typename Sync>
-__device__ float exact_sumsq_lds(const float* x, int n, uint8_t* scratch, const int t, Sync& sync) {
+// SQ = true: a_k = x_k * x_k (RMSNorm); SQ = false: a_k = x_k >= 0 (FloatTensor.sum of softmax numerators / probabilities,
+// J/tensor/standard/FloatTensor.java:211-219).  start = value of the running sum before x[0] (chunked sums of long vectors).
+template <bool SQ, typename Sync>
+__device__ float exact_seqsum_lds(const float* x, int n, uint8_t* scratch, const int t, Sync& sync, const float start) {
     const int lane = t & 63, wave = t >> 6;
     float* w_tot = reinterpret_cast<float*>(scratch);                    // [4]  predictor wave totals
     uint32_t* w_nd = reinterpret_cast<uint32_t*>(scratch + 16);          // [4]  run-sum wave totals
@@ -171,7 +176,8 @@ __device__ float exact_sumsq_lds(const float* x, int n, uint8_t* scratch, const 
 #pragma unroll
     for (int i = 0; i < SS_MAX_SPT; ++i) {
         const float4 v = *reinterpret_cast<const float4*>(x + 4 * min(seg0 + i, nseg));
-        a[i].x = v.x * v.x; a[i].y = v.y * v.y; a[i].z = v.z * v.z; a[i].w = v.w * v.w;
+        if (SQ) { a[i].x = v.x * v.x; a[i].y = v.y * v.y; a[i].z = v.z * v.z; a[i].w = v.w * v.w; }
+        else a[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < SS_MAX_SPT; ++i) {
@@ -185,7 +191,7 @@ __device__ float exact_sumsq_lds(const float* x, int n, uint8_t* scratch, const 
     if (lane == 63) w_tot[wave] = incl;
     sync();
     SS_STAMP(1);
-    float P = incl - qt;
+    float P = start + (incl - qt);
     for (int w = 0; w < wave; ++w) P += w_tot[w];
 
     // ---- translation D of each segment from two representative starts (even / odd mantissa)
@@ -252,16 +258,21 @@ __device__ float exact_sumsq_lds(const float* x, int n, uint8_t* scratch, const 
     // ---- replay the hard segments in order (one wavefront), see replay_events
     if (wave == 0) {
         const int nhard = w_cnt[0] + w_cnt[1] + w_cnt[2] + w_cnt[3];
-        float base = 0.f;
+        float base = start;
         int fail = 0;
-        replay_events<1>(x, 4, nseg, nhard, es, pre, hlist, base, fail);
-        if (fail || misc[0]) base = naive_sumsq_lds(x, 0, n, 0.f);       // never expected: plain chain
+        replay_events<1, SQ>(x, 4, nseg, nhard, es, pre, hlist, base, fail);
+        if (fail || misc[0]) base = naive_sumsq_lds<SQ>(x, 0, n, start);       // never expected: plain chain
         if (lane == 0) result[0] = base;
         SS_STAMP(6);
     }
     sync();
     SS_STAMP(7);
     return result[0];
+}
+
+template <typename Sync>
+__device__ __forceinline__ float exact_sumsq_lds(const float* x, int n, uint8_t* scratch, const int t, Sync& sync) {
+    return exact_seqsum_lds<true>(x, n, scratch, t, sync, 0.f);
 }
 
 }  // namespace gl3

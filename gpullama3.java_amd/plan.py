@@ -185,6 +185,18 @@ class HipMasterPlan:
         hip.check(hip.lib().gl3_forward_decode(self._ctx, token, position, None, C.byref(self._arg)), self._ctx)
         return int(self._arg.value)
 
+    def forward_decode_sample(self, token: int, position: int, temperature: float, topp: float, coin: float) -> int:
+        """One decode step + Sampler.selectSampler(...).sampleToken(logits) (Sampler.java:76-123); `coin` = rng.nextFloat(1f) from the
+        caller's RandomGenerator (javarand.L32X64MixRandom mirrors RandomGeneratorFactory.getDefault())."""
+        out = C.c_int32()
+        hip.check(hip.lib().gl3_forward_decode_sample(self._ctx, token, position, temperature, topp, coin, C.byref(out)), self._ctx)
+        return int(out.value)
+
+    def sample_probs(self) -> np.ndarray:
+        out = np.empty(self.cfg.vocab, np.float32)
+        hip.check(hip.lib().gl3_get_sample_probs(self._ctx, _p(out)), self._ctx)
+        return out
+
     def prefill(self, tokens, start_pos: int = 0, batch: int | None = None):
         """LlamaBench.prefill (J/bench/LlamaBench.java:258-273): chunks of `batch` (llama-bench -b; default max_batch)."""
         tokens = list(tokens)

@@ -175,6 +175,18 @@ GL3_API int32_t gl3_finalize(gl3_ctx* ctx);
 GL3_API int32_t gl3_forward_decode(gl3_ctx* ctx, int32_t token, int32_t position, float* logits_out,
                                    int32_t* argmax_out);
 
+/* One decode step + Sampler.selectSampler(vocab, temperature, topp, seed).sampleToken(logits)
+ * (J/inference/sampler/Sampler.java:76-123): temperature == 0 -> greedy argmax; else logits / temperature, softmax (max,
+ * exp in double, strictly sequential f32 sum, divide) on the device, then CategoricalSampler (topp outside (0,1); on the
+ * device, 4 bytes come back) or ToppSampler (probabilities to the host, the reference's heap selection in native code).
+ * `coin` is rng.nextFloat(1f) drawn by the CALLER from its own RandomGenerator — RandomGeneratorFactory.getDefault()
+ * .create(seed) in the reference — one per sampled token, exactly where the reference draws it; the library holds no RNG, so
+ * the random stream and the sampled ids are the reference's by construction. */
+GL3_API int32_t gl3_forward_decode_sample(gl3_ctx* ctx, int32_t token, int32_t position, float temperature, float topp,
+                                          float coin, int32_t* token_out);
+/* Parity tap: the probabilities (f32[vocab]) the last gl3_forward_decode_sample sampled from. */
+GL3_API int32_t gl3_get_sample_probs(gl3_ctx* ctx, float* out);
+
 /* Optional: page-lock a caller-owned host buffer (e.g. the MemorySegment the Java shim passes as logits_out on every step) so
  * that gl3_forward_decode copies the logits straight into it instead of going through the plan's pinned staging buffer and a
  * host memcpy.  The buffer must stay allocated until gl3_unpin_host_buffer / gl3_destroy. */

@@ -472,6 +472,59 @@ ORC_API void orc_rmsnorm(float* out, const float* x, const float* w, int size, f
     orc_tensor t = {w, ORC_F32}; rmsnorm(out, x, &t, 0, size, eps);
 }
 ORC_API void orc_softmax(float* a, int n) { softmax(a, n); }
+/* ---- sampling: Sampler.selectSampler's lambda + CategoricalSampler / ToppSampler -------------------------------------
+ * J/inference/sampler/Sampler.java:76-123 (temperature scaling, softmax, inner sampler), CategoricalSampler.java:33-44,
+ * ToppSampler.java:24-160.  coin = rng.nextFloat(1f) of the caller's RandomGenerator.  probs_out (nullable) receives the
+ * softmax output the sampler drew from.                                                                                 */
+static int topp_cmp(const float* v, int a, int b) {      /* Comparator.comparingDouble(logits::getFloat).reversed() */
+    double da = v[a], db = v[b];
+    return (db < da) ? -1 : (db > da) ? 1 : 0;
+}
+static void topp_sift_down(int* array, int from, int n, const float* v) {            /* ToppSampler.siftDown :30-44 */
+    int prev = from, next;
+    while ((next = 2 * prev + 1) < n) {
+        int r = 2 * prev + 2;
+        if (r < n && topp_cmp(v, array[r], array[next]) < 0) next = r;
+        if (topp_cmp(v, array[next], array[prev]) < 0) { int tmp = array[prev]; array[prev] = array[next]; array[next] = tmp; prev = next; }
+        else break;
+    }
+}
+ORC_API int orc_sample(const float* logits, int n, float temperature, float topp, float coin, float* probs_out) {
+    if (temperature == 0.0f) return orc_argmax(logits, n);                           /* Sampler.java:79-81 */
+    float* p = (float*)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; i++) p[i] = logits[i] / temperature;                      /* divideInPlace(temperature) */
+    softmax(p, n);
+    if (probs_out) memcpy(probs_out, p, sizeof(float) * (size_t)n);
+    int result;
+    if (topp <= 0 || topp >= 1) {                                                    /* CategoricalSampler.sampleFromFloatTensor */
+        float cdf = 0.0f;
+        result = n - 1;
+        for (int i = 0; i < n; i++) { cdf += p[i]; if (coin < cdf) { result = i; break; } }
+    } else {                                                                         /* ToppSampler.sampleFromFloatTensor + processTopP */
+        int* indices = (int*)malloc(sizeof(int) * (size_t)n);
+        int head = 0, tail = n - 1;
+        float cutoff = (1.0f - topp) / (n - 1);
+        for (int i = 0; i < n; i++) { if (p[i] >= cutoff) indices[head++] = i; else indices[tail--] = i; }
+        int n0 = head;
+        for (int i = n0 / 2 - 1; i >= 0; --i) topp_sift_down(indices, i, n0, p);
+        float cumulativeProb = 0.0f;
+        int lastIndex = 0;
+        for (int i = n0 - 1; i >= 0; i--) {
+            int tmp = indices[0]; indices[0] = indices[i]; indices[i] = tmp;
+            cumulativeProb += p[indices[i]];
+            if (cumulativeProb > topp) { lastIndex = i; break; }
+            topp_sift_down(indices, 0, i - 1, p);
+        }
+        float r = coin * cumulativeProb;
+        float cdf = 0.0f;
+        result = indices[lastIndex];
+        for (int i = n0 - 1; i >= lastIndex; i--) { cdf += p[indices[i]]; if (r < cdf) { result = indices[i]; break; } }
+        free(indices);
+    }
+    free(p);
+    return result;
+}
+
 /* 0 = scalar dots (the default of this oracle, -Dllama.VectorBitSize=0), 256 = Vector-API dots for F16 / Q4_0 matrices */
 ORC_API int orc_set_vector_bits(orc_ctx* o, int bits) {
     if (bits != 0 && bits != 256) return -1;

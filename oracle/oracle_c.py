@@ -63,6 +63,7 @@ def lib():
         L.orc_get_float.argtypes = [C.c_void_p, C.c_int, C.c_long]
         L.orc_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
         L.orc_softmax.argtypes = [C.c_void_p, C.c_int]
+        L.orc_sample.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.orc_set_vector_bits.argtypes = [C.c_void_p, C.c_int]
         L.orc_dot_v256.restype = C.c_float
         L.orc_dot_v256.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -137,3 +138,11 @@ class COracle:
 def argmax(v: np.ndarray) -> int:
     v = np.ascontiguousarray(v, np.float32)
     return lib().orc_argmax(_p(v), v.size)
+
+
+def sample(logits: np.ndarray, temperature: float, topp: float, coin: float, want_probs: bool = False):
+    """Sampler.selectSampler(vocab, temperature, topp, .).sampleToken(logits) with rng.nextFloat(1f) = coin."""
+    v = np.ascontiguousarray(logits, np.float32)
+    probs = np.empty_like(v) if want_probs else None
+    tok = lib().orc_sample(_p(v), v.size, temperature, topp, coin, _p(probs) if want_probs else None)
+    return (tok, probs) if want_probs else tok
