@@ -28,7 +28,7 @@ using namespace gl3;
 
 constexpr int SM_BLOCKS = 256, SM_CHUNK = 4096;
 
-__global__ __launch_bounds__(256) void sm_scale_max_kernel(const float* __restrict__ logits, int n, float temperature, float* __restrict__ p,
+__global__ __launch_bounds__(256) void smp_scale_max_kernel(const float* __restrict__ logits, int n, float temperature, float* __restrict__ p,
                                                             float* __restrict__ blockmax) {
     __shared__ float red[4];
     float mx = -INFINITY;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void sm_scale_max_kernel(const float* __restri
     if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-__global__ __launch_bounds__(256) void sm_exp_kernel(float* __restrict__ p, int n, const float* __restrict__ blockmax, int nblocks) {
+__global__ __launch_bounds__(256) void smp_exp_kernel(float* __restrict__ p, int n, const float* __restrict__ blockmax, int nblocks) {
     __shared__ float red[4];
     float mx = -INFINITY;
     for (int i = threadIdx.x; i < nblocks; i += 256) mx = fmaxf(mx, blockmax[i]);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void sm_exp_kernel(float* __restrict__ p, int 
 // per chunk (gl3_seqsum.h) continued from the exact running value.  chunk_end[c] = running sum after chunk c (the cdf at the
 // chunk boundaries).  With pick = true the kernel then samples: first index whose cdf exceeds coin (CategoricalSampler).
 template <bool PICK>
-__global__ __launch_bounds__(256) void sm_seqsum_kernel(const float* __restrict__ p, int n, float* __restrict__ total, float* __restrict__ chunk_end,
+__global__ __launch_bounds__(256) void smp_seqsum_kernel(const float* __restrict__ p, int n, float* __restrict__ total, float* __restrict__ chunk_end,
                                                          float coin, int* __restrict__ picked) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* xf = reinterpret_cast<float*>(smem);                      // [SM_CHUNK + 32]
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void sm_seqsum_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void sm_div_kernel(float* __restrict__ p, int n, const float* __restrict__ total) {
+__global__ __launch_bounds__(256) void smp_div_kernel(float* __restrict__ p, int n, const float* __restrict__ total) {
     const float s = *total;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = p[i] / s;     // divideInPlace(sum)
 }
@@ -162,8 +162,8 @@ int32_t gl3_sample_alloc(gl3_ctx* ctx) {
     GL3_HIP(hipMalloc((void**)&ctx->sm_probs, (size_t)ctx->d.vocab * 4));
     GL3_HIP(hipMalloc((void**)&ctx->sm_aux, (size_t)(SM_BLOCKS + nchunks + 8) * 4));
     GL3_HIP(hipHostMalloc((void**)&ctx->h_probs, (size_t)ctx->d.vocab * 4));
-    GL3_HIP(hipFuncSetAttribute((const void*)sm_seqsum_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    GL3_HIP(hipFuncSetAttribute((const void*)sm_seqsum_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    GL3_HIP(hipFuncSetAttribute((const void*)smp_seqsum_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    GL3_HIP(hipFuncSetAttribute((const void*)smp_seqsum_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     return GL3_OK;
 }
 
@@ -185,13 +185,13 @@ int32_t gl3_sample_run(gl3_ctx* ctx, const float* logits_dev, float temperature,
     int* picked = reinterpret_cast<int*>(ctx->sm_aux + SM_BLOCKS + 1);
     float* chunk_end = ctx->sm_aux + SM_BLOCKS + 8;
     const size_t smem = (size_t)(SM_CHUNK + 32) * 4 + ss_scratch_bytes(SM_CHUNK);
-    hipLaunchKernelGGL(sm_scale_max_kernel, dim3(SM_BLOCKS), dim3(256), 0, s, logits_dev, n, temperature, ctx->sm_probs, blockmax);
-    hipLaunchKernelGGL(sm_exp_kernel, dim3(SM_BLOCKS), dim3(256), 0, s, ctx->sm_probs, n, blockmax, SM_BLOCKS);
-    hipLaunchKernelGGL(sm_seqsum_kernel<false>, dim3(1), dim3(256), smem, s, ctx->sm_probs, n, total, chunk_end, 0.f, picked);
-    hipLaunchKernelGGL(sm_div_kernel, dim3(SM_BLOCKS), dim3(256), 0, s, ctx->sm_probs, n, total);
+    hipLaunchKernelGGL(smp_scale_max_kernel, dim3(SM_BLOCKS), dim3(256), 0, s, logits_dev, n, temperature, ctx->sm_probs, blockmax);
+    hipLaunchKernelGGL(smp_exp_kernel, dim3(SM_BLOCKS), dim3(256), 0, s, ctx->sm_probs, n, blockmax, SM_BLOCKS);
+    hipLaunchKernelGGL(smp_seqsum_kernel<false>, dim3(1), dim3(256), smem, s, ctx->sm_probs, n, total, chunk_end, 0.f, picked);
+    hipLaunchKernelGGL(smp_div_kernel, dim3(SM_BLOCKS), dim3(256), 0, s, ctx->sm_probs, n, total);
     const bool use_topp = topp > 0.f && topp < 1.f;                  // Sampler.java:88-98
     if (!use_topp) {
-        hipLaunchKernelGGL(sm_seqsum_kernel<true>, dim3(1), dim3(256), smem, s, ctx->sm_probs, n, (float*)nullptr, chunk_end, coin, picked);
+        hipLaunchKernelGGL(smp_seqsum_kernel<true>, dim3(1), dim3(256), smem, s, ctx->sm_probs, n, (float*)nullptr, chunk_end, coin, picked);
         GL3_HIP(hipMemcpyAsync(ctx->h_argmax, picked, sizeof(int), hipMemcpyDeviceToHost, s));
         GL3_HIP(hipStreamSynchronize(s));
         *token_out = *ctx->h_argmax;
