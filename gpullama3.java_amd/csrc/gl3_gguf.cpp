@@ -46,6 +46,9 @@ uint64_t type_bytes(int type, uint64_t n) {       // GGMLType.java:5-21 (type si
     case GL3_TYPE_F16: return n * 2;
     case GL3_TYPE_Q4_0: return n / 32 * 18;
     case GL3_TYPE_Q8_0: return n / 32 * 34;
+    case GL3_TYPE_Q4_K: return n / 256 * 144;
+    case GL3_TYPE_Q5_K: return n / 256 * 176;
+    case GL3_TYPE_Q6_K: return n / 256 * 210;
     default: return 0;
     }
 }
@@ -125,6 +128,51 @@ bool read_value(Cursor& c, int ty, MetaValue& v) {
 
 int32_t fail(gl3_gguf* g, int32_t code, const std::string& m) { g->err = m; return code; }
 
+// ---- K-quants: FloatTensor.getFloat of the reference's CPU tensors (f32 arithmetic, left to right) ----------------------
+inline float f16_at(const uint8_t* p) { uint16_t h; memcpy(&h, p, 2); return (float)__builtin_bit_cast(_Float16, h); }
+
+// Q4_KFloatTensor.getScaleK4 / getMinK4 (J/tensor/standard/Q4_KFloatTensor.java:63-83; shared by Q5_K :67-83)
+inline int k4_scale(int j, const uint8_t* sc) { return j < 4 ? (sc[j] & 63) : ((sc[j + 4] & 0xF) | ((sc[j - 4] >> 6) << 4)); }
+inline int k4_min(int j, const uint8_t* sc) { return j < 4 ? (sc[j + 4] & 63) : ((sc[j + 4] >> 4) | ((sc[j] >> 6) << 4)); }
+
+// Q4_KFloatTensor.getFloat :86-114 (block = f16 d | f16 dmin | 12 scale bytes | 128 nibble bytes = 144 B per 256 elements)
+inline float q4k_get(const uint8_t* base, size_t i) {
+    const uint8_t* b = base + (i / 256) * 144;
+    const int w = (int)(i % 256), pair = w / 64, pos = w % 64;
+    const float d = f16_at(b), dmin = f16_at(b + 2);
+    int sub, q;
+    if (pos < 32) { sub = pair * 2; q = b[16 + pair * 32 + pos] & 0xF; }
+    else { sub = pair * 2 + 1; q = (b[16 + pair * 32 + pos - 32] >> 4) & 0xF; }
+    return d * (float)k4_scale(sub, b + 4) * (float)q - dmin * (float)k4_min(sub, b + 4);
+}
+// Q5_KFloatTensor.getFloat :86-120 (f16 d | f16 dmin | 12 scale bytes | 32 high-bit bytes | 128 nibble bytes = 176 B)
+inline float q5k_get(const uint8_t* base, size_t i) {
+    const uint8_t* b = base + (i / 256) * 176;
+    const int w = (int)(i % 256), pair = w / 64, pos = w % 64;
+    const float d = f16_at(b), dmin = f16_at(b + 2);
+    int sub, q, hb;
+    if (pos < 32) { sub = pair * 2; q = b[48 + pair * 32 + pos] & 0xF; hb = (b[16 + pos] >> (pair * 2)) & 1; }
+    else { sub = pair * 2 + 1; q = (b[48 + pair * 32 + pos - 32] >> 4) & 0xF; hb = (b[16 + pos - 32] >> (pair * 2 + 1)) & 1; }
+    q += hb * 16;
+    return d * (float)k4_scale(sub, b + 4) * (float)q - dmin * (float)k4_min(sub, b + 4);
+}
+// Q6_KFloatTensor.getFloat (128 low-nibble bytes | 64 high-2-bit bytes | 16 int8 scales | f16 d = 210 B)
+inline float q6k_get(const uint8_t* base, size_t i) {
+    const uint8_t* b = base + (i / 256) * 210;
+    const int w = (int)(i % 256), half = w / 128, ph = w % 128, grp = ph / 32, pg = ph % 32, is = pg / 16;
+    const float d = f16_at(b + 208);
+    const uint8_t* ql = b + half * 64;
+    const uint8_t* qh = b + 128 + half * 32;
+    const int8_t* sc = reinterpret_cast<const int8_t*>(b + 192 + half * 8);
+    int qv;
+    switch (grp) {
+    case 0: qv = ((ql[pg] & 0xF) | (((qh[pg] >> 0) & 3) << 4)) - 32; return d * (float)sc[is] * (float)qv;
+    case 1: qv = ((ql[32 + pg] & 0xF) | (((qh[pg] >> 2) & 3) << 4)) - 32; return d * (float)sc[is + 2] * (float)qv;
+    case 2: qv = ((ql[pg] >> 4) | (((qh[pg] >> 4) & 3) << 4)) - 32; return d * (float)sc[is + 4] * (float)qv;
+    default: qv = ((ql[32 + pg] >> 4) | (((qh[pg] >> 6) & 3) << 4)) - 32; return d * (float)sc[is + 6] * (float)qv;
+    }
+}
+
 bool meta_num(const gl3_gguf* g, const std::string& key, double* out) {
     auto it = g->meta.find(key);
     if (it == g->meta.end() || it->second.type == GT_STRING || it->second.type == GT_ARRAY) return false;
@@ -137,6 +185,39 @@ thread_local std::string g_open_err;
 }  // namespace
 
 extern "C" {
+
+// ModelLoader.dequantizeToQ8_0TornadoTensor (J/model/loader/ModelLoader.java:173-224): what the reference's GPU path does with
+// Q4_K / Q5_K / Q6_K tensors at load time — dequantise element by element with the CPU tensor's getFloat and re-quantise to
+// Q8_0 blocks: scale = maxAbs / 127 (stored as f16, RNE), q = clamp(Math.round(x * (1 / scale)), -128, 127), with the
+// UNROUNDED scale in the reciprocal.  n = number of elements (multiple of 256); dst receives n / 32 * 34 bytes.
+int32_t gl3_kquant_to_q8_0(int32_t src_type, const void* src, uint64_t n, void* dst) {
+    if (!src || !dst || (n % 256)) return GL3_E_ARG;
+    if (src_type != GL3_TYPE_Q4_K && src_type != GL3_TYPE_Q5_K && src_type != GL3_TYPE_Q6_K) return GL3_E_UNSUPPORTED;
+    const uint8_t* s = (const uint8_t*)src;
+    uint8_t* out = (uint8_t*)dst;
+    const uint64_t nblk = n / 32;
+#pragma omp parallel for schedule(static)
+    for (long long b = 0; b < (long long)nblk; ++b) {
+        float x[32];
+        float max_abs = 0.f;
+        for (int i = 0; i < 32; ++i) {
+            const size_t e = (size_t)b * 32 + i;
+            x[i] = src_type == GL3_TYPE_Q4_K ? q4k_get(s, e) : src_type == GL3_TYPE_Q5_K ? q5k_get(s, e) : q6k_get(s, e);
+            max_abs = std::fmax(max_abs, std::fabs(x[i]));
+        }
+        const float scale = max_abs / 127.0f;
+        const uint16_t h = __builtin_bit_cast(uint16_t, (_Float16)scale);          // Float.floatToFloat16: round to nearest even
+        uint8_t* o = out + (size_t)b * 34;
+        o[0] = (uint8_t)(h & 0xFF); o[1] = (uint8_t)(h >> 8);
+        const float inv = scale != 0.f ? 1.0f / scale : 0.f;
+        for (int i = 0; i < 32; ++i) {
+            int q = (int)std::floor(x[i] * inv + 0.5f);                            // Math.round(float): ties toward +infinity
+            q = q < -128 ? -128 : q > 127 ? 127 : q;
+            o[2 + i] = (uint8_t)(int8_t)q;
+        }
+    }
+    return GL3_OK;
+}
 
 const char* gl3_gguf_last_error(const gl3_gguf* g) { return g ? g->err.c_str() : g_open_err.c_str(); }
 
@@ -274,7 +355,8 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
     if (d->ctx <= 0) d->ctx = ctx < 4096 ? (int32_t)ctx : 4096;
     else if (d->ctx > (int32_t)ctx) d->ctx = (int32_t)ctx;
     d->rms_eps = (float)eps;
-    d->weight_type = emb.type;
+    // K-quant files run as Q8_0 after the load-time conversion (ModelLoader.loadTornadoTensor :163-164)
+    d->weight_type = (emb.type == GL3_TYPE_Q4_K || emb.type == GL3_TYPE_Q5_K || emb.type == GL3_TYPE_Q6_K) ? GL3_TYPE_Q8_0 : emb.type;
     if (rope_theta) *rope_theta = (float)theta;
     return GL3_OK;
 }
@@ -308,11 +390,22 @@ int32_t gl3_load_gguf(const char* path, const gl3_model_desc* opts, gl3_ctx** ou
     if ((r = gl3_gguf_model_desc(g, &d, &theta)) != GL3_OK) { g_open_err = g->err; gl3_gguf_close(g); return r; }
     gl3_ctx* ctx = nullptr;
     if ((r = gl3_create(&d, &ctx)) != GL3_OK) { g_open_err = gl3_last_error(nullptr); gl3_gguf_close(g); return r; }
+    std::vector<uint8_t> kq;          // Q8_0 image of the K-quant tensor being uploaded
     auto up = [&](const std::string& name, int id, int layer, bool required) -> int32_t {
         auto it = g->by_name.find(name);
         if (it == g->by_name.end()) return required ? GL3_E_STATE : GL3_OK;
         const TensorInfo& t = g->tensors[it->second];
-        return gl3_upload_tensor(ctx, id, layer, g->base + g->data_off + t.offset, t.bytes, t.type);
+        const uint8_t* data = g->base + g->data_off + t.offset;
+        if (t.type == GL3_TYPE_Q4_K || t.type == GL3_TYPE_Q5_K || t.type == GL3_TYPE_Q6_K) {     // K-quant -> Q8_0 at load
+            uint64_t n = 1;
+            for (int dd = 0; dd < t.n_dims; ++dd) n *= t.ne[dd];
+            if (n % 256) return GL3_E_ARG;
+            kq.resize((size_t)(n / 32 * 34));
+            int32_t rr = gl3_kquant_to_q8_0(t.type, data, n, kq.data());
+            if (rr != GL3_OK) return rr;
+            return gl3_upload_tensor(ctx, id, layer, kq.data(), kq.size(), GL3_TYPE_Q8_0);
+        }
+        return gl3_upload_tensor(ctx, id, layer, data, t.bytes, t.type);
     };
     r = up("token_embd.weight", GL3_T_TOKEN_EMBD, 0, true);
     if (r == GL3_OK) r = up("output_norm.weight", GL3_T_OUTPUT_NORM, 0, true);

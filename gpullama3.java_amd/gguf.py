@@ -18,7 +18,9 @@ GGUF_MAGIC = 0x46554747
 ALIGNMENT = 32
 
 GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0 = 0, 1, 2, 8
-TYPE_SIZE = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_Q4_0: (32, 18), GGML_Q8_0: (32, 34)}
+GGML_Q4_K, GGML_Q5_K, GGML_Q6_K = 12, 13, 14        # K-quants: 256-element super-blocks (J/tensor/GGMLType.java:18-20)
+TYPE_SIZE = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_Q4_0: (32, 18), GGML_Q8_0: (32, 34),
+             GGML_Q4_K: (256, 144), GGML_Q5_K: (256, 176), GGML_Q6_K: (256, 210)}
 
 # gguf_metadata_value_type
 _U8, _I8, _U16, _I16, _U32, _I32, _F32, _BOOL, _STR, _ARR, _U64, _I64, _F64 = range(13)

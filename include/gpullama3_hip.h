@@ -62,7 +62,8 @@ typedef enum {
 enum { GL3_ARCH_LLAMA = 0, GL3_ARCH_QWEN3 = 1, GL3_ARCH_QWEN2 = 2 };
 
 /* ggml tensor types of the wire format (J/tensor/GGMLType.java:5-21) */
-enum { GL3_TYPE_F32 = 0, GL3_TYPE_F16 = 1, GL3_TYPE_Q4_0 = 2, GL3_TYPE_Q8_0 = 8 };
+enum { GL3_TYPE_F32 = 0, GL3_TYPE_F16 = 1, GL3_TYPE_Q4_0 = 2, GL3_TYPE_Q8_0 = 8,
+       GL3_TYPE_Q4_K = 12, GL3_TYPE_Q5_K = 13, GL3_TYPE_Q6_K = 14 };   /* K-quants: converted to Q8_0 at load (gl3_kquant_to_q8_0) */
 
 /* weight set (J/inference/weights/tornado/TornadoWeights.java:20-48; GGUF names in
  * J/model/loader/LlamaModelLoader.java:83-98, Qwen3ModelLoader.java:96-118) */
@@ -264,6 +265,12 @@ GL3_API int32_t gl3_gguf_meta_string(const gl3_gguf* g, const char* key, const c
 GL3_API int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* desc, float* rope_theta);
 /* RoPE.precomputeFreqsCis with ropeScaling = false: cr / ci are f32[ctx * head_size/2]. */
 GL3_API void gl3_rope_table(int32_t ctx, int32_t head_size, float theta, float* cr, float* ci);
+/* ModelLoader.dequantizeToQ8_0TornadoTensor (J/model/loader/ModelLoader.java:173-224): the load-time conversion the reference's GPU
+ * path applies to Q4_K / Q5_K / Q6_K tensors — element-wise getFloat of the CPU tensor classes (Q4_KFloatTensor.java:86-114,
+ * Q5_KFloatTensor.java:86-120, Q6_KFloatTensor.java) re-quantised to Q8_0 blocks.  n_elements % 256 == 0; dst: n / 32 * 34 bytes.
+ * gl3_load_gguf applies it to every K-quant tensor; a host that uploads tensors itself can call it first. */
+GL3_API int32_t gl3_kquant_to_q8_0(int32_t src_type, const void* src, uint64_t n_elements, void* dst);
+
 /* open + gl3_create + one gl3_upload_tensor per tensor + RoPE table + gl3_finalize (not finalized when opts->tp_size > 1 or
  * GL3_FLAG_FORCE_RCCL is set: call gl3_tp_init / gl3_tp_attach_local and gl3_finalize).  opts may be NULL; it supplies
  * ctx / max_batch / device / tp_rank / tp_size / flags / n_seqs. */
