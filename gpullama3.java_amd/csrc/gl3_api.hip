@@ -67,7 +67,7 @@ static hipError_t allow_big_lds() {
 
 // rows_valid / out / resid_in may address a slice (tensor parallel row split); w holds exactly that slice.
 static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const Q8Mat* w2, const float* x,
-                          const float* norm_w, float* out, const float* resid_in) {
+                          const float* norm_w, float* out, const float* resid_in, float out_scale = 1.0f) {
     if (w.fmt != GL3_TYPE_Q8_0) {      // F16 / Q4_0: element-wise chains, one output row per lane (gl3_rowlane_kernels.h)
         hipStream_t s = ctx->stream;
         if (pro == PRO_RMS) {
@@ -77,7 +77,7 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
         }
         if (w.vl) {                   // Vector-API order (8 accumulator lanes per row): lane = (row, accumulator), HBM-bound
             VlArgs v{};
-            v.w = w.w; v.w2 = w2 ? w2->w : nullptr; v.rows = w.rows; v.k = w.k; v.x = x; v.out = out; v.resid_in = resid_in;
+            v.w = w.w; v.w2 = w2 ? w2->w : nullptr; v.rows = w.rows; v.k = w.k; v.x = x; v.out = out; v.resid_in = resid_in; v.out_scale = out_scale;
             const dim3 vg(((w.rows + 7) / 8 + VL_WAVES - 1) / VL_WAVES), vb(64 * VL_WAVES);
             const size_t vs = vl_smem_bytes(w.k);
 #define GL3_VL(WT_) \
@@ -91,7 +91,7 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
             return;
         }
         RlArgs a{};
-        a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.k = w.k; a.x = x; a.out = out; a.resid_in = resid_in;
+        a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.k = w.k; a.x = x; a.out = out; a.resid_in = resid_in; a.out_scale = out_scale;
         const dim3 grid((w.rows + 63) / 64);
         const size_t sm = rl_smem_bytes(w.k, epi);
 #define GL3_RL(WT_) \
@@ -108,7 +108,7 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
     static const int max_wgs = getenv("GL3_WGS") ? atoi(getenv("GL3_WGS")) : 512;   // 2 resident workgroups per CU
     MatvecArgs a{};
     a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.k = w.k; a.ng = w.ng; a.nstrips = w.nstrips;
-    a.x = x; a.norm_w = norm_w; a.eps = ctx->d.rms_eps; a.out = out; a.resid_in = resid_in;
+    a.x = x; a.norm_w = norm_w; a.eps = ctx->d.rms_eps; a.out = out; a.resid_in = resid_in; a.out_scale = out_scale;
     const int wgs = w.nstrips < max_wgs ? w.nstrips : max_wgs;
     const size_t smem = matvec_smem(pro, epi, w);
     if (pro == PRO_RMS && epi == EPI_STORE) launch_matvec_t<PRO_RMS, EPI_STORE>(ctx, a, wgs, smem, nt);
@@ -175,7 +175,7 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
     aa.dyn = ctx->dyn_cur; aa.att = ctx->att; aa.xb = ctx->xb + (size_t)d.tp_rank * ctx->q_dim_l;
     aa.n_heads = ctx->heads_l; aa.n_kv_heads = ctx->kv_heads_l;
     aa.hs = d.head_size; aa.q_dim = ctx->q_dim_l; aa.kv_dim = ctx->kv_dim_l; aa.ctx = d.ctx;
-    aa.eps = d.rms_eps; aa.arch = d.arch;
+    aa.eps = d.rms_eps; aa.arch = ctx->rope_arch; aa.att_mul = ctx->att_mul;
     const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 4) + d.head_size) * 4;
     const int pv_rows = d.ctx < PV_ROWS ? d.ctx : PV_ROWS;
     const size_t sm2 = ((size_t)((d.ctx + 3) & ~3) + (size_t)pv_rows * PV_COLS) * 4;
@@ -197,11 +197,11 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
     int32_t r;
 
     pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
-    if (ctx->emb.fmt == GL3_TYPE_Q8_0) hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn_cur, ctx->x);
-    else if (ctx->emb.vl && ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_vl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x);
-    else if (ctx->emb.vl) hipLaunchKernelGGL((embed_vl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x);
-    else if (ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_rl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x);
-    else hipLaunchKernelGGL((embed_rl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x);
+    if (ctx->emb.fmt == GL3_TYPE_Q8_0) hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
+    else if (ctx->emb.vl && ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_vl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
+    else if (ctx->emb.vl) hipLaunchKernelGGL((embed_vl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
+    else if (ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_rl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
+    else hipLaunchKernelGGL((embed_rl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
     pr.end();
 
     for (int l = 0; l < d.n_layers; ++l) {
@@ -218,7 +218,7 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         // x[rows of this rank] += Wo[rows, :] . xb
         pr.begin(GL3_K_MATVEC_WO, mv_bytes(L.wo), q8);
         launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->x + (size_t)rank * ctx->dim_l,
-                      ctx->x + (size_t)rank * ctx->dim_l);
+                      ctx->x + (size_t)rank * ctx->dim_l, ctx->resid_scale);
         pr.end();
         if ((r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
 
@@ -229,7 +229,7 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
 
         pr.begin(GL3_K_MATVEC_DOWN, mv_bytes(L.w2), q8);
         launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->x + (size_t)rank * ctx->dim_l,
-                      ctx->x + (size_t)rank * ctx->dim_l);
+                      ctx->x + (size_t)rank * ctx->dim_l, ctx->resid_scale);
         pr.end();
         if ((r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
         if (ctx->taps) hipMemcpyAsync(ctx->taps + (size_t)l * d.dim, ctx->x, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, s);
@@ -237,7 +237,7 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
     if (want_logits) {
         pr.begin(GL3_K_MATVEC_LOGITS, mv_bytes(ctx->wcls) + d.dim * 4, q8);
         launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm,
-                      ctx->logits + (size_t)rank * ctx->vocab_l, nullptr);
+                      ctx->logits + (size_t)rank * ctx->vocab_l, nullptr, ctx->logit_scale);
         pr.end();
         if ((r = all_gather(ctx, GB_LOGITS, ctx->vocab_l, pr)) != GL3_OK) return r;
     }
@@ -299,7 +299,13 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     const gl3_model_desc& d = ctx->d;
     auto bail = [&](int32_t code, const std::string& msg) { g_create_err = msg.empty() ? ctx->err : msg; gl3_destroy(ctx); return code; };
     const double t0 = now_ms();
-    if (d.arch != GL3_ARCH_LLAMA && d.arch != GL3_ARCH_QWEN3 && d.arch != GL3_ARCH_QWEN2) return bail(GL3_E_UNSUPPORTED, "unsupported architecture");
+    if (d.arch != GL3_ARCH_LLAMA && d.arch != GL3_ARCH_QWEN3 && d.arch != GL3_ARCH_QWEN2 && d.arch != GL3_ARCH_GRANITE)
+        return bail(GL3_E_UNSUPPORTED, "unsupported architecture");
+    ctx->rope_arch = d.arch == GL3_ARCH_GRANITE ? 0 : d.arch;       // Granite: the Llama graph (adjacent-pair RoPE) + four scalars
+    if (d.arch == GL3_ARCH_GRANITE) {
+        if (!(d.attention_scale > 0.f)) return bail(GL3_E_ARG, "granite: attention_scale must be > 0");
+        ctx->emb_scale = d.embedding_scale; ctx->resid_scale = d.residual_scale; ctx->logit_scale = d.logit_scale; ctx->att_mul = d.attention_scale;
+    }
     if (d.weight_type != GL3_TYPE_Q8_0 && d.weight_type != GL3_TYPE_F16 && d.weight_type != GL3_TYPE_Q4_0)
         return bail(GL3_E_UNSUPPORTED, "matrix weight type must be Q8_0, F16 or Q4_0");
     if (d.weight_type != GL3_TYPE_Q8_0 && (d.dim % 64 || d.hidden % 64 || (d.n_heads * d.head_size) % 64))

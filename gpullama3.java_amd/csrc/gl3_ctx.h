@@ -75,6 +75,10 @@ struct gl3_ctx {
     // derived (local = this tensor-parallel rank's share)
     int q_dim = 0, kv_dim = 0, heads_l = 0, kv_heads_l = 0, q_dim_l = 0, kv_dim_l = 0, hidden_l = 0, vocab_l = 0, dim_l = 0;
     int n_tsplit = 1;        // ceil(ctx / 64) score tiles
+    // Granite (InferenceCore.forwardGranite): embedding / residual / logit multipliers (1 otherwise) and the score multiplier
+    // (0 = divide by sqrt(head_size)); rope_arch = RoPE / per-head-norm flavour of the kernels (0 adjacent pairs, 1 qwen3, 2 NeoX)
+    float emb_scale = 1.f, resid_scale = 1.f, logit_scale = 1.f, att_mul = 0.f;
+    int rope_arch = 0;
     hipStream_t stream = nullptr;
     // weights
     Q8Mat emb, wcls;

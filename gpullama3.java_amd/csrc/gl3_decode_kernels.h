@@ -65,6 +65,8 @@ struct MatvecArgs {
     float eps;
     float* out;              // EPI_STORE: out[row]; EPI_SWIGLU: hb[row]; EPI_RESID: out[row] = resid_in[row] + acc
     const float* resid_in;   // may be NULL (tensor-parallel ranks > 0)
+    float out_scale;         // EPI_STORE / EPI_RESID: the row result is multiplied by this first (1 except Granite: residualScale after wo /
+                             // down, logitScale on the logits — InferenceCore.forwardGranite :893-894, :911-912, :921; x * 1.0f is exact)
 };
 
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
@@ -350,8 +352,8 @@ __global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_
             const int row = strip * 16 + 4 * (lane >> 4) + r;
             if (row < a.rows) {
                 const float v0 = r == 0 ? acc[0][0] : r == 1 ? acc[0][1] : r == 2 ? acc[0][2] : acc[0][3];
-                if (EPI == EPI_STORE) a.out[row] = v0;
-                if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + v0 : v0;
+                if (EPI == EPI_STORE) a.out[row] = v0 * a.out_scale;
+                if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + v0 * a.out_scale : v0 * a.out_scale;
                 if (EPI == EPI_SWIGLU) {                  // InferenceCore.java:155-158, exp in double
                     const float v1 = r == 0 ? acc[NM - 1][0] : r == 1 ? acc[NM - 1][1] : r == 2 ? acc[NM - 1][2] : acc[NM - 1][3];
                     const float gte = v0 / (float)(1.0 + exp(-(double)v0));
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_
 // Embedding row gather + dequant: x[i] = q * d  (token_embedding_table.copyTo, InferenceCore.java:61;
 // replaces the host row copy of forwardTornadoVM :956-980 + convertQ8_0toFP32).
 static __global__ __launch_bounds__(256) void embed_q8t_kernel(const uint8_t* __restrict__ emb, int ng, int dim,
-                                                         const int* __restrict__ dyn, float* __restrict__ x) {
+                                                         const int* __restrict__ dyn, float* __restrict__ x, float emb_scale) {
     const int token = dyn[0];
     const uint8_t* strip = emb + (size_t)(token >> 4) * ng * TILE_BYTES;
     const int i16 = token & 15;
@@ -376,7 +378,7 @@ static __global__ __launch_bounds__(256) void embed_q8t_kernel(const uint8_t* __
         const int l = i16 + 16 * (b & 3);
         const float d = h2f(*reinterpret_cast<const uint16_t*>(p + 2 * l));
         const int8_t q = (int8_t)p[(j < 16 ? 128 : 1152) + 16 * l + (j & 15)];
-        x[i] = (float)q * d;
+        x[i] = ((float)q * d) * emb_scale;        // Granite: embeddingScale (forwardGranite :829); 1 otherwise (exact)
     }
 }
 
@@ -408,6 +410,7 @@ struct AttnArgs {
     const int* posv;
     size_t seq_stride;       // floats between the KV caches of consecutive sequences
     int qkv_stride, xb_stride;   // floats between consecutive tokens' rows of qkv / xb
+    float att_mul;           // 0: score / sqrt(head_size); Granite: score * attentionScale (forwardGranite :870-872)
     int group;               // attn_head_kernel: query heads per workgroup (0 / 1: one; kvMul: the whole group of a kv head)
 };
 
@@ -524,7 +527,7 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
         }
         score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
         const float sqrt_hs = (float)sqrt((double)hs);
-        a.att[(size_t)(kvh * kvmul + hq) * a.ctx + t0 + r] = score / sqrt_hs;
+        a.att[(size_t)(kvh * kvmul + hq) * a.ctx + t0 + r] = a.att_mul != 0.f ? score * a.att_mul : score / sqrt_hs;
     }
 }
 
@@ -642,7 +645,7 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
             qv = qn; kv = kn;
         }
         score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
-        sc = score / sqrt_hs;
+        sc = a.att_mul != 0.f ? score * a.att_mul : score / sqrt_hs;
         if (G > 1) e_s[g * AF_MAXN + tt] = sc;
     }
     ATT_STAMP(3);

@@ -329,7 +329,8 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
     if (a == "llama") d->arch = GL3_ARCH_LLAMA;
     else if (a == "qwen3") d->arch = GL3_ARCH_QWEN3;
     else if (a == "qwen2") d->arch = GL3_ARCH_QWEN2;
-    else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, qwen3, qwen2)");
+    else if (a == "granite") d->arch = GL3_ARCH_GRANITE;
+    else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, qwen3, qwen2, granite)");
     auto need = [&](const char* k, double* v) { return meta_num(g, a + "." + k, v); };
     // defaults as the reference loaders: rms epsilon 1e-5, rope theta 10000 (LlamaModelLoader.java:62-63)
     double dim, hid, nl, nh, nkv, eps = 1e-5, theta = 10000.0, ctx, kl;
@@ -355,6 +356,11 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
     if (d->ctx <= 0) d->ctx = ctx < 4096 ? (int32_t)ctx : 4096;
     else if (d->ctx > (int32_t)ctx) d->ctx = (int32_t)ctx;
     d->rms_eps = (float)eps;
+    if (d->arch == GL3_ARCH_GRANITE) {          // GraniteLoader.java:55-58 (same defaults)
+        double es = 12.0, rs = 0.22, as = 0.0078125, ls = 16.0;
+        need("embedding_scale", &es); need("residual_scale", &rs); need("attention.scale", &as); need("logit_scale", &ls);
+        d->embedding_scale = (float)es; d->residual_scale = (float)rs; d->attention_scale = (float)as; d->logit_scale = (float)ls;
+    }
     // K-quant files run as Q8_0 after the load-time conversion (ModelLoader.loadTornadoTensor :163-164)
     d->weight_type = (emb.type == GL3_TYPE_Q4_K || emb.type == GL3_TYPE_Q5_K || emb.type == GL3_TYPE_Q6_K) ? GL3_TYPE_Q8_0 : emb.type;
     if (rope_theta) *rope_theta = (float)theta;

@@ -48,7 +48,7 @@ typedef int v16i_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ size_t chunked(int b, int j, int cc, int ntok) { return ((size_t)(j / cc) * ntok + b) * cc + (j % cc); }
 
 __global__ __launch_bounds__(256) void pf_embed_kernel(const uint8_t* __restrict__ emb, int ng, int dim,
-                                                        const int32_t* __restrict__ tokens, float* __restrict__ X, int cc) {
+                                                        const int32_t* __restrict__ tokens, float* __restrict__ X, int cc, float emb_scale) {
     const int token = tokens[blockIdx.x];
     const uint8_t* strip = emb + (size_t)(token >> 4) * ng * TILE_BYTES;
     const int i16 = token & 15;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void pf_embed_kernel(const uint8_t* __restrict
         const int l = i16 + 16 * (b & 3);
         const float d = h2f(*reinterpret_cast<const uint16_t*>(p + 2 * l));
         const int8_t q = (int8_t)p[(j < 16 ? 128 : 1152) + 16 * l + (j & 15)];
-        X[chunked(bt, i, cc, nt)] = (float)q * d;
+        X[chunked(bt, i, cc, nt)] = ((float)q * d) * emb_scale;
     }
 }
 
@@ -122,6 +122,7 @@ struct GemmArgs {
     int ntt, nrt;                         // token tiles, row tiles (grid = 8 * ceil(ntt * nrt / 8), see the XCD mapping)
     int ntok;
     float* out; int out_stride;           // EPI_STORE / EPI_SWIGLU: out[b*stride + row]; EPI_RESID: out +=
+    float out_scale;                      // EPI_STORE / EPI_RESID: result *= out_scale first (Granite; 1 otherwise, exact)
 };
 
 // LDS-tiled version: workgroup = 128 weight rows (64 gate + 64 up rows for the SwiGLU epilogue) x 128 tokens, 4
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float4 v = {acc[f][tf][2 * q][0], acc[f][tf][2 * q][1], acc[f][tf][2 * q + 1][0], acc[f][tf][2 * q + 1][1]};
+                    float4 v = {acc[f][tf][2 * q][0] * a.out_scale, acc[f][tf][2 * q][1] * a.out_scale, acc[f][tf][2 * q + 1][0] * a.out_scale, acc[f][tf][2 * q + 1][1] * a.out_scale};
                     if (rbase + 8 * q + 3 < a.rows) {
                         if (EPI == EPI_RESID) { v.x = old[q].x + v.x; v.y = old[q].y + v.y; v.z = old[q].z + v.z; v.w = old[q].w + v.w; }
                         *reinterpret_cast<float4*>(o + 8 * q) = v;
@@ -563,8 +564,8 @@ __global__ __launch_bounds__(bd_threads(BD_NP)) void bd_gemm_kernel(const GemmAr
                 float g = v0;
                 g = g / (float)(1.0 + exp(-(double)g));
                 o[i] = g * acc[NM - 1][j][i >> 1][i & 1];
-            } else if (EPI == EPI_STORE) o[i] = v0;
-            else o[i] = o[i] + v0;
+            } else if (EPI == EPI_STORE) o[i] = v0 * a.out_scale;
+            else o[i] = o[i] + v0 * a.out_scale;
         }
     }
 }
@@ -617,6 +618,7 @@ struct PfAttnArgs {
     float* out; int out_stride;          // [ntok][q_dim]
     int n_heads, n_kv_heads, hs, kv_dim, ctx;
     const int32_t* seq; const int32_t* pos; size_t seq_stride;
+    float att_mul;                       // 0: score / sqrt(head_size); Granite: score * attentionScale
 };
 
 __global__ void pf_attn_scores_kernel(const PfAttnArgs a) {
@@ -647,7 +649,7 @@ __global__ void pf_attn_scores_kernel(const PfAttnArgs a) {
         float score = 0.f;
         for (int j = 0; j < hs; ++j) score = score + q[j] * kk[j];
         const float sqrt_hs = (float)sqrt((double)hs);
-        a.att[((size_t)b * a.n_heads + kvh * kvmul + hq) * a.ctx + t0 + r] = score / sqrt_hs;
+        a.att[((size_t)b * a.n_heads + kvh * kvmul + hq) * a.ctx + t0 + r] = a.att_mul != 0.f ? score * a.att_mul : score / sqrt_hs;
     }
 }
 
@@ -713,7 +715,7 @@ constexpr int PA_TB = 16;
 template <int HS>
 __global__ __launch_bounds__(256) void pf_scores_tiled_kernel(const float* __restrict__ Q, int q_stride, const float* __restrict__ kc,
                                                               float* __restrict__ att, int n_heads, int kvmul, int kv_dim, int ctx,
-                                                              int pos0, int ntok) {
+                                                              int pos0, int ntok, float att_mul) {
     extern __shared__ __attribute__((aligned(16))) float kt[];       // [64][PITCH]
     constexpr int PITCH = HS + 4, H4 = HS / 4;
     const int t = threadIdx.x, nthr = blockDim.x;
@@ -763,8 +765,8 @@ __global__ __launch_bounds__(256) void pf_scores_tiled_kernel(const float* __res
         }
         const int b = b0 + tb;
         if (t0 + r < t1) {
-            if (t0 + r <= pos0 + b) att[((size_t)b * n_heads + head) * ctx + t0 + r] = s0 / sqrt_hs;
-            if (tb + 1 < nb && t0 + r <= pos0 + b + 1) att[((size_t)(b + 1) * n_heads + head) * ctx + t0 + r] = s1 / sqrt_hs;
+            if (t0 + r <= pos0 + b) att[((size_t)b * n_heads + head) * ctx + t0 + r] = att_mul != 0.f ? s0 * att_mul : s0 / sqrt_hs;
+            if (tb + 1 < nb && t0 + r <= pos0 + b + 1) att[((size_t)(b + 1) * n_heads + head) * ctx + t0 + r] = att_mul != 0.f ? s1 * att_mul : s1 / sqrt_hs;
         }
     }
 }
@@ -957,11 +959,11 @@ void gl3_prefill_free(gl3_ctx* ctx) {
 }
 
 template <int EPI>
-static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok, float* out, int out_stride) {
+static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok, float* out, int out_stride, float out_scale = 1.0f) {
     gl3_prefill_state* p = ctx->pf;
     GemmArgs a{};
     a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.ng = w.ng; a.nb = w.k / 32;
-    a.XQ = p->XQ; a.XS = p->XS; a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride;
+    a.XQ = p->XQ; a.XS = p->XS; a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride; a.out_scale = out_scale;
     // 128-row tiles only when they still give >= 2 workgroups per CU; otherwise 64-row tiles, and 8 wavefronts per
     // workgroup when even those leave a single workgroup per CU
     static const bool bd_off = getenv("GL3_NO_BD_GEMM") && atoi(getenv("GL3_NO_BD_GEMM"));
@@ -1019,7 +1021,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
     float* AOr = p->AO + (size_t)rank * n * qd;
     float* HBr = p->HB + (size_t)rank * n * hid;
     int32_t r;
-    hipLaunchKernelGGL(pf_embed_kernel, dim3(n), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, p->tokens, p->X, dml);
+    hipLaunchKernelGGL(pf_embed_kernel, dim3(n), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, p->tokens, p->X, dml, ctx->emb_scale);
     auto nq_smem = [&](int k) { return (size_t)(k + 32) * 4 + ss_scratch_bytes(k) + 64; };
     for (int l = 0; l < d.n_layers; ++l) {
         gl3_layer& L = ctx->layers[l];
@@ -1030,11 +1032,11 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         ra.QKV = p->QKV; ra.qkv_stride = qkv_dim; ra.kcache = ctx->kcache + l * kv_layer; ra.vcache = ctx->vcache + l * kv_layer;
         ra.cr = ctx->rope_cr; ra.ci = ctx->rope_ci; ra.qnorm = L.qnorm; ra.knorm = L.knorm; ra.bq = L.bq; ra.bk = L.bk; ra.bv = L.bv; ra.n_heads = H;
         ra.n_kv_heads = KVH; ra.hs = d.head_size; ra.q_dim = qd; ra.kv_dim = kvd;
-        ra.arch = d.arch; ra.eps = d.rms_eps; ra.seq = seq; ra.pos = pos; ra.seq_stride = ctx->kv_seq_stride;
+        ra.arch = ctx->rope_arch; ra.eps = d.rms_eps; ra.seq = seq; ra.pos = pos; ra.seq_stride = ctx->kv_seq_stride;
         PfAttnArgs aa{};
         aa.Q = p->QKV; aa.q_stride = qkv_dim; aa.kcache = ra.kcache; aa.vcache = ra.vcache; aa.att = p->ATT; aa.out = AOr;
         aa.out_stride = qd; aa.n_heads = H; aa.n_kv_heads = KVH; aa.hs = d.head_size; aa.kv_dim = kvd;
-        aa.ctx = d.ctx; aa.seq = seq; aa.pos = pos; aa.seq_stride = ctx->kv_seq_stride;
+        aa.ctx = d.ctx; aa.seq = seq; aa.pos = pos; aa.seq_stride = ctx->kv_seq_stride; aa.att_mul = ctx->att_mul;
         const int nsplit = (max_pos + 1 + ATT_TT - 1) / ATT_TT;
         const int hs = d.head_size;
         if (one_seq < 0 && fused_decode) {
@@ -1044,7 +1046,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
             ha.qkv = p->QKV; ha.qkv_stride = qkv_dim; ha.kcache = ra.kcache; ha.vcache = ra.vcache; ha.rope_cr = ctx->rope_cr; ha.rope_ci = ctx->rope_ci;
             ha.qnorm = L.qnorm; ha.knorm = L.knorm; ha.bq = L.bq; ha.bk = L.bk; ha.bv = L.bv; ha.dyn = ctx->dyn; ha.att = nullptr;
             ha.xb = AOr; ha.xb_stride = qd; ha.n_heads = H; ha.n_kv_heads = KVH; ha.hs = hs; ha.q_dim = qd; ha.kv_dim = kvd; ha.ctx = d.ctx;
-            ha.eps = d.rms_eps; ha.arch = d.arch; ha.seqv = seq; ha.posv = pos; ha.seq_stride = ctx->kv_seq_stride;
+            ha.eps = d.rms_eps; ha.arch = ctx->rope_arch; ha.att_mul = ctx->att_mul; ha.seqv = seq; ha.posv = pos; ha.seq_stride = ctx->kv_seq_stride;
             ha.group = bd_group;
             hipLaunchKernelGGL(attn_head_kernel, dim3(H / bd_group, n), dim3(256), attn_head_smem(hs, bd_group), s, ha);
         } else {
@@ -1055,7 +1057,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
             const size_t sms = (size_t)64 * (hs + 4) * 4;
             const dim3 g1(nsplit, KVH, ntt), b1(64 * kvmul);
             const float* kc1 = aa.kcache + (size_t)one_seq * ctx->kv_seq_stride;
-#define GL3_SCORES(HS_) hipLaunchKernelGGL((pf_scores_tiled_kernel<HS_>), g1, b1, sms, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n)
+#define GL3_SCORES(HS_) hipLaunchKernelGGL((pf_scores_tiled_kernel<HS_>), g1, b1, sms, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul)
             if (hs == 128) GL3_SCORES(128);
             else if (hs == 64) GL3_SCORES(64);
             else GL3_SCORES(32);
@@ -1075,7 +1077,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         if ((r = gl3_all_gather(ctx, GB_PF_AO, (size_t)n * qd)) != GL3_OK) return r;
         hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->AO, ctx->q_dim, qd, (const float*)nullptr,
                            0.f, p->XQ, p->XS, p->maxk);
-        launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, Xr, dml);
+        launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, Xr, dml, ctx->resid_scale);
         if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
         hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.ffn_norm, d.rms_eps,
                            p->XQ, p->XS, p->maxk);
@@ -1083,7 +1085,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         if ((r = gl3_all_gather(ctx, GB_PF_HB, (size_t)n * hid)) != GL3_OK) return r;
         hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->HB, d.hidden, hid, (const float*)nullptr, 0.f,
                            p->XQ, p->XS, p->maxk);
-        launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, Xr, dml);
+        launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, Xr, dml, ctx->resid_scale);
         if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
     }
     GL3_HIP(hipGetLastError());
@@ -1153,7 +1155,7 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
         const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
         hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk);
         // vocab rows are split across ranks: this rank's logits are the chunk [n][vocab / tp] of the rank-chunked buffer
-        launch_gemm<EPI_STORE>(ctx, ctx->wcls, nullptr, n, p->LOGITS + (size_t)d.tp_rank * n * vl, vl);
+        launch_gemm<EPI_STORE>(ctx, ctx->wcls, nullptr, n, p->LOGITS + (size_t)d.tp_rank * n * vl, vl, ctx->logit_scale);
         if ((rr = gl3_all_gather(ctx, GB_PF_LOGITS, (size_t)n * vl)) != GL3_OK) return rr;
         hipLaunchKernelGGL(pf_argmax_rows_kernel, dim3(n), dim3(1024), 0, s, p->LOGITS, d.vocab, p->amax, vl);
         return GL3_OK;

@@ -53,18 +53,18 @@ static __global__ __launch_bounds__(256) void repack_rl_kernel(const uint8_t* __
 // token_embedding_table.copyTo -> getFloat per element (InferenceCore.java:61)
 template <int WT>
 static __global__ __launch_bounds__(256) void embed_rl_kernel(const uint8_t* __restrict__ emb, int dim, const int* __restrict__ dyn,
-                                                              float* __restrict__ x) {
+                                                              float* __restrict__ x, float emb_scale) {
     const int token = dyn[0], g = token >> 6, lane = token & 63;
     const uint8_t* gb = emb + (size_t)g * rl_group_bytes(WT, dim);
     for (int i = threadIdx.x; i < dim; i += 256) {
         if (WT == WT_F16) {
-            x[i] = h2f(*reinterpret_cast<const uint16_t*>(gb + (size_t)(i >> 3) * 1024 + lane * 16 + 2 * (i & 7)));
+            x[i] = h2f(*reinterpret_cast<const uint16_t*>(gb + (size_t)(i >> 3) * 1024 + lane * 16 + 2 * (i & 7))) * emb_scale;
         } else {
             const uint8_t* b = gb + (size_t)(i >> 5) * 1152;
             const int j = i & 31;
             const uint8_t byte = b[128 + lane * 16 + (j & 15)];
             const int q = j < 16 ? (byte & 0x0F) : (byte >> 4);
-            x[i] = (float)(q - 8) * h2f(*reinterpret_cast<const uint16_t*>(b + 2 * lane));
+            x[i] = ((float)(q - 8) * h2f(*reinterpret_cast<const uint16_t*>(b + 2 * lane))) * emb_scale;
         }
     }
 }
@@ -99,6 +99,7 @@ struct RlArgs {
     int rows, k;
     const float* x;                         // f32[k] activation (normalised where the reference normalises)
     float* out; const float* resid_in;      // EPI_RESID: out[i] = resid_in[i] + result
+    float out_scale;                        // result *= out_scale first (Granite residual / logit scaling; 1 otherwise)
 };
 
 // Workgroup = one 64-row group, 9 wavefronts in two roles (as in matvec_q8t_kernel, register pressure = max of the roles):
@@ -241,8 +242,8 @@ static __global__ __launch_bounds__(RL_THREADS) void matvec_rl_kernel(const RlAr
 #endif
     const int row = g * 64 + lane;
     if (row >= a.rows) return;
-    if (EPI == EPI_STORE) a.out[row] = res[0];
-    else if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + res[0] : res[0];
+    if (EPI == EPI_STORE) a.out[row] = res[0] * a.out_scale;
+    else if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + res[0] * a.out_scale : res[0] * a.out_scale;
     else {
         float gte = res[0];
         gte = gte / (float)(1.0 + exp(-(double)gte));            // InferenceCore.java:155-158

@@ -59,19 +59,19 @@ static __global__ __launch_bounds__(256) void repack_vl_kernel(const uint8_t* __
 // token_embedding_table.copyTo -> getFloat per element (InferenceCore.java:61): SCALAR semantics (IEEE f16 -> f32)
 template <int WT>
 static __global__ __launch_bounds__(256) void embed_vl_kernel(const uint8_t* __restrict__ emb, int dim, const int* __restrict__ dyn,
-                                                              float* __restrict__ x) {
+                                                              float* __restrict__ x, float emb_scale) {
     const int token = dyn[0], g = token >> 3, rr = token & 7;
     const uint8_t* gb = emb + (size_t)g * vl_group_bytes(WT, dim);
     for (int i = threadIdx.x; i < dim; i += 256) {
         if (WT == WT_F16) {
             const int c = i >> 6, e = i & 63, l = e & 7, kk = e >> 3;
-            x[i] = h2f(reinterpret_cast<const uint16_t*>(gb + (size_t)c * 1024 + (rr * 8 + l) * 16)[kk]);
+            x[i] = h2f(reinterpret_cast<const uint16_t*>(gb + (size_t)c * 1024 + (rr * 8 + l) * 16)[kk]) * emb_scale;
         } else {
             const int b = i >> 5, j = i & 31, c = b >> 3, kk = b & 7, l = j & 7;
             const uint8_t* cb = gb + (size_t)c * 1152;
             const uint8_t byte = cb[(rr * 8 + l) * 16 + ((j & 8) ? 8 : 0) + kk];       // j in [8,16) or [24,32): byte 8 + l
             const int q = j < 16 ? (byte & 0x0F) : (byte >> 4);
-            x[i] = (float)(q - 8) * h2f(reinterpret_cast<const uint16_t*>(cb + 1024 + rr * 16)[kk]);
+            x[i] = ((float)(q - 8) * h2f(reinterpret_cast<const uint16_t*>(cb + 1024 + rr * 16)[kk])) * emb_scale;
         }
     }
 }
@@ -81,6 +81,7 @@ struct VlArgs {
     int rows, k;
     const float* x;                         // f32[k] activation (normalised where the reference normalises)
     float* out; const float* resid_in;      // EPI_RESID: out[i] = resid_in[i] + result
+    float out_scale;                        // result *= out_scale first (Granite residual / logit scaling; 1 otherwise)
 };
 
 constexpr int VL_WAVES = 2;                 // 16 rows per workgroup: 4096-row matrices still give one workgroup per CU
@@ -242,8 +243,8 @@ static __global__ __launch_bounds__(64 * VL_WAVES, WT == WT_Q4_0 ? 2 : 1) void m
     }
     const int row = g * 8 + rr;
     if (l == 0 && row < a.rows) {
-        if (EPI == EPI_STORE) a.out[row] = res[0];
-        if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + res[0] : res[0];
+        if (EPI == EPI_STORE) a.out[row] = res[0] * a.out_scale;
+        if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + res[0] * a.out_scale : res[0] * a.out_scale;
         if (EPI == EPI_SWIGLU) {                               // InferenceCore.java:155-158, exp in double
             const float gte = res[0] / (float)(1.0 + exp(-(double)res[0]));
             a.out[row] = gte * res[NM - 1];

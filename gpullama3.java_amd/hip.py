@@ -29,7 +29,8 @@ class ModelDesc(C.Structure):
                 ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("head_size", C.c_int32),
                 ("vocab", C.c_int32), ("ctx", C.c_int32), ("rms_eps", C.c_float), ("weight_type", C.c_int32),
                 ("max_batch", C.c_int32), ("device", C.c_int32), ("tp_rank", C.c_int32), ("tp_size", C.c_int32),
-                ("flags", C.c_uint32), ("n_seqs", C.c_int32)]
+                ("flags", C.c_uint32), ("n_seqs", C.c_int32), ("embedding_scale", C.c_float), ("attention_scale", C.c_float),
+                ("residual_scale", C.c_float), ("logit_scale", C.c_float)]
 
 
 class KernelTimes(C.Structure):

@@ -42,7 +42,8 @@ class HipMasterPlan:
         self._ctx = C.c_void_p()
         d = hip.ModelDesc(C.sizeof(hip.ModelDesc), c.arch, c.dim, c.hidden, c.n_layers, c.n_heads, c.n_kv_heads,
                           c.head_size, c.vocab, c.ctx, c.rms_eps, model.wtype, prefill_batch_size, device, tp_rank,
-                          tp_size, flags, n_seqs)
+                          tp_size, flags, n_seqs, getattr(c, "embedding_scale", 1.0), getattr(c, "attention_scale", 0.0),
+                          getattr(c, "residual_scale", 1.0), getattr(c, "logit_scale", 1.0))
         hip.check(L.gl3_create(C.byref(d), C.byref(self._ctx)))
         self.tp_size, self.tp_rank = tp_size, tp_rank
         self.max_batch = prefill_batch_size

@@ -19,8 +19,8 @@ import numpy as np
 from . import gguf
 from .gguf import GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0
 
-ARCH_LLAMA, ARCH_QWEN3, ARCH_QWEN2 = 0, 1, 2
-_ARCH_NAME = {ARCH_LLAMA: "llama", ARCH_QWEN3: "qwen3", ARCH_QWEN2: "qwen2"}
+ARCH_LLAMA, ARCH_QWEN3, ARCH_QWEN2, ARCH_GRANITE = 0, 1, 2, 3
+_ARCH_NAME = {ARCH_LLAMA: "llama", ARCH_QWEN3: "qwen3", ARCH_QWEN2: "qwen2", ARCH_GRANITE: "granite"}
 
 
 @dataclass
@@ -38,6 +38,11 @@ class ModelConfig:
     rms_eps: float
     rope_theta: float
     tied: bool          # wcls shares token_embd (AbstractModelLoader.java:194)
+    # Granite only (GraniteLoader.java:55-58); neutral values for every other architecture
+    embedding_scale: float = 1.0
+    attention_scale: float = 0.0
+    residual_scale: float = 1.0
+    logit_scale: float = 1.0
 
     @property
     def q_dim(self):
@@ -63,6 +68,11 @@ CONFIGS = {
     "tiny-qwen2": ModelConfig("tiny-qwen2-random", ARCH_QWEN2, 256, 512, 2, 8, 2, 32, 512, 64, 1e-6, 1000000.0, True),
     "mid-qwen2": ModelConfig("mid-qwen2-random", ARCH_QWEN2, 1536, 4480, 2, 12, 2, 128, 2048, 160, 1e-6, 1000000.0, False),
     # multi-head attention (n_heads == n_kv_heads, kvMul = 1) with head_size 128: Llama-2-7B-style head layout
+    # Granite 3.x shape: the Llama graph with the four muP scalars (forwardGranite); values of granite-3.3-2b
+    "tiny-granite": ModelConfig("tiny-granite-random", ARCH_GRANITE, 256, 512, 2, 8, 2, 32, 512, 64, 1e-5, 10000.0, True,
+                                 embedding_scale=12.0, attention_scale=0.015625, residual_scale=0.22, logit_scale=8.0),
+    "mid-granite": ModelConfig("mid-granite-random", ARCH_GRANITE, 2048, 4096, 2, 32, 8, 64, 4096, 160, 1e-5, 10000.0, True,
+                                embedding_scale=12.0, attention_scale=0.015625, residual_scale=0.22, logit_scale=8.0),
     "mha-llama": ModelConfig("mha-llama-random", ARCH_LLAMA, 1024, 2048, 2, 8, 8, 128, 1024, 160, 1e-5, 10000.0, False),
     # full-size SHAPES of the BASELINE models with few layers / a small vocabulary, so that the CPU oracle finishes in seconds:
     # one Llama-3-8B layer (K = 14336: 112 tile groups, activation quads == 14 * 256 exactly), the 128256-row vocabulary
@@ -179,7 +189,9 @@ class SynthModel:
     def oracle_cfg(self):
         c = self.cfg
         return dict(arch=c.arch, dim=c.dim, hidden=c.hidden, n_layers=c.n_layers, n_heads=c.n_heads,
-                    n_kv_heads=c.n_kv_heads, head_size=c.head_size, vocab=c.vocab, ctx=c.ctx, rms_eps=c.rms_eps)
+                    n_kv_heads=c.n_kv_heads, head_size=c.head_size, vocab=c.vocab, ctx=c.ctx, rms_eps=c.rms_eps,
+                    embedding_scale=c.embedding_scale, attention_scale=c.attention_scale, residual_scale=c.residual_scale,
+                    logit_scale=c.logit_scale)
 
     def weight_bytes(self):
         return sum(v[0].nbytes for v in self.tensors.values())
@@ -196,6 +208,9 @@ class SynthModel:
             f"{a}.context_length": c.ctx, f"{a}.attention.layer_norm_rms_epsilon": float(c.rms_eps),
             f"{a}.rope.freq_base": float(c.rope_theta), f"{a}.vocab_size": c.vocab,
         }
+        if c.arch == ARCH_GRANITE:
+            md.update({"granite.embedding_scale": float(c.embedding_scale), "granite.attention.scale": float(c.attention_scale),
+                       "granite.residual_scale": float(c.residual_scale), "granite.logit_scale": float(c.logit_scale)})
         if c.arch == ARCH_QWEN3:
             md[f"{a}.attention.key_length"] = c.head_size
             md[f"{a}.attention.value_length"] = c.head_size
@@ -220,7 +235,9 @@ class SynthModel:
                           md.get(f"{a}.attention.head_count_kv", nh), hs,
                           md.get(f"{a}.vocab_size", g.tensors["token_embd.weight"][0][1]),
                           ctx or md[f"{a}.context_length"], md[f"{a}.attention.layer_norm_rms_epsilon"],
-                          md[f"{a}.rope.freq_base"], "output.weight" not in g.tensors)
+                          md[f"{a}.rope.freq_base"], "output.weight" not in g.tensors,
+                          embedding_scale=md.get("granite.embedding_scale", 1.0), attention_scale=md.get("granite.attention.scale", 0.0),
+                          residual_scale=md.get("granite.residual_scale", 1.0), logit_scale=md.get("granite.logit_scale", 1.0))
         tensors = {}
         for name, (dims, ty, raw) in g.tensors.items():
             rows = dims[1] if len(dims) > 1 else 1

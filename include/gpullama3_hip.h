@@ -59,7 +59,8 @@ typedef enum {
 /* model families with all three plan modes in the reference (ForwardPlanFactory.java:123-141) */
 /* LLAMA: InferenceCore.forwardJava (also Mistral GGUFs, architecture "llama"); QWEN3: forwardJavaQwen3 (per-head q/k RMSNorm,
  * NeoX RoPE); QWEN2: forwardJavaQwen2 :434-563 (q/k/v bias, NeoX RoPE; Qwen2.5, DeepSeek-R1-Distill-Qwen). */
-enum { GL3_ARCH_LLAMA = 0, GL3_ARCH_QWEN3 = 1, GL3_ARCH_QWEN2 = 2 };
+enum { GL3_ARCH_LLAMA = 0, GL3_ARCH_QWEN3 = 1, GL3_ARCH_QWEN2 = 2,
+       GL3_ARCH_GRANITE = 3 /* InferenceCore.forwardGranite :814-924: the Llama graph + embedding / attention / residual / logit scalars */ };
 
 /* ggml tensor types of the wire format (J/tensor/GGMLType.java:5-21) */
 enum { GL3_TYPE_F32 = 0, GL3_TYPE_F16 = 1, GL3_TYPE_Q4_0 = 2, GL3_TYPE_Q8_0 = 8,
@@ -119,6 +120,10 @@ typedef struct {
     int32_t tp_size;        /* tensor-parallel degree: heads / hidden units / vocab rows are split tp_size ways */
     uint32_t flags;         /* GL3_FLAG_* */
     int32_t n_seqs;         /* independent sequences with their own KV cache (static batched decode); 0 or 1 = one */
+    /* GL3_ARCH_GRANITE only (GraniteLoader.java:55-58: granite.embedding_scale, granite.attention.scale, granite.residual_scale,
+     * granite.logit_scale): x *= embedding_scale after the embedding lookup, score *= attention_scale (instead of / sqrt(head_size)),
+     * block output *= residual_scale before the residual add, logits *= logit_scale */
+    float embedding_scale, attention_scale, residual_scale, logit_scale;
 } gl3_model_desc;
 
 /* Per-kernel-class device time of one instrumented decode step (HIP events around every launch). */

@@ -47,9 +47,11 @@ enum {
 };
 
 typedef struct {
-    int32_t arch;       /* 0 = llama (InferenceCore.forwardJava), 1 = qwen3 (forwardJavaQwen3), 2 = qwen2 (forwardJavaQwen2) */
+    int32_t arch;       /* 0 = llama (InferenceCore.forwardJava), 1 = qwen3 (forwardJavaQwen3), 2 = qwen2 (forwardJavaQwen2),
+                           3 = granite (forwardGranite :814-924: the llama graph + the four scalars below) */
     int32_t dim, hidden, n_layers, n_heads, n_kv_heads, head_size, vocab, ctx;
     float   rms_eps;
+    float   embedding_scale, attention_scale, residual_scale, logit_scale;   /* granite only (GraniteLoader.java:55-58) */
 } orc_config;
 
 typedef struct { const void* p; int type; } orc_tensor;
@@ -283,7 +285,7 @@ static void attention(orc_ctx* o, int l, int pos) {
             const float* kk = kc + (size_t)t * kvd + (h / kvmul) * hs;
             float score = 0.f;
             for (int j = 0; j < hs; j++) score += q[j] * kk[j];
-            att[t] = score / sqrt_hs;
+            att[t] = o->c.arch == 3 ? score * o->c.attention_scale : score / sqrt_hs;        /* granite :870-872 */
         }
         softmax(att, pos + 1);
         float* xb = o->xb + h * hs;
@@ -309,6 +311,7 @@ static void forward(orc_ctx* o, int token, int pos, int want_logits, float* laye
     int dim = c->dim, hs = c->head_size, kvd = o->kv_dim, qd = o->q_dim;
     /* weights.token_embedding_table.copyTo(token * dim, state.x, 0, dim) */
     for (int i = 0; i < dim; i++) o->x[i] = t_get(&o->global[ORC_T_TOKEN_EMBD], (size_t)token * dim + i);
+    if (c->arch == 3) for (int i = 0; i < dim; i++) o->x[i] = o->x[i] * c->embedding_scale;       /* forwardGranite :829 */
 
     for (int l = 0; l < c->n_layers; l++) {
         rmsnorm(o->xb, o->x, &o->layer[ORC_T_ATTN_NORM][l], 0, dim, c->rms_eps);
@@ -322,7 +325,7 @@ static void forward(orc_ctx* o, int token, int pos, int want_logits, float* laye
             for (int i = 0; i < kvd; i++) o->k[i] = o->k[i] + t_get(&o->layer[ORC_T_BK][l], i);
             for (int i = 0; i < kvd; i++) o->v[i] = o->v[i] + t_get(&o->layer[ORC_T_BV][l], i);
         }
-        if (c->arch == 0) {
+        if (c->arch == 0 || c->arch == 3) {
             /* adjacent-pair RoPE, q for i<dim and k for i<kvDim — InferenceCore.java:75-87 */
             for (int i = 0; i < dim; i += 2) {
                 int head_dim = i % hs;
@@ -364,6 +367,7 @@ static void forward(orc_ctx* o, int token, int pos, int want_logits, float* laye
         attention(o, l, pos);
 
         matmul(o, &o->layer[ORC_T_WO][l], o->xb, o->xb2, dim, qd);
+        if (c->arch == 3) for (int i = 0; i < dim; i++) o->xb2[i] = o->xb2[i] * c->residual_scale;   /* :893 */
         for (int i = 0; i < dim; i++) o->x[i] = o->x[i] + o->xb2[i];
 
         rmsnorm(o->xb, o->x, &o->layer[ORC_T_FFN_NORM][l], 0, dim, c->rms_eps);
@@ -376,12 +380,14 @@ static void forward(orc_ctx* o, int token, int pos, int want_logits, float* laye
             o->hb[i] = v * o->hb2[i];
         }
         matmul(o, &o->layer[ORC_T_W2][l], o->hb, o->xb, dim, c->hidden);
+        if (c->arch == 3) for (int i = 0; i < dim; i++) o->xb[i] = o->xb[i] * c->residual_scale;     /* :911 */
         for (int i = 0; i < dim; i++) o->x[i] = o->x[i] + o->xb[i];
         if (layer_x) memcpy(layer_x + (size_t)l * dim, o->x, sizeof(float) * dim);
     }
     if (!want_logits) return;
     rmsnorm(o->x, o->x, &o->global[ORC_T_OUTPUT_NORM], 0, dim, c->rms_eps);
     matmul(o, &o->global[ORC_T_OUTPUT], o->x, o->logits, c->vocab, dim);
+    if (c->arch == 3) for (int i = 0; i < c->vocab; i++) o->logits[i] = o->logits[i] * c->logit_scale;   /* :921 */
 }
 
 /* ------------------------------- C API ----------------------------------- */

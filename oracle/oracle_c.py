@@ -22,7 +22,9 @@ T_IDS = {"token_embd.weight": 0, "output_norm.weight": 1, "output.weight": 2, "a
 
 class OrcConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("arch", "dim", "hidden", "n_layers", "n_heads", "n_kv_heads",
-                                          "head_size", "vocab", "ctx")] + [("rms_eps", C.c_float)]
+                                          "head_size", "vocab", "ctx")] + [("rms_eps", C.c_float), ("embedding_scale", C.c_float),
+                                                                           ("attention_scale", C.c_float), ("residual_scale", C.c_float),
+                                                                           ("logit_scale", C.c_float)]
 
 
 def build(force: bool = False):
@@ -84,7 +86,9 @@ class COracle:
         L = lib()
         c = model.cfg
         self.cfg = c
-        oc = OrcConfig(c.arch, c.dim, c.hidden, c.n_layers, c.n_heads, c.n_kv_heads, c.head_size, c.vocab, c.ctx, c.rms_eps)
+        oc = OrcConfig(c.arch, c.dim, c.hidden, c.n_layers, c.n_heads, c.n_kv_heads, c.head_size, c.vocab, c.ctx, c.rms_eps,
+                       getattr(c, "embedding_scale", 1.0), getattr(c, "attention_scale", 0.0), getattr(c, "residual_scale", 1.0),
+                       getattr(c, "logit_scale", 1.0))
         self._h = L.orc_create(C.byref(oc))
         assert L.orc_set_vector_bits(self._h, vector_bits) == 0
         self._keep = [model]

@@ -199,6 +199,9 @@ class NpOracle:
         bs, ts = BLOCK[emb_ty]
         row = emb_raw.view(np.uint8).reshape(-1)[token * dim // bs * ts: (token + 1) * dim // bs * ts]
         x = dequant(row, emb_ty, dim)
+        granite = c["arch"] == 3                       # forwardGranite (InferenceCore.java:814-924): llama graph + four scalars
+        if granite:
+            x = (x * F32(c["embedding_scale"])).astype(F32)
         half = hs // 2
         fcr = self.cr[pos * half:(pos + 1) * half]
         fci = self.ci[pos * half:(pos + 1) * half]
@@ -212,7 +215,7 @@ class NpOracle:
                 q = q + self._f32(p + "attn_q.bias", qd)
                 k = k + self._f32(p + "attn_k.bias", kvd)
                 v = v + self._f32(p + "attn_v.bias", kvd)
-            if c["arch"] == 0:   # InferenceCore.java:75-87, adjacent pairs
+            if c["arch"] in (0, 3):   # InferenceCore.java:75-87, adjacent pairs
                 def rot(vec):
                     vv = vec.reshape(-1, half, 2)
                     v0, v1 = vv[:, :, 0], vv[:, :, 1]
@@ -242,17 +245,20 @@ class NpOracle:
             for h in range(H):   # InferenceCore.java:98-137
                 qh = q[h * hs:(h + 1) * hs]
                 kk = self.kc[l, :pos + 1, (h // kvmul) * hs:(h // kvmul + 1) * hs]
-                score = seq_sum(kk * qh[None, :], axis=1) / sqrt_hs
+                score = seq_sum(kk * qh[None, :], axis=1)
+                score = (score * F32(c["attention_scale"])).astype(F32) if granite else score / sqrt_hs
                 a = softmax(score)
                 vv = self.vc[l, :pos + 1, (h // kvmul) * hs:(h // kvmul + 1) * hs]
                 xb[h * hs:(h + 1) * hs] = seq_sum(a[:, None] * vv, axis=0)
-            x = x + self._mm(p + "attn_output.weight", xb, dim, qd)
+            ao = self._mm(p + "attn_output.weight", xb, dim, qd)
+            x = x + ((ao * F32(c["residual_scale"])).astype(F32) if granite else ao)
             xb = rmsnorm(x, self._f32(p + "ffn_norm.weight", dim), eps)
             hb = self._mm(p + "ffn_gate.weight", xb, hid, dim)
             hb2 = self._mm(p + "ffn_up.weight", xb, hid, dim)
             sig = (1.0 + np.exp(-hb.astype(np.float64))).astype(F32)   # (float)(1.0 + Math.exp(-value))
             hb = (hb / sig) * hb2
-            x = x + self._mm(p + "ffn_down.weight", hb.astype(F32), dim, hid)
+            dn = self._mm(p + "ffn_down.weight", hb.astype(F32), dim, hid)
+            x = x + ((dn * F32(c["residual_scale"])).astype(F32) if granite else dn)
             if layer_x is not None:
                 layer_x.append(x.copy())
         self.x = x
@@ -260,7 +266,8 @@ class NpOracle:
             return None
         x = rmsnorm(x, self._f32("output_norm.weight", dim), eps)
         name = "output.weight" if "output.weight" in self.t else "token_embd.weight"
-        return self._mm(name, x, c["vocab"], dim)
+        lg = self._mm(name, x, c["vocab"], dim)
+        return (lg * F32(c["logit_scale"])).astype(F32) if granite else lg
 
 
 def argmax(v: np.ndarray) -> int:
