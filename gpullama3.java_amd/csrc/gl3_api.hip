@@ -299,9 +299,10 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     const gl3_model_desc& d = ctx->d;
     auto bail = [&](int32_t code, const std::string& msg) { g_create_err = msg.empty() ? ctx->err : msg; gl3_destroy(ctx); return code; };
     const double t0 = now_ms();
-    if (d.arch != GL3_ARCH_LLAMA && d.arch != GL3_ARCH_QWEN3 && d.arch != GL3_ARCH_QWEN2 && d.arch != GL3_ARCH_GRANITE)
+    if (d.arch != GL3_ARCH_LLAMA && d.arch != GL3_ARCH_QWEN3 && d.arch != GL3_ARCH_QWEN2 && d.arch != GL3_ARCH_GRANITE && d.arch != GL3_ARCH_PHI3)
         return bail(GL3_E_UNSUPPORTED, "unsupported architecture");
-    ctx->rope_arch = d.arch == GL3_ARCH_GRANITE ? 0 : d.arch;       // Granite: the Llama graph (adjacent-pair RoPE) + four scalars
+    // Granite: the Llama graph (adjacent-pair RoPE) + four scalars; Phi-3: NeoX pairs like Qwen2, without biases
+    ctx->rope_arch = d.arch == GL3_ARCH_GRANITE ? 0 : d.arch == GL3_ARCH_PHI3 ? 2 : d.arch;
     if (d.arch == GL3_ARCH_GRANITE) {
         if (!(d.attention_scale > 0.f)) return bail(GL3_E_ARG, "granite: attention_scale must be > 0");
         ctx->emb_scale = d.embedding_scale; ctx->resid_scale = d.residual_scale; ctx->logit_scale = d.logit_scale; ctx->att_mul = d.attention_scale;
@@ -514,6 +515,7 @@ int32_t gl3_upload_tensor(gl3_ctx* ctx, int32_t id, int32_t layer, const void* h
     const double t0 = now_ms();
     int32_t r = GL3_OK;
     const int rank = d.tp_rank;
+    if ((id == GL3_T_WQKV || id == GL3_T_W13) && d.arch != GL3_ARCH_PHI3) GL3_FAIL(GL3_E_ARG, "fused attn_qkv / gate|up tensors belong to GL3_ARCH_PHI3");
     const bool is_mat = !(id == GL3_T_OUTPUT_NORM || id == GL3_T_ATTN_NORM || id == GL3_T_FFN_NORM || id == GL3_T_ATTN_Q_NORM ||
                           id == GL3_T_ATTN_K_NORM || id == GL3_T_BQ || id == GL3_T_BK || id == GL3_T_BV);
     if (is_mat && type != d.weight_type) GL3_FAIL(GL3_E_UNSUPPORTED, "matrix ggml type differs from gl3_model_desc.weight_type");
@@ -540,6 +542,20 @@ int32_t gl3_upload_tensor(gl3_ctx* ctx, int32_t id, int32_t layer, const void* h
     case GL3_T_W1: r = upload_q8(ctx, L->w1, 0, ctx->hidden_l, host, bytes, d.hidden, d.dim, (long)rank * ctx->hidden_l); break;
     case GL3_T_W3: r = upload_q8(ctx, L->w3, 0, ctx->hidden_l, host, bytes, d.hidden, d.dim, (long)rank * ctx->hidden_l); break;
     case GL3_T_W2: r = upload_q8(ctx, L->w2, 0, ctx->dim_l, host, bytes, d.dim, d.hidden, (long)rank * ctx->dim_l); break;
+    case GL3_T_WQKV: {        // phi3: rows q | k | v of one tensor; each rank keeps its heads of all three parts
+        const int full = ctx->q_dim + 2 * ctx->kv_dim;
+        r = upload_q8(ctx, L->wqkv, 0, ctx->q_dim_l, host, bytes, full, d.dim, (long)rank * ctx->q_dim_l);
+        if (r == GL3_OK) r = upload_q8(ctx, L->wqkv, ctx->q_dim_l, ctx->kv_dim_l, host, bytes, full, d.dim, (long)ctx->q_dim + (long)rank * ctx->kv_dim_l);
+        if (r == GL3_OK) r = upload_q8(ctx, L->wqkv, ctx->q_dim_l + ctx->kv_dim_l, ctx->kv_dim_l, host, bytes, full, d.dim,
+                                       (long)ctx->q_dim + ctx->kv_dim + (long)rank * ctx->kv_dim_l);
+        if (r == GL3_OK) L->have |= (1u << GL3_T_WQ) | (1u << GL3_T_WK) | (1u << GL3_T_WV);
+        break;
+    }
+    case GL3_T_W13:           // phi3: rows gate | up of one tensor
+        r = upload_q8(ctx, L->w1, 0, ctx->hidden_l, host, bytes, 2 * d.hidden, d.dim, (long)rank * ctx->hidden_l);
+        if (r == GL3_OK) r = upload_q8(ctx, L->w3, 0, ctx->hidden_l, host, bytes, 2 * d.hidden, d.dim, (long)d.hidden + (long)rank * ctx->hidden_l);
+        if (r == GL3_OK) L->have |= (1u << GL3_T_W1) | (1u << GL3_T_W3);
+        break;
     default: GL3_FAIL(GL3_E_ARG, "unknown tensor id");
     }
     if (r != GL3_OK) return r;

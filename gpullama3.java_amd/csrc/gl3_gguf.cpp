@@ -330,7 +330,8 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
     else if (a == "qwen3") d->arch = GL3_ARCH_QWEN3;
     else if (a == "qwen2") d->arch = GL3_ARCH_QWEN2;
     else if (a == "granite") d->arch = GL3_ARCH_GRANITE;
-    else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, qwen3, qwen2, granite)");
+    else if (a == "phi3") d->arch = GL3_ARCH_PHI3;
+    else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, qwen3, qwen2, granite, phi3)");
     auto need = [&](const char* k, double* v) { return meta_num(g, a + "." + k, v); };
     // defaults as the reference loaders: rms epsilon 1e-5, rope theta 10000 (LlamaModelLoader.java:62-63)
     double dim, hid, nl, nh, nkv, eps = 1e-5, theta = 10000.0, ctx, kl;
@@ -422,7 +423,18 @@ int32_t gl3_load_gguf(const char* path, const gl3_model_desc* opts, gl3_ctx** ou
         {"ffn_gate.weight", GL3_T_W1, -1}, {"ffn_down.weight", GL3_T_W2, -1}, {"ffn_up.weight", GL3_T_W3, -1},
         {"attn_q_norm.weight", GL3_T_ATTN_Q_NORM, GL3_ARCH_QWEN3}, {"attn_k_norm.weight", GL3_T_ATTN_K_NORM, GL3_ARCH_QWEN3},
         {"attn_q.bias", GL3_T_BQ, GL3_ARCH_QWEN2}, {"attn_k.bias", GL3_T_BK, GL3_ARCH_QWEN2}, {"attn_v.bias", GL3_T_BV, GL3_ARCH_QWEN2}};
-    for (int l = 0; l < d.n_layers && r == GL3_OK; ++l)
+    // Phi-3 (Phi3ModelLoader.java:111-116): attn_qkv and ffn_up (= gate | up) are fused tensors
+    static const struct { const char* name; int id; } phi3_layer[] = {
+        {"attn_norm.weight", GL3_T_ATTN_NORM}, {"attn_qkv.weight", GL3_T_WQKV}, {"attn_output.weight", GL3_T_WO},
+        {"ffn_norm.weight", GL3_T_FFN_NORM}, {"ffn_up.weight", GL3_T_W13}, {"ffn_down.weight", GL3_T_W2}};
+    if (d.arch == GL3_ARCH_PHI3) {
+        for (int l = 0; l < d.n_layers && r == GL3_OK; ++l)
+            for (const auto& t : phi3_layer) {
+                r = up("blk." + std::to_string(l) + "." + t.name, t.id, l, true);
+                if (r != GL3_OK) break;
+            }
+    }
+    for (int l = 0; l < d.n_layers && r == GL3_OK && d.arch != GL3_ARCH_PHI3; ++l)
         for (const auto& t : per_layer) {
             if (t.arch_only >= 0 && t.arch_only != d.arch) continue;
             r = up("blk." + std::to_string(l) + "." + t.name, t.id, l, true);

@@ -21,7 +21,9 @@ K_NAMES = ["matvec_qkv", "matvec_wo", "matvec_gateup", "matvec_down", "matvec_lo
 T_IDS = {"token_embd.weight": 0, "output_norm.weight": 1, "output.weight": 2, "attn_norm.weight": 3,
          "attn_q.weight": 4, "attn_k.weight": 5, "attn_v.weight": 6, "attn_output.weight": 7,
          "ffn_norm.weight": 8, "ffn_gate.weight": 9, "ffn_down.weight": 10, "ffn_up.weight": 11,
-         "attn_q_norm.weight": 12, "attn_k_norm.weight": 13, "attn_q.bias": 14, "attn_k.bias": 15, "attn_v.bias": 16}
+         "attn_q_norm.weight": 12, "attn_k_norm.weight": 13, "attn_q.bias": 14, "attn_k.bias": 15, "attn_v.bias": 16,
+         "attn_qkv.weight": 17}
+T_W13 = 18          # phi3: blk.L.ffn_up.weight holds gate | up (forwardJavaPhi3)
 
 
 class ModelDesc(C.Structure):

@@ -66,6 +66,8 @@ class HipMasterPlan:
                 if name.startswith("blk."):
                     _, l, rest = name.split(".", 2)
                     tid, layer = hip.T_IDS[rest], int(l)
+                    if c.arch == 4 and rest == "ffn_up.weight":        # phi3: the fused gate | up tensor
+                        tid = hip.T_W13
                 else:
                     tid, layer = hip.T_IDS[name], 0
                 raw = np.ascontiguousarray(raw)

@@ -19,8 +19,8 @@ import numpy as np
 from . import gguf
 from .gguf import GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0
 
-ARCH_LLAMA, ARCH_QWEN3, ARCH_QWEN2, ARCH_GRANITE = 0, 1, 2, 3
-_ARCH_NAME = {ARCH_LLAMA: "llama", ARCH_QWEN3: "qwen3", ARCH_QWEN2: "qwen2", ARCH_GRANITE: "granite"}
+ARCH_LLAMA, ARCH_QWEN3, ARCH_QWEN2, ARCH_GRANITE, ARCH_PHI3 = 0, 1, 2, 3, 4
+_ARCH_NAME = {ARCH_LLAMA: "llama", ARCH_QWEN3: "qwen3", ARCH_QWEN2: "qwen2", ARCH_GRANITE: "granite", ARCH_PHI3: "phi3"}
 
 
 @dataclass
@@ -73,6 +73,9 @@ CONFIGS = {
                                  embedding_scale=12.0, attention_scale=0.015625, residual_scale=0.22, logit_scale=8.0),
     "mid-granite": ModelConfig("mid-granite-random", ARCH_GRANITE, 2048, 4096, 2, 32, 8, 64, 4096, 160, 1e-5, 10000.0, True,
                                 embedding_scale=12.0, attention_scale=0.015625, residual_scale=0.22, logit_scale=8.0),
+    # Phi-3 shape: fused attn_qkv / gate|up tensors, NeoX RoPE, multi-head attention (Phi-3-mini: 32 / 32 heads)
+    "tiny-phi3": ModelConfig("tiny-phi3-random", ARCH_PHI3, 256, 512, 2, 8, 8, 32, 512, 64, 1e-5, 10000.0, False),
+    "mid-phi3": ModelConfig("mid-phi3-random", ARCH_PHI3, 1536, 4096, 2, 12, 4, 128, 2048, 160, 1e-5, 10000.0, False),
     "mha-llama": ModelConfig("mha-llama-random", ARCH_LLAMA, 1024, 2048, 2, 8, 8, 128, 1024, 160, 1e-5, 10000.0, False),
     # full-size SHAPES of the BASELINE models with few layers / a small vocabulary, so that the CPU oracle finishes in seconds:
     # one Llama-3-8B layer (K = 14336: 112 tile groups, activation quads == 14 * 256 exactly), the 128256-row vocabulary
@@ -148,6 +151,14 @@ def tensor_specs(cfg: ModelConfig, wtype: int):
     specs = [("token_embd.weight", cfg.vocab, cfg.dim, wtype, "mat")]
     for l in range(cfg.n_layers):
         p = f"blk.{l}."
+        if cfg.arch == ARCH_PHI3:       # Phi3ModelLoader.java:111-116: attn_qkv = q | k | v rows, ffn_up = gate | up rows
+            specs += [(p + "attn_norm.weight", 1, cfg.dim, GGML_F32, "norm"),
+                      (p + "attn_qkv.weight", cfg.q_dim + 2 * cfg.kv_dim, cfg.dim, wtype, "mat"),
+                      (p + "attn_output.weight", cfg.dim, cfg.q_dim, wtype, "mat"),
+                      (p + "ffn_norm.weight", 1, cfg.dim, GGML_F32, "norm"),
+                      (p + "ffn_down.weight", cfg.dim, cfg.hidden, wtype, "mat"),
+                      (p + "ffn_up.weight", 2 * cfg.hidden, cfg.dim, wtype, "mat")]
+            continue
         specs += [
             (p + "attn_norm.weight", 1, cfg.dim, GGML_F32, "norm"),
             (p + "attn_q.weight", cfg.q_dim, cfg.dim, wtype, "mat"),
@@ -184,7 +195,25 @@ class SynthModel:
         return self.tensors.items()
 
     def oracle_tensors(self):
-        return {k: (v[0], v[1]) for k, v in self.tensors.items()}
+        """name -> (raw, type) with the Phi-3 fused tensors presented as row views q | k | v and gate | up (no copy)."""
+        out = {}
+        c = self.cfg
+        for k, v in self.tensors.items():
+            raw, ty, rows, cols = v
+            if c.arch == ARCH_PHI3 and k.endswith("attn_qkv.weight"):
+                rb = raw.size // rows
+                pre = k[: -len("attn_qkv.weight")]
+                out[pre + "attn_q.weight"] = (raw[: c.q_dim * rb], ty)
+                out[pre + "attn_k.weight"] = (raw[c.q_dim * rb:(c.q_dim + c.kv_dim) * rb], ty)
+                out[pre + "attn_v.weight"] = (raw[(c.q_dim + c.kv_dim) * rb:], ty)
+            elif c.arch == ARCH_PHI3 and k.endswith("ffn_up.weight"):
+                rb = raw.size // rows
+                pre = k[: -len("ffn_up.weight")]
+                out[pre + "ffn_gate.weight"] = (raw[: c.hidden * rb], ty)
+                out[pre + "ffn_up.weight"] = (raw[c.hidden * rb:], ty)
+            else:
+                out[k] = (raw, ty)
+        return out
 
     def oracle_cfg(self):
         c = self.cfg

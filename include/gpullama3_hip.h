@@ -60,7 +60,8 @@ typedef enum {
 /* LLAMA: InferenceCore.forwardJava (also Mistral GGUFs, architecture "llama"); QWEN3: forwardJavaQwen3 (per-head q/k RMSNorm,
  * NeoX RoPE); QWEN2: forwardJavaQwen2 :434-563 (q/k/v bias, NeoX RoPE; Qwen2.5, DeepSeek-R1-Distill-Qwen). */
 enum { GL3_ARCH_LLAMA = 0, GL3_ARCH_QWEN3 = 1, GL3_ARCH_QWEN2 = 2,
-       GL3_ARCH_GRANITE = 3 /* InferenceCore.forwardGranite :814-924: the Llama graph + embedding / attention / residual / logit scalars */ };
+       GL3_ARCH_GRANITE = 3, /* InferenceCore.forwardGranite :814-924: the Llama graph + embedding / attention / residual / logit scalars */
+       GL3_ARCH_PHI3 = 4     /* InferenceCore.forwardJavaPhi3 :699-800: fused attn_qkv and gate|up tensors (GL3_T_WQKV, GL3_T_W13), NeoX RoPE */ };
 
 /* ggml tensor types of the wire format (J/tensor/GGMLType.java:5-21) */
 enum { GL3_TYPE_F32 = 0, GL3_TYPE_F16 = 1, GL3_TYPE_Q4_0 = 2, GL3_TYPE_Q8_0 = 8,
@@ -86,7 +87,9 @@ enum {
     GL3_T_BQ = 14,          /* blk.L.attn_q.bias        [q_dim]        F32, qwen2 (Qwen2StandardWeights q_bias) */
     GL3_T_BK = 15,          /* blk.L.attn_k.bias        [kv_dim]       F32, qwen2 */
     GL3_T_BV = 16,          /* blk.L.attn_v.bias        [kv_dim]       F32, qwen2 */
-    GL3_T_COUNT = 17
+    GL3_T_WQKV = 17,        /* blk.L.attn_qkv.weight    [(qDim + 2 kvDim) x dim]  phi3: rows q | k | v (Phi3ModelLoader.java:112)          */
+    GL3_T_W13 = 18,         /* blk.L.ffn_up.weight      [2 hidden x dim]          phi3: rows gate | up (forwardJavaPhi3 :778-780)          */
+    GL3_T_COUNT = 19
 };
 
 /* gl3_model_desc.flags */

@@ -48,7 +48,9 @@ enum {
 
 typedef struct {
     int32_t arch;       /* 0 = llama (InferenceCore.forwardJava), 1 = qwen3 (forwardJavaQwen3), 2 = qwen2 (forwardJavaQwen2),
-                           3 = granite (forwardGranite :814-924: the llama graph + the four scalars below) */
+                           3 = granite (forwardGranite :814-924: the llama graph + the four scalars below),
+                           4 = phi3 (forwardJavaPhi3 :699-800: NeoX RoPE pairs, no bias, no per-head norm; the fused attn_qkv / gate|up
+                               tensors are handed to this oracle as row views wq | wk | wv and w1 | w3 of the same bytes) */
     int32_t dim, hidden, n_layers, n_heads, n_kv_heads, head_size, vocab, ctx;
     float   rms_eps;
     float   embedding_scale, attention_scale, residual_scale, logit_scale;   /* granite only (GraniteLoader.java:55-58) */

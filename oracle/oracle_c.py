@@ -91,16 +91,19 @@ class COracle:
                        getattr(c, "logit_scale", 1.0))
         self._h = L.orc_create(C.byref(oc))
         assert L.orc_set_vector_bits(self._h, vector_bits) == 0
-        self._keep = [model]
-        for name, t in model.tensors.items():
+        tensors = model.oracle_tensors() if hasattr(model, "oracle_tensors") else model.tensors      # phi3: fused tensors as row views
+        self._keep = [model, tensors]
+        for name, t in tensors.items():
             raw, ty = t[0], t[1]
+            raw = np.ascontiguousarray(raw)
+            self._keep.append(raw)
             if name.startswith("blk."):
                 _, l, rest = name.split(".", 2)
                 L.orc_set_tensor(self._h, T_IDS[rest], int(l), _p(raw), ty)
             else:
                 L.orc_set_tensor(self._h, T_IDS[name], 0, _p(raw), ty)
-        if "output.weight" not in model.tensors:      # tied: wcls = token_embd
-            raw, ty = model.tensors["token_embd.weight"][:2]
+        if "output.weight" not in tensors:      # tied: wcls = token_embd
+            raw, ty = tensors["token_embd.weight"][:2]
             L.orc_set_tensor(self._h, T_IDS["output.weight"], 0, _p(raw), ty)
         self._cr, self._ci = model.rope
         L.orc_set_rope(self._h, _p(self._cr), _p(self._ci))

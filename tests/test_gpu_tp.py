@@ -21,7 +21,7 @@ def planmod():
 
 @pytest.mark.parametrize("cfg,tp,wtype", [("mid-llama", 2, 8), ("mid-llama", 4, 8), ("mid-qwen3", 2, 8), ("tiny-llama-tied", 2, 8),
                                           ("mid-llama", 2, 2), ("mid-llama", 4, 1), ("mid-qwen3", 2, 1), ("mid-qwen2", 2, 8),
-                                          ("mid-llama", 8, 8), ("mid-llama", 8, 2), ("mid-qwen3", 8, 8), ("mid-granite", 2, 8)])   # BASELINE configs[3]: Q4_0 row split, tp = 8 (one kv head per rank)
+                                          ("mid-llama", 8, 8), ("mid-llama", 8, 2), ("mid-qwen3", 8, 8), ("mid-granite", 2, 8), ("mid-phi3", 2, 8), ("mid-phi3", 4, 2)])   # BASELINE configs[3]: Q4_0 row split, tp = 8 (one kv head per rank)
 def test_row_split_ranks_are_bit_identical_to_the_oracle(pkg, orc, planmod, cfg, tp, wtype):
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=17)
