@@ -72,3 +72,13 @@ def test_header_is_plain_c99(tmp_path):
     text = open(os.path.join(root, "tools", "gl3_bench.cpp")).read()
     incs = [l.split()[1] for l in text.splitlines() if l.startswith("#include")]
     assert all(i.startswith("<") or i == '"../include/gpullama3_hip.h"' for i in incs), incs
+
+
+def test_no_jdk_in_this_image_shim_is_uncompiled():
+    """INTEGRATION.md §2 (the JDK-21 FFM class HipMasterPlan) is shown, not compiled: this image — and the GPU box, which runs
+    the same image — has no JDK.  The day `javac` appears this test fails on purpose: compile the shim against the reference
+    interfaces and replace this test by that compile step."""
+    import shutil
+    first = open(os.path.join(os.path.dirname(ge.PKG_DIR), "INTEGRATION.md")).readline()
+    assert "UNCOMPILED" in first
+    assert shutil.which("javac") is None and shutil.which("java") is None, "a JDK is available: compile INTEGRATION.md §2 now"
