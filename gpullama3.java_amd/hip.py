@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_DIR, "libgpullama_hip.so")
+SO_PATH = os.environ.get("GL3_LIB") or os.path.join(_DIR, "libgpullama_hip.so")      # GL3_LIB: an experimental build of the same library
 
 GL3_OK = 0
 ERR_NAMES = {0: "GL3_OK", -1: "GL3_E_ARG", -2: "GL3_E_UNSUPPORTED", -3: "GL3_E_OOM", -4: "GL3_E_HIP", -5: "GL3_E_RCCL",
