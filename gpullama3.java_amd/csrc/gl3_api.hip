@@ -256,7 +256,7 @@ static int32_t dmalloc(gl3_ctx* ctx, T** p, size_t n) {
 static int32_t alloc_mat(gl3_ctx* ctx, Q8Mat& m, int rows, int k) {
     m.rows = rows; m.k = k; m.ng = ((k / 32) + 3) / 4; m.nstrips = (rows + 15) / 16; m.fmt = ctx->d.weight_type;
     m.vl = m.fmt != GL3_TYPE_Q8_0 && !(ctx->d.flags & GL3_FLAG_SCALAR_DOT);
-    GL3_HIP(hipMalloc((void**)&m.w, m.bytes()));
+    GL3_HIP(hipMalloc((void**)&m.w, m.bytes() + GL3_TAIL_PAD));
     if (m.fmt != GL3_TYPE_Q8_0) GL3_HIP(hipMemset(m.w, 0, m.bytes()));      // padded rows of the last 64-row group
     return GL3_OK;
 }

@@ -1,0 +1,234 @@
+// gl3_bd_gemm.h — the Q8_0 batched-matmul argument block and the static-batched-decode GEMM (<= 32 tokens).
+// (Round 1's producer / chain-wavefront kernel, 32 rows x 32 tokens per workgroup with an LDS ring and a barrier per 8 blocks,
+// is in the history: 106 us of GEMMs per Qwen3-4B layer at B = 32 against 53 us for the kernel below.)
+// Included by gl3_prefill.hip (product) and by scripts/probes/bd_probe.hip (stand-alone timing harness), both after
+// `using namespace gl3;`.
+#pragma once
+#include "gl3_decode_kernels.h"
+#include <type_traits>
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef long v2l_t __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------------
+// Batched Q8_0 matmul: out[b][n] = sum_blocks float(isum) * (wScale * aScale), blocks ascending
+// (FloatTensor.matmul(context, ...) :102-111 with dotQ8Activation).
+struct GemmArgs {
+    const uint8_t* w; const uint8_t* w2;  // Q8T matrices (w2: up projection for the SwiGLU epilogue)
+    int rows, ng, nb;                     // valid rows, tile groups per strip, real blocks per row (k/32)
+    const uint8_t* XQ; const float* XS; int maxk;
+    int tslots;                           // bdw_gemm_kernel: token slots of the XQ2 / XS2 layout (32); 0 = row layout
+    int ntt, nrt;                         // token tiles, row tiles (grid = 8 * ceil(ntt * nrt / 8), see the XCD mapping)
+    int ntok;
+    float* out; int out_stride;           // EPI_STORE / EPI_SWIGLU: out[b*stride + row]; EPI_RESID: out +=
+    float out_scale;                      // EPI_STORE / EPI_RESID: result *= out_scale first (Granite; 1 otherwise, exact)
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Static-batched decode, wave-owned form (<= 32 tokens).  One wavefront = one workgroup = 16 weight rows (one Q8T strip) x
+// 16 tokens x ALL of K, result in registers, accumulated block by block in the reference's order.  No operand staging in LDS,
+// no barriers; grid = strips x token tiles.
+//   * one v_mfma_i32_16x16x32_i8 per (block, token tile).  The Q8T tile stores a block row as two 16-byte halves, so a
+//     lane's natural load is 16 B: lane (row r, k-group g) loads half g & 1 of block 2j + (g >> 1) — two blocks per
+//     load — and two v_permlane32_swap turn that into the 8 B x 4 k-groups of block 2j (low registers) and of block
+//     2j + 1 (high registers).  The int8 dot is exact, so the order of k inside a block is free; only A and B have to
+//     agree, and B (the int8 activations) is stored pre-split for exactly this access (XQ2 below): no swap on that side.
+//   * weight scales: the 128-byte f16 header of TWO tiles per load (lanes 0-31 / 32-63), converted once and parked in LDS
+//     as f32, read back as one broadcast float4 = the 4 rows a lane accumulates.  Activation scales: one float per lane
+//     and tile, parked in LDS twice ({s, s} = a ready v_pk_mul operand).
+//   * a tile runs in two halves one iteration apart — front(i + 1): swaps + MFMAs, back(i): (float)isum * (wScale * aScale)
+//     and result += p, blocks ascending — so the MFMA latency sits behind the previous tile's arithmetic.
+//   * addresses are a uniform base (SGPRs, advanced by scalar adds) + a loop-invariant per-lane offset, and NOTHING is
+//     clamped or guarded: the rings read up to DA tiles past the end of a strip / of the activations, which is why
+//     every weight matrix and XQ2 / XS2 carry GL3_TAIL_PAD bytes of slack (alloc_mat, gl3_prefill_init).  A load under a
+//     condition makes the compiler wait vmcnt(0) at every use ("conditional loads"), and so did several other
+//     constructs here — ring slots must not be float4s whose odd elements feed v_pk_mul broadcasts, a later tile's swaps
+//     must not be scheduled behind their loads (sched_barrier per tile), the prologue has to issue in the loop's order,
+//     loop exits inside the unrolled trip split the ring's live ranges, and since vmcnt counts in issue order every stream
+//     (weights from HBM, activations from L2) needs the same ring depth.
+//   * SwiGLU: gate and up rows of a strip in one wavefront (NM = 2): the activations are fetched once for both matrices.
+// Measured dead ends (scripts/probes/bd_probe.hip): k-slices per strip with an adding wavefront or an owning slice
+// (LDS exchange + one barrier per round: never faster than one wavefront per strip, 17-22 us vs 17.7 on the 2560 x 9728
+// matrix); token tiles of a strip in one workgroup; rings deeper than 8 tiles; non-temporal weight loads (the token tiles
+// re-read the lines from L2); gate and up as separate wavefronts with silu(g) * u in the next quantiser (2432 single-matrix
+// wavefronts fetch the activations twice: 21-22 us vs 18.3 fused).
+// Activation layout (written by pf_norm_quant_kernel when tslots != 0), tslots = 32 token slots:
+//   XS2[k / 128][tslots][4] f32 = the 4 block scales of a tile;
+//   XQ2[k / 64][tslots][64] int8 = blocks 2j, 2j + 1 of a token, already in the lanes' operand order: bytes 16g .. 16g + 7 =
+//   k-chunk c(g) of block 2j, bytes 16g + 8 .. 16g + 15 = the same chunk of block 2j + 1, with c(0..3) = k 0-7, 16-23, 8-15,
+//   24-31 (what the swap leaves in k-group g on the weight side) — bdq_offset() below.
+constexpr int BD_TS = 32;
+
+// byte offset of quad qd (elements 4qd .. 4qd + 3 of a token's row) in XQ2, and float offset of block blk's scale in XS2
+__device__ __forceinline__ size_t bdq_offset(int qd, int tok, int tslots) {
+    const int blk = qd >> 3, qi = qd & 7, c = qi >> 1;
+    const int g = ((c & 1) << 1) | (c >> 1);                 // k-chunk 0, 1, 2, 3 -> k-group 0, 2, 1, 3
+    return ((size_t)(blk >> 1) * tslots + tok) * 64 + 16 * g + 8 * (blk & 1) + 4 * (qi & 1);
+}
+__device__ __forceinline__ size_t bds_offset(int blk, int tok, int tslots) { return ((size_t)(blk >> 2) * tslots + tok) * 4 + (blk & 3); }
+
+// grid: workgroup id -> (strip, token tile).  The token tiles of a strip stream the same weights, so they sit 8 ids apart: same
+// XCD (= id % 8), i.e. one L2, and dispatched together.
+__host__ __device__ inline int bdw_grid(int strips, int nt) { return ((strips + 7) / 8) * 8 * nt; }
+
+template <int EPI, int DA, int WPE>
+__global__ __launch_bounds__(64, WPE) void bdw_gemm_kernel(const GemmArgs a) {
+    constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int TS = BD_TS;
+    static_assert(DA % 2 == 0, "ring slots are static under the unroll");
+    __shared__ __attribute__((aligned(16))) float wsl[4 * NM * 64];     // [tile & 3][matrix][block][row] weight scales
+    __shared__ __attribute__((aligned(16))) float xsl[4 * 128];         // [tile & 3][blocks 01 | 23][token][2 blocks][2]: activation scale pairs, a token's float4s 16 B apart (no bank conflicts)
+    const int lane = threadIdx.x, t = lane & 15, g = lane >> 4;
+    const int NTG = (a.ntok + 15) >> 4;                                         // token tiles of this launch
+    const int nstrips = (a.rows + 15) >> 4;
+    const int h = (blockIdx.x >> 3) % NTG;
+    const int strip = (blockIdx.x / (8 * NTG)) * 8 + (blockIdx.x & 7);
+    if (strip >= nstrips) return;                                               // padding of the grid to a multiple of 8 strips
+    const int ntiles = a.ng;
+    const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
+    // uniform stream bases of the NEXT tile to fetch, advanced by scalar adds
+    const uint8_t* pa[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) pa[m] = (m == 0 ? a.w : a.w2) + (size_t)strip * strip_bytes;
+    const uint8_t* pb = a.XQ;
+    const float* px = a.XS;
+    const uint32_t la = ((g & 1) ? 1152 : 128) + 16 * (t + 16 * (g >> 1));       // + 512 for the tile's second block pair
+    const uint32_t lh = (lane >> 5) * TILE_BYTES + 4 * (lane & 31);              // headers of tiles i (lanes 0-31), i + 1 (32-63)
+    const uint32_t lb = (16 * h + t) * 64 + 16 * g;                              // + TS * 64 for the second pair
+    const uint32_t lx = ((16 * h + t) * 4 + g) * 4;
+    v4i_t Ar[NM][DA][2]; uint32_t Hr[NM][DA / 2]; v2l_t Br[DA][2]; float Xr[DA];
+    auto fetch = [&](int u) {                            // the tile at the stream heads -> ring slot u; heads advance one tile
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) Ar[m][u][jj] = *reinterpret_cast<const v4i_t*>(pa[m] + la + 512 * jj);
+            if ((u & 1) == 0) Hr[m][u / 2] = *reinterpret_cast<const uint32_t*>(pa[m] + lh);
+            pa[m] += TILE_BYTES;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) Br[u][jj] = *reinterpret_cast<const v2l_t*>(pb + lb + jj * (TS * 64));
+        Xr[u] = *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(px) + lx);
+        pb += 2 * TS * 64;
+        px += TS * 4;
+    };
+    auto park_h = [&](int u2, int i) {                   // f16 -> f32 weight scales of tiles i, i + 1 into their LDS slots
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const uint32_t hh = Hr[m][u2];
+            *reinterpret_cast<float2*>(&wsl[(((i + (lane >> 5)) & 3) * NM + m) * 64 + 2 * (lane & 31)]) =
+                make_float2(h2f((uint16_t)(hh & 0xffff)), h2f((uint16_t)(hh >> 16)));
+        }
+    };
+    auto park_x = [&](int u, int i) { *reinterpret_cast<float2*>(&xsl[(i & 3) * 128 + (g >> 1) * 64 + 4 * t + 2 * (g & 1)]) = make_float2(Xr[u], Xr[u]); };
+    // 16 B per lane (two blocks x one half) -> lo = 8 B of block 2j, hi = 8 B of block 2j + 1 for all four k-groups:
+    // v_permlane32_swap exchanges lo[lanes 32-63] with hi[lanes 0-31]
+    auto split = [](const v4i_t v, long& lo, long& hi) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)v[0], (unsigned)v[2], false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)v[1], (unsigned)v[3], false, false);
+        lo = (long)(((unsigned long)r1[0] << 32) | r0[0]);
+        hi = (long)(((unsigned long)r1[1] << 32) | r0[1]);
+    };
+    v2f_t acc[NM][2];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) { acc[m][0] = v2f_t{0.f, 0.f}; acc[m][1] = v2f_t{0.f, 0.f}; }
+    const v4i_t cbias = {0x4B400000, 0x4B400000, 0x4B400000, 0x4B400000};      // 1.5 * 2^23: int accumulator read as float = bias + isum
+    const v2f_t fbias = {12582912.f, 12582912.f};
+    v4i_t Cb[2][NM][4]; float4 Wc[NM][4]; v2f_t Xc[4];
+    auto scales = [&](int i) {                           // weight / activation scales of tile i: LDS -> Wc / Xc
+        const float4 x01 = *reinterpret_cast<const float4*>(&xsl[(i & 3) * 128 + 4 * t]), x23 = *reinterpret_cast<const float4*>(&xsl[(i & 3) * 128 + 64 + 4 * t]);
+        Xc[0] = v2f_t{x01.x, x01.y}; Xc[1] = v2f_t{x01.z, x01.w}; Xc[2] = v2f_t{x23.x, x23.y}; Xc[3] = v2f_t{x23.z, x23.w};
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi) Wc[m][bi] = *reinterpret_cast<const float4*>(&wsl[((i & 3) * NM + m) * 64 + 16 * bi + 4 * g]);
+    };
+    auto front = [&](int u) {                            // ring slot u: swaps + 4 MFMAs per matrix -> Cb[u & 1]
+        const int q = u & 1;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const long blo = Br[u][jj][0], bhi = Br[u][jj][1];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                long alo, ahi;
+                split(Ar[m][u][jj], alo, ahi);
+                Cb[q][m][2 * jj] = __builtin_amdgcn_mfma_i32_16x16x32_i8(alo, blo, cbias, 0, 0, 0);         // block 2jj: the low registers
+                Cb[q][m][2 * jj + 1] = __builtin_amdgcn_mfma_i32_16x16x32_i8(ahi, bhi, cbias, 0, 0, 0);     // block 2jj + 1: the high registers
+            }
+        }
+    };
+    // FULL is compile-time (no per-block branches in the full trips); nvalid < 4 only for the partial last tile of a K that is
+    // not a multiple of 128
+    auto back = [&](auto full_tag, int u, int nvalid) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int q = u & 1;
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) {
+            if (!FULL && bi >= nvalid) continue;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const v4i_t c = Cb[q][m][bi];
+                const float4 w4 = Wc[m][bi];
+                const v2f_t ca = v2f_t{__int_as_float(c[0]), __int_as_float(c[1])} - fbias;
+                const v2f_t cb = v2f_t{__int_as_float(c[2]), __int_as_float(c[3])} - fbias;
+                acc[m][0] = acc[m][0] + ca * (v2f_t{w4.x, w4.y} * Xc[bi]);      // result += isum * (wScale * aScale)
+                acc[m][1] = acc[m][1] + cb * (v2f_t{w4.z, w4.w} * Xc[bi]);
+            }
+        }
+    };
+    // prologue: the steady state's issue order
+#pragma unroll
+    for (int u = 0; u < DA; ++u) { fetch(u); __builtin_amdgcn_sched_barrier(0); }
+    park_h(0, 0);
+    park_x(0, 0);
+    front(0);
+    const int nfull = a.nb >> 2;                         // full tiles
+    int base = 0;
+    for (; base + DA <= nfull; base += DA) {             // full trips: branch-free
+#pragma unroll
+        for (int u = 0; u < DA; ++u) {
+            const int i = base + u;
+            scales(i);
+            if ((u & 1) == 0) park_h(((u + 2) % DA) / 2, i + 2);               // scales of tiles i + 2, i + 3 (fetched DA - 2 tiles ago)
+            park_x((u + 1) % DA, i + 1);
+            front((u + 1) % DA);
+            back(std::true_type{}, u, 4);
+            fetch(u);
+            __builtin_amdgcn_sched_barrier(0);           // or the scheduler hoists a later tile's swaps to just behind their loads (vmcnt(0))
+        }
+    }
+    if (base < ntiles) {
+        // last, partial trip: same straight-line schedule (fetches unconditional, no loop exits); only the arithmetic of tiles /
+        // blocks past the end is skipped
+#pragma unroll
+        for (int u = 0; u < DA; ++u) {
+            const int i = base + u;
+            if (i < ntiles) {
+                scales(i);
+                if ((u & 1) == 0) park_h(((u + 2) % DA) / 2, i + 2);
+                park_x((u + 1) % DA, i + 1);
+                front((u + 1) % DA);
+                back(std::false_type{}, u, min(4, a.nb - 4 * i));
+                fetch(u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // epilogue.  C layout: token = 16 h + (lane & 15), weight rows 4g .. 4g + 3 of the strip
+    const int b = 16 * h + t;
+    if (b >= a.ntok) return;
+    const int rbase = strip * 16 + 4 * g;
+    float* o = a.out + (size_t)b * a.out_stride + rbase;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (rbase + i >= a.rows) continue;
+        const float v0 = acc[0][i >> 1][i & 1];
+        if (EPI == EPI_SWIGLU) {
+            float gt = v0;
+            gt = gt / (float)(1.0 + exp(-(double)gt));
+            o[i] = gt * acc[NM - 1][i >> 1][i & 1];
+        } else if (EPI == EPI_STORE) o[i] = v0 * a.out_scale;
+        else o[i] = o[i] + v0 * a.out_scale;
+    }
+}

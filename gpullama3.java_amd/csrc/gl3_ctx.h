@@ -12,6 +12,10 @@
 
 #include "../../include/gpullama3_hip.h"
 
+// Slack behind every weight matrix (and the small-batch activation buffers): bdw_gemm_kernel's load rings run up to 16 tiles
+// past the end of a strip instead of clamping or guarding their addresses (gl3_bd_gemm.h).
+constexpr size_t GL3_TAIL_PAD = 256 * 1024;
+
 struct Q8Mat {               // one repacked matrix: Q8T tiles (gl3_decode_kernels.h) or F16 / Q4_0 row-lane (gl3_rowlane_kernels.h)
     uint8_t* w = nullptr;
     int rows = 0, k = 0;

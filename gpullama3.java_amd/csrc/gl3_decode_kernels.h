@@ -107,7 +107,8 @@ __device__ __forceinline__ float seq_sum_lds(const float* v, int n) {
 // ---------------------------------------------------------------------------------------------------
 // Activation quantisation into LDS (Q8_0FloatTensor.java:96-118): 8 consecutive threads own one 32-block.
 // xq[32*b ..] = int8 quants of block b, xs[b] = f16-rounded activation scale.  v = value already normalised.
-__device__ __forceinline__ void quantize_quad(float4 v, int qd, uint8_t* xq, float* xs) {
+// the 4 packed quants of a quad and its block's scale (valid in all 8 lanes of the block)
+__device__ __forceinline__ uint32_t quantize_quad_pack(float4 v, float& qs_out) {
     float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     // maximum over the block's 8 lanes with DPP moves (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror) instead of
     // three dependent ds_bpermute round trips through LDS (__shfl_xor): ~300 cycles less per quad on the prologue's critical path
@@ -119,10 +120,15 @@ __device__ __forceinline__ void quantize_quad(float4 v, int qd, uint8_t* xq, flo
     const float s0 = v.x * ainv, s1 = v.y * ainv, s2 = v.z * ainv, s3 = v.w * ainv;
     const int q0 = (int)(s0 + copysignf(0.5f, s0)), q1 = (int)(s1 + copysignf(0.5f, s1));
     const int q2 = (int)(s2 + copysignf(0.5f, s2)), q3 = (int)(s3 + copysignf(0.5f, s3));
-    const uint32_t packed = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) |
-                            ((uint32_t)(q3 & 0xFF) << 24);
+    qs_out = (float)(_Float16)qs;                                        // float16ToFloat(floatToFloat16(qs))
+    return (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+}
+
+__device__ __forceinline__ void quantize_quad(float4 v, int qd, uint8_t* xq, float* xs) {
+    float qs;
+    const uint32_t packed = quantize_quad_pack(v, qs);
     *reinterpret_cast<uint32_t*>(xq + 4 * qd) = packed;                  // byte 32*b + 4*(qd&7)
-    if ((qd & 7) == 0) xs[qd >> 3] = (float)(_Float16)qs;               // float16ToFloat(floatToFloat16(qs))
+    if ((qd & 7) == 0) xs[qd >> 3] = qs;
 }
 
 __device__ __forceinline__ int dot32(const int4& a0, const int4& a1, const int4& b0, const int4& b1) {

@@ -17,6 +17,7 @@
 #include "gl3_decode_kernels.h"
 
 using namespace gl3;
+#include "gl3_bd_gemm.h"      // GemmArgs, bdw_gemm_kernel (expects the gl3 names in scope)
 
 struct gl3_prefill_state {
     int max_batch = 0;
@@ -37,8 +38,6 @@ struct gl3_prefill_state {
     int maxk = 0;
 };
 
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-typedef int v16i_t __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------------
 // token_embedding_table.copyTo per token (batchForwardJavaPrefill :96)
@@ -65,11 +64,15 @@ __global__ __launch_bounds__(256) void pf_embed_kernel(const uint8_t* __restrict
 
 // ---------------------------------------------------------------------------------------------------
 // Per token: (RMSNorm with the exact in-order sum of squares) + Q8_0 activation quantisation.
-// One workgroup of 256 threads per token.  NORM = false: plain quantisation of an f32 row.
-template <bool NORM>
+// One workgroup of 256 threads per token (PQ_NORM) or per (token, 1024-element chunk) (the other modes: the blocks are
+// independent, and one workgroup per token left 32 tokens on 32 CUs).
+//   PQ_PLAIN:  quantise an f32 row;  PQ_NORM: RMSNorm, then quantise
+enum { PQ_PLAIN = 0, PQ_NORM = 1 };
+template <int MODE>
 __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restrict__ in, int k, int in_stride,
                                                              const float* __restrict__ norm_w, float eps,
-                                                             uint8_t* __restrict__ XQ, float* __restrict__ XS, int maxk) {
+                                                             uint8_t* __restrict__ XQ, float* __restrict__ XS, int maxk, int tslots) {
+    constexpr bool NORM = MODE == PQ_NORM;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* xf = reinterpret_cast<float*>(smem);                 // [k + 32]
     uint8_t* scratch = smem + (size_t)(k + 32) * 4;             // ss_scratch_bytes(k)
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restr
     }
     uint8_t* xq = XQ + (size_t)b * maxk;
     float* xs = XS + (size_t)b * (maxk >> 5);
-    for (int qd = t; qd < nquads; qd += 256) {
+    for (int qd = t + 256 * blockIdx.y; qd < nquads; qd += 256 * gridDim.y) {
         float4 v;
         if (NORM) {
             v = *reinterpret_cast<const float4*>(xf + 4 * qd);
@@ -108,22 +111,16 @@ __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restr
         } else {
             v = xquad(qd);
         }
-        quantize_quad(v, qd, xq, xs);
+        if (tslots == 0) quantize_quad(v, qd, xq, xs);
+        else {                                           // the wave-owned small-batch GEMM's operand layout (gl3_bd_gemm.h)
+            float qs;
+            const uint32_t packed = quantize_quad_pack(v, qs);
+            *reinterpret_cast<uint32_t*>(XQ + bdq_offset(qd, b, tslots)) = packed;
+            if ((qd & 7) == 0) XS[bds_offset(qd >> 3, b, tslots)] = qs;
+        }
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Batched Q8_0 matmul: out[b][n] = sum_blocks float(isum) * (wScale * aScale), blocks ascending
-// (FloatTensor.matmul(context, ...) :102-111 with dotQ8Activation).
-struct GemmArgs {
-    const uint8_t* w; const uint8_t* w2;  // Q8T matrices (w2: up projection for the SwiGLU epilogue)
-    int rows, ng, nb;                     // valid rows, tile groups per strip, real blocks per row (k/32)
-    const uint8_t* XQ; const float* XS; int maxk;
-    int ntt, nrt;                         // token tiles, row tiles (grid = 8 * ceil(ntt * nrt / 8), see the XCD mapping)
-    int ntok;
-    float* out; int out_stride;           // EPI_STORE / EPI_SWIGLU: out[b*stride + row]; EPI_RESID: out +=
-    float out_scale;                      // EPI_STORE / EPI_RESID: result *= out_scale first (Granite; 1 otherwise, exact)
-};
 
 // LDS-tiled version: workgroup = 128 weight rows (64 gate + 64 up rows for the SwiGLU epilogue) x 128 tokens, 4
 // wavefronts in a 2 x 2 grid, each owning 64 rows x 64 tokens = four 32x32 int8 MFMA tiles.  K advances 4 blocks
@@ -135,7 +132,6 @@ struct GemmArgs {
 // 4096-row wo / down projections still launch >= 256 workgroups at 512 tokens).  The SwiGLU epilogue always runs
 // RF = 1 over two matrices.
 constexpr int GM_TOK = 128, GM_KB = 4;
-typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 __host__ __device__ constexpr int gm_stage_bytes(int arows, int toks = 128) {
     return GM_KB * 2 * arows * 16 + GM_KB * arows * 4 + GM_KB * 2 * toks * 16 + GM_KB * toks * 4;
@@ -403,169 +399,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
                     }
                 }
             }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Static-batched decode (<= 32 sequences, one token each): out[b][n] for a handful of tokens is a long-K, tiny-MN product.
-// The LDS-tiled GEMM above has only rows/128 workgroups then and runs each 32x32 tile's K loop as one latency chain
-// (LDS -> MFMA -> 40 VALU per block); here the work is split like the single-token matvec:
-//   workgroup = 32 weight rows x 32 tokens x all K; producers (waves 1-8): wave w takes block 8r + w - 1 of round r —
-//       A fragment + 16 row scales straight from the Q8T tiles (kept BD_D rounds ahead in registers so ~100 KB per CU are in
-//       flight), B fragment from XQ (L2), one int8 MFMA, p = float(isum) * (wScale * aScale) into a double-buffered LDS ring;
-//   chain (wave 0, raised priority): result += p in block order (16 independent chains per lane) and the epilogue.
-// One barrier per round of 8 blocks.  Grid = rows / 32.
-// BD_NP = producer wavefronts = blocks per round (8; the 4-producer variant with half the LDS ring measured slower).
-constexpr int BD_NC = 2, BD_DB = 4;
-__host__ __device__ constexpr int bd_threads(int np) { return 64 * (np + BD_NC); }
-__host__ __device__ constexpr int bd_smem_bytes(int nm, int np) { return 2 * nm * np * 1024 * 4 + np * 2 * 32 * 4; }
-
-template <int EPI, int BD_NP>
-__global__ __launch_bounds__(bd_threads(BD_NP)) void bd_gemm_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float P[];           // [2][NM][BD_NP][4][64][4] | wscale[BD_NP][NM][32]
-    constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
-    // weight blocks in flight per producer wavefront (5 VGPRs each): a workgroup of a 4096-row matrix must keep ~100 KB
-    // of the weight stream in flight by itself, because only rows/32 workgroups exist
-    constexpr int BD_D = NM == 1 ? 16 : 8;
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6) - BD_NC;  // < 0: chain wavefronts
-    const int tl = lane & 31, hi = lane >> 5;
-    const int row0 = blockIdx.x * 32;
-    const int nstrips = (a.rows + 15) >> 4;
-    const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
-    const int nrounds = (a.nb + BD_NP - 1) / BD_NP;
-
-    if (wave >= 0) {
-        // ------------------------------------------------------------------ producers
-        const int strip = min(nstrips - 1, (row0 >> 4) + (tl >> 4));        // strip of this lane's A row
-        const int tok = min(a.ntok - 1, tl);
-        float* wsl = P + 2 * NM * BD_NP * 1024 + (size_t)wave * NM * 32;     // this wavefront's scale scratch
-        const uint8_t* wbase[NM];
-        wbase[0] = a.w;
-        if (NM == 2) wbase[NM - 1] = a.w2;
-        v4i_t af[NM][BD_D];
-        uint16_t wsr[NM][BD_D];           // lane l: f16 scale of row l & 31
-        v4i_t bf[BD_DB];
-        float xsv[BD_DB];
-        auto load_a = [&](int u, int blk) {
-            const int g = blk >> 2, bi = blk & 3;
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const uint8_t* tile = wbase[m] + (size_t)strip * strip_bytes + (size_t)g * TILE_BYTES;
-                af[m][u] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(tile + (hi ? 1152 : 128) + 16 * ((tl & 15) + 16 * bi)));
-                wsr[m][u] = *reinterpret_cast<const uint16_t*>(tile + 2 * ((tl & 15) + 16 * bi));
-            }
-        };
-        auto load_b = [&](int u, int blk) {
-            bf[u] = *reinterpret_cast<const v4i_t*>(a.XQ + (size_t)tok * a.maxk + (size_t)blk * 32 + 16 * hi);
-            xsv[u] = a.XS[(size_t)tok * (a.maxk >> 5) + blk];
-        };
-        v16i_t cbias;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cbias[r] = 0x4B400000;
-#pragma unroll
-        for (int u = 0; u < BD_D; ++u)
-            if (u * BD_NP + wave < a.nb) load_a(u, u * BD_NP + wave);
-#pragma unroll
-        for (int u = 0; u < BD_DB; ++u)
-            if (u * BD_NP + wave < a.nb) load_b(u, u * BD_NP + wave);
-        for (int base = 0; base < nrounds; base += BD_D) {
-#pragma unroll
-            for (int u = 0; u < BD_D; ++u) {
-                const int r = base + u;
-                if (r < nrounds) {
-                    const int blk = r * BD_NP + wave;
-                    if (blk < a.nb) {
-                        constexpr int dummy = 0; (void)dummy;
-                        const int ub = u % BD_DB;
-                        const v2f_t xs2 = v2f_t{xsv[ub], xsv[ub]};
-#pragma unroll
-                        for (int m = 0; m < NM; ++m) wsl[m * 32 + tl] = h2f(wsr[m][u]);      // both halves write the same value
-#pragma unroll
-                        for (int m = 0; m < NM; ++m) {
-                            const v16i_t c = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[m][u], bf[ub], cbias, 0, 0, 0);
-                            float* dst = P + ((size_t)((r & 1) * NM + m) * BD_NP + wave) * 1024 + lane * 4;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {        // rows 8q + 4hi .. +3 of the 32-row group
-                                const float4 w4 = *reinterpret_cast<const float4*>(wsl + m * 32 + 8 * q + 4 * hi);
-                                const v2f_t wa = v2f_t{w4.x, w4.y}, wb = v2f_t{w4.z, w4.w};
-                                const v2f_t ca = v2f_t{__int_as_float(c[4 * q]), __int_as_float(c[4 * q + 1])} - v2f_t{12582912.f, 12582912.f};
-                                const v2f_t cb = v2f_t{__int_as_float(c[4 * q + 2]), __int_as_float(c[4 * q + 3])} - v2f_t{12582912.f, 12582912.f};
-                                const v2f_t pa = ca * (wa * xs2), pb = cb * (wb * xs2);      // isum * (wScale * aScale)
-                                *reinterpret_cast<float4*>(dst + q * 256) = make_float4(pa[0], pa[1], pb[0], pb[1]);
-                            }
-                        }
-                        if (blk + BD_DB * BD_NP < a.nb) load_b(ub, blk + BD_DB * BD_NP);
-                        if (blk + BD_D * BD_NP < a.nb) load_a(u, blk + BD_D * BD_NP);
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-        __syncthreads();
-        return;
-    }
-    // ---------------------------------------------------------------------- chain wavefronts
-    // Chain wavefront c owns accumulator quads q = 2c, 2c + 1 (rows 8q + 4hi .. +3) of every (token, row) pair: two quads x
-    // NM matrices = 4 or 8 independent packed chains per lane; block w + 1 is fetched from LDS while block w is added.
-    __builtin_amdgcn_s_setprio(3);
-    const int cw = wave + BD_NC;                         // 0 .. BD_NC - 1
-    v2f_t acc[NM][2][2];
-#pragma unroll
-    for (int m = 0; m < NM; ++m)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { acc[m][j][0] = v2f_t{0.f, 0.f}; acc[m][j][1] = v2f_t{0.f, 0.f}; }
-    auto pload = [&](float4 (&v)[NM][2], int r, int w) {
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                v[m][j] = *reinterpret_cast<const float4*>(P + ((size_t)((r & 1) * NM + m) * BD_NP + w) * 1024 + (2 * cw + j) * 256 + lane * 4);
-    };
-    auto padd = [&](const float4 (&v)[NM][2]) {          // result += p (packed: two chains per instruction)
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[m][j][0] = acc[m][j][0] + v2f_t{v[m][j].x, v[m][j].y};
-                acc[m][j][1] = acc[m][j][1] + v2f_t{v[m][j].z, v[m][j].w};
-            }
-    };
-    for (int r = 0; r < nrounds; ++r) {
-        __syncthreads();
-        const int nblk = min(BD_NP, a.nb - r * BD_NP);
-        float4 va[NM][2], vb[NM][2];
-        if (nblk == BD_NP) {
-            pload(va, r, 0);
-#pragma unroll
-            for (int w = 0; w < BD_NP; w += 2) {         // blocks ascending
-                pload(vb, r, w + 1);
-                padd(va);
-                if (w + 2 < BD_NP) pload(va, r, w + 2);
-                padd(vb);
-            }
-        } else {
-            for (int w = 0; w < nblk; ++w) { pload(va, r, w); padd(va); }
-        }
-    }
-    __syncthreads();
-    // epilogue.  C layout: token = lane & 31, weight row = (r & 3) + 8 * (r >> 2) + 4 * hi
-    const int b = tl;
-    if (b >= a.ntok) return;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rbase = row0 + 8 * (2 * cw + j) + 4 * hi;
-        float* o = a.out + (size_t)b * a.out_stride + rbase;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (rbase + i >= a.rows) continue;
-            const float v0 = acc[0][j][i >> 1][i & 1];
-            if (EPI == EPI_SWIGLU) {
-                float g = v0;
-                g = g / (float)(1.0 + exp(-(double)g));
-                o[i] = g * acc[NM - 1][j][i >> 1][i & 1];
-            } else if (EPI == EPI_STORE) o[i] = v0 * a.out_scale;
-            else o[i] = o[i] + v0 * a.out_scale;
         }
     }
 }
@@ -925,8 +758,11 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
         GL3_HIP(hipMalloc((void**)&p->AO, M * ctx->q_dim * 4));
         GL3_HIP(hipMalloc((void**)&p->HB, M * d.hidden * 4));
     }
-    GL3_HIP(hipMalloc((void**)&p->XQ, M * p->maxk));
-    GL3_HIP(hipMalloc((void**)&p->XS, M * (p->maxk / 32) * 4));
+    const size_t MQ = M < 64 ? 64 : M;      // the small-batch operand layout (bd_tslots) always spans its 32 / 64 token slots
+    GL3_HIP(hipMalloc((void**)&p->XQ, MQ * p->maxk + GL3_TAIL_PAD));
+    GL3_HIP(hipMalloc((void**)&p->XS, MQ * (p->maxk / 32) * 4 + GL3_TAIL_PAD));
+    GL3_HIP(hipMemsetAsync(p->XQ, 0, MQ * p->maxk, ctx->stream));
+    GL3_HIP(hipMemsetAsync(p->XS, 0, MQ * (p->maxk / 32) * 4, ctx->stream));
     GL3_HIP(hipMalloc((void**)&p->QKV, M * (ctx->q_dim + 2 * ctx->kv_dim) * 4));
     GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
     GL3_HIP(hipMalloc((void**)&p->seqpos, 2 * M * sizeof(int32_t)));
@@ -935,11 +771,6 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_GEMM_LDS(EPI_STORE, 1, 4); GL3_GEMM_LDS(EPI_STORE, 2, 4); GL3_GEMM_LDS(EPI_STORE, 1, 8);
     GL3_GEMM_LDS(EPI_RESID, 1, 4); GL3_GEMM_LDS(EPI_RESID, 2, 4); GL3_GEMM_LDS(EPI_RESID, 1, 8);
     GL3_GEMM_LDS(EPI_SWIGLU, 1, 4);
-#define GL3_BD_LDS(EPI_, NM_) \
-    GL3_HIP(hipFuncSetAttribute((const void*)bd_gemm_kernel<EPI_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bd_smem_bytes(NM_, 8))); \
-    GL3_HIP(hipFuncSetAttribute((const void*)bd_gemm_kernel<EPI_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bd_smem_bytes(NM_, 4)))
-    GL3_BD_LDS(EPI_STORE, 1); GL3_BD_LDS(EPI_RESID, 1); GL3_BD_LDS(EPI_SWIGLU, 2);
-#undef GL3_BD_LDS
     GL3_GEMM_LDS(EPI_STORE, 1, 4, 32); GL3_GEMM_LDS(EPI_RESID, 1, 4, 32); GL3_GEMM_LDS(EPI_SWIGLU, 1, 4, 32);
 #undef GL3_GEMM_LDS
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -958,6 +789,13 @@ void gl3_prefill_free(gl3_ctx* ctx) {
     ctx->pf = nullptr;
 }
 
+// Token slots of the XQ2 / XS2 operand layout when a step of n tokens runs on the wave-owned small-batch GEMM
+// (bdw_gemm_kernel), 0 = row layout + the tiled GEMMs.  The quantiser and the GEMM of a step must agree, so both ask here.
+static int bd_tslots(int n) {
+    static const bool off = getenv("GL3_BD_GEMM") && atoi(getenv("GL3_BD_GEMM")) == 0;      // A/B switch: tiled GEMMs for small batches too
+    return (!off && n <= 32) ? BD_TS : 0;
+}
+
 template <int EPI>
 static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok, float* out, int out_stride, float out_scale = 1.0f) {
     gl3_prefill_state* p = ctx->pf;
@@ -966,13 +804,11 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     a.XQ = p->XQ; a.XS = p->XS; a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride; a.out_scale = out_scale;
     // 128-row tiles only when they still give >= 2 workgroups per CU; otherwise 64-row tiles, and 8 wavefronts per
     // workgroup when even those leave a single workgroup per CU
-    static const bool bd_off = getenv("GL3_NO_BD_GEMM") && atoi(getenv("GL3_NO_BD_GEMM"));
-    if (ntok <= 32 && !bd_off) {      // static-batched decode: producer / chain split over all K (bd_gemm_kernel)
-        constexpr int NMX = EPI == EPI_SWIGLU ? 2 : 1;
-        const int nwg = (w.rows + 31) / 32;
-        static const bool np4 = getenv("GL3_BD_NP4") && atoi(getenv("GL3_BD_NP4"));      // measured slower (6.1 vs 5.7 ms / step, Qwen3-4B B=32)
-        if (nwg <= 256 || !np4) hipLaunchKernelGGL((bd_gemm_kernel<EPI, 8>), dim3(nwg), dim3(bd_threads(8)), bd_smem_bytes(NMX, 8), ctx->stream, a);
-        else hipLaunchKernelGGL((bd_gemm_kernel<EPI, 4>), dim3(nwg), dim3(bd_threads(4)), bd_smem_bytes(NMX, 4), ctx->stream, a);
+    if (const int ts = bd_tslots(ntok)) {      // static-batched decode: one wavefront per (16-row strip, 16 tokens), all of K
+        a.tslots = ts;
+        const dim3 grid(bdw_grid((w.rows + 15) / 16, (ntok + 15) / 16));
+        if constexpr (EPI == EPI_SWIGLU) hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 4, 2>), grid, dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 8, 2>), grid, dim3(64), 0, ctx->stream, a);
         return;
     }
     if (ntok <= 64) {      // 32-token tiles, 128 rows (x2 matrices for SwiGLU) per workgroup
@@ -1025,8 +861,8 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
     auto nq_smem = [&](int k) { return (size_t)(k + 32) * 4 + ss_scratch_bytes(k) + 64; };
     for (int l = 0; l < d.n_layers; ++l) {
         gl3_layer& L = ctx->layers[l];
-        hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.attn_norm, d.rms_eps,
-                           p->XQ, p->XS, p->maxk);
+        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.attn_norm, d.rms_eps,
+                           p->XQ, p->XS, p->maxk, bd_tslots(n));
         launch_gemm<EPI_STORE>(ctx, L.wqkv, nullptr, n, p->QKV, qkv_dim);
         RopeArgs ra{};
         ra.QKV = p->QKV; ra.qkv_stride = qkv_dim; ra.kcache = ctx->kcache + l * kv_layer; ra.vcache = ctx->vcache + l * kv_layer;
@@ -1075,16 +911,16 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         }
         }
         if ((r = gl3_all_gather(ctx, GB_PF_AO, (size_t)n * qd)) != GL3_OK) return r;
-        hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->AO, ctx->q_dim, qd, (const float*)nullptr,
-                           0.f, p->XQ, p->XS, p->maxk);
+        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN>), dim3(n, (ctx->q_dim / 4 + 255) / 256), dim3(256), 0, s, p->AO, ctx->q_dim, qd, (const float*)nullptr,
+                           0.f, p->XQ, p->XS, p->maxk, bd_tslots(n));
         launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, Xr, dml, ctx->resid_scale);
         if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
-        hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.ffn_norm, d.rms_eps,
-                           p->XQ, p->XS, p->maxk);
+        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.ffn_norm, d.rms_eps,
+                           p->XQ, p->XS, p->maxk, bd_tslots(n));
         launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, HBr, hid);
         if ((r = gl3_all_gather(ctx, GB_PF_HB, (size_t)n * hid)) != GL3_OK) return r;
-        hipLaunchKernelGGL((pf_norm_quant_kernel<false>), dim3(n), dim3(256), 0, s, p->HB, d.hidden, hid, (const float*)nullptr, 0.f,
-                           p->XQ, p->XS, p->maxk);
+        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN>), dim3(n, (d.hidden / 4 + 255) / 256), dim3(256), 0, s, p->HB, d.hidden, hid, (const float*)nullptr, 0.f,
+                           p->XQ, p->XS, p->maxk, bd_tslots(n));
         launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, Xr, dml, ctx->resid_scale);
         if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
     }
@@ -1153,7 +989,7 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
         int32_t rr = pf_layers(ctx, n, mp, -1);
         if (rr != GL3_OK) return rr;
         const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
-        hipLaunchKernelGGL((pf_norm_quant_kernel<true>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk);
+        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk, bd_tslots(n));
         // vocab rows are split across ranks: this rank's logits are the chunk [n][vocab / tp] of the rank-chunked buffer
         launch_gemm<EPI_STORE>(ctx, ctx->wcls, nullptr, n, p->LOGITS + (size_t)d.tp_rank * n * vl, vl, ctx->logit_scale);
         if ((rr = gl3_all_gather(ctx, GB_PF_LOGITS, (size_t)n * vl)) != GL3_OK) return rr;
