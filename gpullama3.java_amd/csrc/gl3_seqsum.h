@@ -111,19 +111,24 @@ __device__ __forceinline__ void replay_events(const float* x, int m, int nseg, i
         }
         SS_STAMP(5);
         const int nev = __builtin_amdgcn_readfirstlane(min(64, nhard + 1 - c0));   // scalar loop control (s_cmp, not a VALU compare + vcc branch)
-        // the sequential part: a pure register chain fed by v_readlane (lane index uniform).  The run add is unconditional
-        // (+0 when there is no easy run before the event) and the binade checks are deferred: lane jj keeps the chain value
-        // before and after event jj's run add (v_cndmask) and all lanes check their own event in parallel afterwards.
-        float b_before = 0.f, b_after = 0.f;
-        auto rl = [&](float v, int j) { return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), j)); };
-        for (int jj = 0; jj < nev; ++jj) {                 // ~45 cycles per event = the five dependent adds
-            const float ra = rl(runadd, jj), s0 = rl(sq.x, jj), s1 = rl(sq.y, jj), s2 = rl(sq.z, jj), s3 = rl(sq.w, jj);
-            b_before = lane == jj ? base : b_before;
-            base = base + ra;
-            b_after = lane == jj ? base : b_after;
-            base = base + s0; base = base + s1; base = base + s2; base = base + s3;
+        // The sequential part.  Lane j already holds event j's operands, so instead of feeding one chain through v_readlane
+        // (5 per event: ~150 cycles per event for a lone wavefront) EVERY lane runs the event's five adds on its own operands and
+        // the result moves one lane up (v_mov_dpp wave_shr:1): at step k lane k holds the true incoming value — lane 0 from the
+        // start, lane k from lane k - 1's step k - 1 — and keeps it from then on (lanes <= k ignore the shifted value).  After nev
+        // steps lane j < nev still has the value before its event for the deferred binade checks, and lane nev - 1's last result
+        // is the chain value after the chunk.  Per step: five adds, one DPP move, one select.
+        float cur = base, t2 = base;
+        for (int k = 0; k < nev; ++k) {
+            const float t1 = cur + runadd;                  // +0 when there is no easy run before the event
+            t2 = t1 + sq.x; t2 = t2 + sq.y; t2 = t2 + sq.z; t2 = t2 + sq.w;
+            const float up = u2f((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f2u(t2), 0x138, 0xf, 0xf, false));   // wave_shr:1
+            cur = lane > k ? up : cur;
         }
-        if (lane < nev && er != 0u) fail |= (int)((f2u(b_before) >> 23) != er) | (int)((f2u(b_after) >> 23) != er);
+        if (lane < nev && er != 0u) {
+            const float after_run = cur + runadd;
+            fail |= (int)((f2u(cur) >> 23) != er) | (int)((f2u(after_run) >> 23) != er);
+        }
+        base = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(t2), nev - 1));
     }
     fail = __builtin_amdgcn_ballot_w64(fail != 0) != 0;          // any lane's violation fails the wavefront
 }
