@@ -24,6 +24,7 @@ struct GemmArgs {
     int ntok;
     float* out; int out_stride;           // EPI_STORE / EPI_SWIGLU: out[b*stride + row]; EPI_RESID: out +=
     float out_scale;                      // EPI_STORE / EPI_RESID: result *= out_scale first (Granite; 1 otherwise, exact)
+    uint8_t* XQo; float* XSo;             // bdw_gemm_kernel<EPI_SWIGLU, .., QOUT>: hb leaves the kernel quantised (XQ2 / XS2 layout)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -49,6 +50,8 @@ struct GemmArgs {
 //     loop exits inside the unrolled trip split the ring's live ranges, and since vmcnt counts in issue order every stream
 //     (weights from HBM, activations from L2) needs the same ring depth.
 //   * SwiGLU: gate and up rows of a strip in one wavefront (NM = 2): the activations are fetched once for both matrices.
+//     QOUT: a workgroup is the two strips of one 32-row block of hb and writes it quantised for the down projection
+//     (block maximum through LDS in the epilogue) — one launch and one f32 round trip less per layer.
 // Measured dead ends (scripts/probes/bd_probe.hip): k-slices per strip with an adding wavefront or an owning slice
 // (LDS exchange + one barrier per round: never faster than one wavefront per strip, 17-22 us vs 17.7 on the 2560 x 9728
 // matrix); token tiles of a strip in one workgroup; rings deeper than 8 tiles; non-temporal weight loads (the token tiles
@@ -58,34 +61,33 @@ struct GemmArgs {
 //   XS2[k / 128][tslots][4] f32 = the 4 block scales of a tile;
 //   XQ2[k / 64][tslots][64] int8 = blocks 2j, 2j + 1 of a token, already in the lanes' operand order: bytes 16g .. 16g + 7 =
 //   k-chunk c(g) of block 2j, bytes 16g + 8 .. 16g + 15 = the same chunk of block 2j + 1, with c(0..3) = k 0-7, 16-23, 8-15,
-//   24-31 (what the swap leaves in k-group g on the weight side) — bdq_offset() below.
+//   24-31 (what the swap leaves in k-group g on the weight side) — bdq_offset() in gl3_decode_kernels.h.
 constexpr int BD_TS = 32;
-
-// byte offset of quad qd (elements 4qd .. 4qd + 3 of a token's row) in XQ2, and float offset of block blk's scale in XS2
-__device__ __forceinline__ size_t bdq_offset(int qd, int tok, int tslots) {
-    const int blk = qd >> 3, qi = qd & 7, c = qi >> 1;
-    const int g = ((c & 1) << 1) | (c >> 1);                 // k-chunk 0, 1, 2, 3 -> k-group 0, 2, 1, 3
-    return ((size_t)(blk >> 1) * tslots + tok) * 64 + 16 * g + 8 * (blk & 1) + 4 * (qi & 1);
-}
-__device__ __forceinline__ size_t bds_offset(int blk, int tok, int tslots) { return ((size_t)(blk >> 2) * tslots + tok) * 4 + (blk & 3); }
 
 // grid: workgroup id -> (strip, token tile).  The token tiles of a strip stream the same weights, so they sit 8 ids apart: same
 // XCD (= id % 8), i.e. one L2, and dispatched together.
 __host__ __device__ inline int bdw_grid(int strips, int nt) { return ((strips + 7) / 8) * 8 * nt; }
 
-template <int EPI, int DA, int WPE>
-__global__ __launch_bounds__(64, WPE) void bdw_gemm_kernel(const GemmArgs a) {
+template <int EPI, int DA, int WPE, bool QOUT = false>
+__global__ __launch_bounds__(QOUT ? 128 : 64, WPE) void bdw_gemm_kernel(const GemmArgs a) {
+    static_assert(!QOUT || EPI == EPI_SWIGLU, "the quantising epilogue is the SwiGLU one");
+    constexpr int NWV = QOUT ? 2 : 1;                  // QOUT: two wavefronts = the two strips of one 32-row activation block
     constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int TS = BD_TS;
     static_assert(DA % 2 == 0, "ring slots are static under the unroll");
-    __shared__ __attribute__((aligned(16))) float wsl[4 * NM * 64];     // [tile & 3][matrix][block][row] weight scales
-    __shared__ __attribute__((aligned(16))) float xsl[4 * 128];         // [tile & 3][blocks 01 | 23][token][2 blocks][2]: activation scale pairs, a token's float4s 16 B apart (no bank conflicts)
-    const int lane = threadIdx.x, t = lane & 15, g = lane >> 4;
+    __shared__ __attribute__((aligned(16))) float wsl_all[NWV][4 * NM * 64];   // [tile & 3][matrix][block][row] weight scales
+    __shared__ __attribute__((aligned(16))) float xsl_all[NWV][4 * 128];       // [tile & 3][blocks 01 | 23][token][2 blocks][2]: activation scale pairs, a token's float4s 16 B apart (no bank conflicts)
+    __shared__ float amax_s[NWV][64];
+    const int lane = threadIdx.x & 63, t = lane & 15, g = lane >> 4;
+    const int wv = QOUT ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    float* wsl = wsl_all[wv];
+    float* xsl = xsl_all[wv];
     const int NTG = (a.ntok + 15) >> 4;                                         // token tiles of this launch
     const int nstrips = (a.rows + 15) >> 4;
     const int h = (blockIdx.x >> 3) % NTG;
-    const int strip = (blockIdx.x / (8 * NTG)) * 8 + (blockIdx.x & 7);
-    if (strip >= nstrips) return;                                               // padding of the grid to a multiple of 8 strips
+    const int unit = (blockIdx.x / (8 * NTG)) * 8 + (blockIdx.x & 7);           // strip (QOUT: strip pair)
+    if (unit * NWV >= nstrips) return;                                          // padding of the grid to a multiple of 8 units
+    const int strip = unit * NWV + wv;                                          // QOUT: rows % 32 == 0, so both strips exist
     const int ntiles = a.ng;
     const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
     // uniform stream bases of the NEXT tile to fetch, advanced by scalar adds
@@ -217,6 +219,38 @@ __global__ __launch_bounds__(64, WPE) void bdw_gemm_kernel(const GemmArgs a) {
     }
     // epilogue.  C layout: token = 16 h + (lane & 15), weight rows 4g .. 4g + 3 of the strip
     const int b = 16 * h + t;
+    if constexpr (QOUT) {
+        // hb = silu(gate) * up leaves the kernel as the down projection's int8 operand (Q8_0FloatTensor.java:96-118): the two
+        // wavefronts hold the 32 rows of one activation block for 16 tokens; block maximum through LDS, then every lane packs
+        // its four rows = one quad of the block.  The f32 hb is not written (nothing else reads it on this path).
+        float hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float gt = acc[0][i >> 1][i & 1];
+            gt = gt / (float)(1.0 + exp(-(double)gt));
+            hv[i] = gt * acc[NM - 1][i >> 1][i & 1];
+        }
+        amax_s[wv][lane] = fmaxf(fmaxf(fabsf(hv[0]), fabsf(hv[1])), fmaxf(fabsf(hv[2]), fabsf(hv[3])));
+        __syncthreads();
+        float amax = 0.f;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) amax = fmaxf(amax, amax_s[w][16 * gg + t]);
+        if (b >= a.ntok) return;
+        const float qs = amax / 127.0f;
+        const float ainv = qs != 0.f ? 1.0f / qs : 0.f;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sv = hv[i] * ainv;
+            packed |= (uint32_t)((int)(sv + copysignf(0.5f, sv)) & 0xFF) << (8 * i);
+        }
+        const int blk = strip >> 1;
+        *reinterpret_cast<uint32_t*>(a.XQo + bdq_offset(blk * 8 + (strip & 1) * 4 + g, b, TS)) = packed;
+        if (wv == 0 && g == 0) a.XSo[bds_offset(blk, b, TS)] = (float)(_Float16)qs;
+        return;
+    }
     if (b >= a.ntok) return;
     const int rbase = strip * 16 + 4 * g;
     float* o = a.out + (size_t)b * a.out_stride + rbase;

@@ -131,6 +131,15 @@ __device__ __forceinline__ void quantize_quad(float4 v, int qd, uint8_t* xq, flo
     if ((qd & 7) == 0) xs[qd >> 3] = qs;
 }
 
+// Small-batch operand layout (gl3_bd_gemm.h): byte offset of quad qd (elements 4qd .. 4qd + 3 of a token's row) in XQ2, and
+// float offset of block blk's scale in XS2; tslots token slots.
+__device__ __forceinline__ size_t bdq_offset(int qd, int tok, int tslots) {
+    const int blk = qd >> 3, qi = qd & 7, c = qi >> 1;
+    const int g = ((c & 1) << 1) | (c >> 1);                 // k-chunk 0, 1, 2, 3 -> k-group 0, 2, 1, 3
+    return ((size_t)(blk >> 1) * tslots + tok) * 64 + 16 * g + 8 * (blk & 1) + 4 * (qi & 1);
+}
+__device__ __forceinline__ size_t bds_offset(int blk, int tok, int tslots) { return ((size_t)(blk >> 2) * tslots + tok) * 4 + (blk & 3); }
+
 __device__ __forceinline__ int dot32(const int4& a0, const int4& a1, const int4& b0, const int4& b1) {
     int s = 0;
     s = __builtin_amdgcn_sdot4(a0.x, b0.x, s, false); s = __builtin_amdgcn_sdot4(a0.y, b0.y, s, false);
@@ -418,6 +427,9 @@ struct AttnArgs {
     int qkv_stride, xb_stride;   // floats between consecutive tokens' rows of qkv / xb
     float att_mul;           // 0: score / sqrt(head_size); Granite: score * attentionScale (forwardGranite :870-872)
     int group;               // attn_head_kernel: query heads per workgroup (0 / 1: one; kvMul: the whole group of a kv head)
+    // attn_head_kernel, static-batched decode on one rank: the output leaves the kernel as the wo projection's int8 operand in the
+    // small-batch layout (gl3_bd_gemm.h: XQ2 / XS2, xq_slots token slots) instead of f32 xb; NULL = write xb
+    uint8_t* xq_out; float* xs_out; int xq_slots;
 };
 
 __device__ __forceinline__ void rope_head(float* v, int hs, const float* cr, const float* ci, int arch, int t0, int nthreads) {
@@ -703,7 +715,30 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
             acc = a4.x * v0 + acc; acc = a4.y * v1 + acc; acc = a4.z * v2 + acc; acc = a4.w * v3 + acc;
         }
         for (; tt < n; ++tt) acc = e[tt] * vt[tt * hs + j] + acc;
-        a.xb[(size_t)bt * a.xb_stride + (size_t)(h0 + g) * hs + j] = acc;
+        if (a.xq_out) {
+            // Q8_0 activation quantisation of the 32-element block this half-wavefront holds (Q8_0FloatTensor.java:96-118; head
+            // sizes are multiples of 32, so a block never straddles heads or passes): block maximum over 32 lanes, round half
+            // away from zero, four lanes' bytes packed by the quad's first lane.
+            float am = fabsf(acc);
+            am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, am), 0xB1, 0xf, 0xf, false)));
+            am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, am), 0x4E, 0xf, 0xf, false)));
+            am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, am), 0x141, 0xf, 0xf, false)));
+            am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, am), 0x140, 0xf, 0xf, false)));
+            am = fmaxf(am, __shfl_xor(am, 16, 64));
+            const float qs = am / 127.0f;
+            const float ainv = qs != 0.f ? 1.0f / qs : 0.f;
+            const float sv = acc * ainv;
+            const int q0 = (int)(sv + copysignf(0.5f, sv)) & 0xFF;
+            const int q1 = __builtin_amdgcn_update_dpp(0, q0, 0x55, 0xf, 0xf, false);      // quad_perm [1,1,1,1]
+            const int q2 = __builtin_amdgcn_update_dpp(0, q0, 0xAA, 0xf, 0xf, false);      // [2,2,2,2]
+            const int q3 = __builtin_amdgcn_update_dpp(0, q0, 0xFF, 0xf, 0xf, false);      // [3,3,3,3]
+            const int el = (h0 + g) * hs + j;                                                // element of the token's q_dim row
+            if ((lane & 3) == 0)
+                *reinterpret_cast<uint32_t*>(a.xq_out + bdq_offset(el >> 2, bt, a.xq_slots)) = (uint32_t)q0 | ((uint32_t)q1 << 8) | ((uint32_t)q2 << 16) | ((uint32_t)q3 << 24);
+            if ((lane & 31) == 0) a.xs_out[bds_offset(el >> 5, bt, a.xq_slots)] = (float)(_Float16)qs;
+        } else {
+            a.xb[(size_t)bt * a.xb_stride + (size_t)(h0 + g) * hs + j] = acc;
+        }
     }
     ATT_STAMP(6);
 }

@@ -25,6 +25,8 @@ struct gl3_prefill_state {
     float* X = nullptr;                 // [M][dim] residual stream (rank-chunked [tp][n][dim/tp] under tensor parallelism)
     uint8_t* XQ = nullptr;              // [M][maxk] int8 activations
     float* XS = nullptr;                // [M][maxk/32] activation scales
+    uint8_t* XQb = nullptr;             // second small-batch operand buffer: hb quantised by the gate/up kernel's own epilogue
+    float* XSb = nullptr;               //   (its input still being read by other workgroups)
     float* QKV = nullptr;               // [M][q_dim + 2 kv_dim]
     float* AO = nullptr;                // [M][q_dim] attention output (rank-chunked)
     float* HB = nullptr;                // [M][hidden] (rank-chunked)
@@ -761,6 +763,10 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     const size_t MQ = M < 64 ? 64 : M;      // the small-batch operand layout (bd_tslots) always spans its 32 / 64 token slots
     GL3_HIP(hipMalloc((void**)&p->XQ, MQ * p->maxk + GL3_TAIL_PAD));
     GL3_HIP(hipMalloc((void**)&p->XS, MQ * (p->maxk / 32) * 4 + GL3_TAIL_PAD));
+    GL3_HIP(hipMalloc((void**)&p->XQb, (size_t)BD_TS * p->maxk + GL3_TAIL_PAD));
+    GL3_HIP(hipMalloc((void**)&p->XSb, (size_t)BD_TS * (p->maxk / 32) * 4 + GL3_TAIL_PAD));
+    GL3_HIP(hipMemsetAsync(p->XQb, 0, (size_t)BD_TS * p->maxk, ctx->stream));
+    GL3_HIP(hipMemsetAsync(p->XSb, 0, (size_t)BD_TS * (p->maxk / 32) * 4, ctx->stream));
     GL3_HIP(hipMemsetAsync(p->XQ, 0, MQ * p->maxk, ctx->stream));
     GL3_HIP(hipMemsetAsync(p->XS, 0, MQ * (p->maxk / 32) * 4, ctx->stream));
     GL3_HIP(hipMalloc((void**)&p->QKV, M * (ctx->q_dim + 2 * ctx->kv_dim) * 4));
@@ -783,7 +789,7 @@ void gl3_prefill_free(gl3_ctx* ctx) {
     if (!p) return;
     for (auto ge : p->step_graphs) if (ge) hipGraphExecDestroy(ge);
     auto f = [](void* q) { if (q) hipFree(q); };
-    f(p->tokens); f(p->XQ); f(p->XS); f(p->QKV); f(p->ATT); f(p->seqpos); f(p->amax);
+    f(p->tokens); f(p->XQ); f(p->XS); f(p->XQb); f(p->XSb); f(p->QKV); f(p->ATT); f(p->seqpos); f(p->amax);
     if (!p->in_arena) { f(p->X); f(p->AO); f(p->HB); f(p->LOGITS); }
     delete p;
     ctx->pf = nullptr;
@@ -797,18 +803,24 @@ static int bd_tslots(int n) {
 }
 
 template <int EPI>
-static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok, float* out, int out_stride, float out_scale = 1.0f) {
+static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok, float* out, int out_stride, float out_scale = 1.0f,
+                        bool second_operand = false, bool quantised_out = false) {
     gl3_prefill_state* p = ctx->pf;
     GemmArgs a{};
     a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.ng = w.ng; a.nb = w.k / 32;
-    a.XQ = p->XQ; a.XS = p->XS; a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride; a.out_scale = out_scale;
+    a.XQ = second_operand ? p->XQb : p->XQ; a.XS = second_operand ? p->XSb : p->XS;
+    a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride; a.out_scale = out_scale;
+    a.XQo = p->XQb; a.XSo = p->XSb;
     // 128-row tiles only when they still give >= 2 workgroups per CU; otherwise 64-row tiles, and 8 wavefronts per
     // workgroup when even those leave a single workgroup per CU
     if (const int ts = bd_tslots(ntok)) {      // static-batched decode: one wavefront per (16-row strip, 16 tokens), all of K
         a.tslots = ts;
         const dim3 grid(bdw_grid((w.rows + 15) / 16, (ntok + 15) / 16));
-        if constexpr (EPI == EPI_SWIGLU) hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 4, 2>), grid, dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 8, 2>), grid, dim3(64), 0, ctx->stream, a);
+        if constexpr (EPI == EPI_SWIGLU) {
+            if (quantised_out)      // workgroup = the two strips of a 32-row block of hb; hb is written as the down projection's operand
+                hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 4, 2, true>), dim3(bdw_grid((w.rows + 31) / 32, (ntok + 15) / 16)), dim3(128), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 4, 2>), grid, dim3(64), 0, ctx->stream, a);
+        } else hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 8, 2>), grid, dim3(64), 0, ctx->stream, a);
         return;
     }
     if (ntok <= 64) {      // 32-token tiles, 128 rows (x2 matrices for SwiGLU) per workgroup
@@ -853,6 +865,10 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
     // one workgroup per (kv head, token) serves the kv head's whole group of query heads when its LDS image fits
     const int bd_group = (kvmul <= 8 && attn_head_smem(d.head_size, kvmul) <= 150 * 1024) ? kvmul : 1;
     const bool fused_decode = ctx->fused_attn_ok && max_pos < AF_MAXN && !(getenv("GL3_NO_FUSED_BD_ATTN") && atoi(getenv("GL3_NO_FUSED_BD_ATTN")));
+    // small batch on one rank: the attention output and hb leave their kernels already quantised for the next GEMM (no
+    // separate quantise launches; under tensor parallelism the f32 vectors are gathered first, so the launches stay)
+    static const bool fuse_off = getenv("GL3_NO_FUSED_QUANT") && atoi(getenv("GL3_NO_FUSED_QUANT"));
+    const bool fuse_q = !fuse_off && bd_tslots(n) != 0 && d.tp_size == 1 && (d.hidden % 32) == 0 && (d.head_size % 32) == 0;
     float* Xr = p->X + (size_t)rank * n * dml;           // this rank's chunk of X / AO / HB
     float* AOr = p->AO + (size_t)rank * n * qd;
     float* HBr = p->HB + (size_t)rank * n * hid;
@@ -884,6 +900,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
             ha.xb = AOr; ha.xb_stride = qd; ha.n_heads = H; ha.n_kv_heads = KVH; ha.hs = hs; ha.q_dim = qd; ha.kv_dim = kvd; ha.ctx = d.ctx;
             ha.eps = d.rms_eps; ha.arch = ctx->rope_arch; ha.att_mul = ctx->att_mul; ha.seqv = seq; ha.posv = pos; ha.seq_stride = ctx->kv_seq_stride;
             ha.group = bd_group;
+            if (fuse_q) { ha.xq_out = p->XQ; ha.xs_out = p->XS; ha.xq_slots = bd_tslots(n); }
             hipLaunchKernelGGL(attn_head_kernel, dim3(H / bd_group, n), dim3(256), attn_head_smem(hs, bd_group), s, ha);
         } else {
         hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(H + KVH, n), dim3(64), 0, s, ra);
@@ -911,17 +928,23 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         }
         }
         if ((r = gl3_all_gather(ctx, GB_PF_AO, (size_t)n * qd)) != GL3_OK) return r;
-        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN>), dim3(n, (ctx->q_dim / 4 + 255) / 256), dim3(256), 0, s, p->AO, ctx->q_dim, qd, (const float*)nullptr,
-                           0.f, p->XQ, p->XS, p->maxk, bd_tslots(n));
+        if (!(fuse_q && one_seq < 0 && fused_decode))
+            hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN>), dim3(n, (ctx->q_dim / 4 + 255) / 256), dim3(256), 0, s, p->AO, ctx->q_dim, qd, (const float*)nullptr,
+                               0.f, p->XQ, p->XS, p->maxk, bd_tslots(n));
         launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, Xr, dml, ctx->resid_scale);
         if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
         hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.ffn_norm, d.rms_eps,
                            p->XQ, p->XS, p->maxk, bd_tslots(n));
-        launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, HBr, hid);
-        if ((r = gl3_all_gather(ctx, GB_PF_HB, (size_t)n * hid)) != GL3_OK) return r;
-        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN>), dim3(n, (d.hidden / 4 + 255) / 256), dim3(256), 0, s, p->HB, d.hidden, hid, (const float*)nullptr, 0.f,
-                           p->XQ, p->XS, p->maxk, bd_tslots(n));
-        launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, Xr, dml, ctx->resid_scale);
+        if (fuse_q) {
+            launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, HBr, hid, 1.0f, false, true);
+            launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, Xr, dml, ctx->resid_scale, true);
+        } else {
+            launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, HBr, hid);
+            if ((r = gl3_all_gather(ctx, GB_PF_HB, (size_t)n * hid)) != GL3_OK) return r;
+            hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN>), dim3(n, (d.hidden / 4 + 255) / 256), dim3(256), 0, s, p->HB, d.hidden, hid, (const float*)nullptr, 0.f,
+                               p->XQ, p->XS, p->maxk, bd_tslots(n));
+            launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, Xr, dml, ctx->resid_scale);
+        }
         if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
     }
     GL3_HIP(hipGetLastError());
