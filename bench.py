@@ -95,30 +95,54 @@ def main():
         return bench_decode_batch(args, cfg, synth, plan_mod, pkg, torch, np, dev)
     t0 = time.time()
     keep_host = (world == 1 and not args.no_cpu_baseline)
-    uid, exchange = None, None
-    if world > 1 and transport == "rccl":
-        obj = [plan_mod.make_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(obj, src=0)
-        uid = obj[0]
-    elif world > 1:
-        def exchange(handle):
-            out = [None] * world
-            dist.all_gather_object(out, handle)
-            return out
     wtype = {"q8_0": synth.GGML_Q8_0, "f16": synth.GGML_F16, "q4_0": synth.GGML_Q4_0}[args.wtype]
     WT = args.wtype.upper()
     bpe = {"q8_0": 34 / 32, "f16": 2.0, "q4_0": 18 / 32}[args.wtype]          # weight bytes per element
-    if keep_host:
-        model = synth.make_torch(cfg, wtype=wtype, seed=args.seed, device=dev)
-    else:
-        model = synth.StreamModel(cfg, wtype, synth.iter_torch(cfg, wtype=wtype, seed=args.seed, device=dev))
-    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(model, prefill_batch_size=args.batch, device=local_rank,
-                                                           tp_rank=rank, tp_size=world, unique_id=uid, p2p_exchange=exchange)
-    if dist is not None:
-        dist.barrier()                      # every rank's plan exists and is attached before the first gather
+    toks = pkg.javarand.bench_tokens(cfg.vocab, args.n_prompt + args.n_gen)
+
+    def build_plan(transport):
+        uid, exchange = None, None
+        if world > 1 and transport == "rccl":
+            obj = [plan_mod.make_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(obj, src=0)
+            uid = obj[0]
+        elif world > 1:
+            def exchange(handle):
+                out = [None] * world
+                dist.all_gather_object(out, handle)
+                return out
+        if keep_host:
+            mdl = synth.make_torch(cfg, wtype=wtype, seed=args.seed, device=dev)
+        else:
+            mdl = synth.StreamModel(cfg, wtype, synth.iter_torch(cfg, wtype=wtype, seed=args.seed, device=dev))
+        pl = plan_mod.HipMasterPlan.initializeTornadoVMPlan(mdl, prefill_batch_size=args.batch, device=local_rank,
+                                                             tp_rank=rank, tp_size=world, unique_id=uid, p2p_exchange=exchange)
+        if dist is not None:
+            dist.barrier()                  # every rank's plan exists and is attached before the first gather
+        return mdl, pl
+
+    model, plan = build_plan(transport)
+    if world > 1 and transport != "rccl":
+        # one decode step as a transport self-test: the peer-write gather reports a timeout / mapping problem as an error (its spin
+        # is bounded); if any rank saw one, every rank rebuilds its plan over RCCL instead of failing the run
+        ok = 1
+        try:
+            plan.forward_decode(toks[0], 0, copy=False)
+            torch.cuda.synchronize()
+        except Exception as e:              # noqa: BLE001
+            ok = 0
+            print("rank %d: peer-write transport failed its self-test (%s); falling back to RCCL" % (rank, e), file=sys.stderr)
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        if not all(flags):
+            try:
+                plan.freeTornadoExecutionPlan()
+            except Exception:               # noqa: BLE001
+                pass
+            transport = "rccl"
+            model, plan = build_plan(transport)
     torch.cuda.empty_cache()
     setup_s = time.time() - t0
-    toks = pkg.javarand.bench_tokens(cfg.vocab, args.n_prompt + args.n_gen)
 
     def barrier():
         if dist is not None:

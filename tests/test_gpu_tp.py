@@ -26,7 +26,7 @@ def test_row_split_ranks_are_bit_identical_to_the_oracle(pkg, orc, planmod, cfg,
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=17)
     o = orc.COracle(m, vector_bits=0 if wtype == 8 else 256)         # F16 / Q4_0: the plan's default Vector-API dot order
-    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 6 if tp <= 2 else 3)     # in-process ranks time-share one GPU: keep tp >= 4 short
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 4 if tp <= 2 else 2)     # in-process ranks time-share one GPU: keep tp >= 4 short
     ref = [o.forward(t, p) for p, t in enumerate(toks)]
     grp = plan_mod.make_local_group(tp)
     out = [None] * tp
