@@ -56,7 +56,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pp", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--wtype", default="q8_0", choices=["q8_0", "f16", "q4_0"], help="ggml type of the matrices (default: the headline Q8_0)")
+    ap.add_argument("--wtype", default="q8_0", choices=["q8_0", "f16", "q4_0", "q8_0_f32act"],
+                    help="ggml type of the matrices (default: the headline Q8_0); q8_0_f32act = Q8_0 with -Dllama.quantizeActivation=false "
+                         "(f32 activation, Q8_0FloatTensor.vectorDot)")
     ap.add_argument("--decode-batch", type=int, default=0, help="BASELINE configs[4]: static-batched decode of B independent sequences "
                     "(e.g. --model qwen3-4b --decode-batch 32); prints its own JSON line instead of the tg/pp line")
     args = ap.parse_args()
@@ -95,9 +97,10 @@ def main():
         return bench_decode_batch(args, cfg, synth, plan_mod, pkg, torch, np, dev)
     t0 = time.time()
     keep_host = (world == 1 and not args.no_cpu_baseline)
-    wtype = {"q8_0": synth.GGML_Q8_0, "f16": synth.GGML_F16, "q4_0": synth.GGML_Q4_0}[args.wtype]
+    wtype = {"q8_0": synth.GGML_Q8_0, "f16": synth.GGML_F16, "q4_0": synth.GGML_Q4_0, "q8_0_f32act": synth.GGML_Q8_0}[args.wtype]
     WT = args.wtype.upper()
-    bpe = {"q8_0": 34 / 32, "f16": 2.0, "q4_0": 18 / 32}[args.wtype]          # weight bytes per element
+    bpe = {"q8_0": 34 / 32, "f16": 2.0, "q4_0": 18 / 32, "q8_0_f32act": 34 / 32}[args.wtype]          # weight bytes per element
+    plan_flags = hip.FLAG_F32_ACTIVATION if args.wtype == "q8_0_f32act" else 0
     toks = pkg.javarand.bench_tokens(cfg.vocab, args.n_prompt + args.n_gen)
 
     def build_plan(transport):
@@ -116,7 +119,7 @@ def main():
         else:
             mdl = synth.StreamModel(cfg, wtype, synth.iter_torch(cfg, wtype=wtype, seed=args.seed, device=dev))
         pl = plan_mod.HipMasterPlan.initializeTornadoVMPlan(mdl, prefill_batch_size=args.batch, device=local_rank,
-                                                             tp_rank=rank, tp_size=world, unique_id=uid, p2p_exchange=exchange)
+                                                             tp_rank=rank, tp_size=world, unique_id=uid, p2p_exchange=exchange, flags=plan_flags)
         if dist is not None:
             dist.barrier()                  # every rank's plan exists and is attached before the first gather
         return mdl, pl
@@ -225,7 +228,7 @@ def main():
     if "matvec_gateup" in kern and args.wtype == "q8_0":
         dom["avg_us_instrumented_steps"] = kern["matvec_gateup"]["avg_us"]
     kname = "matvec_q8t_kernel<PRO_RMS,EPI_SWIGLU> (fused RMSNorm + gate/up Q8_0 matvec + SwiGLU, %dx%d x2)" if args.wtype == "q8_0" else \
-        "rmsnorm_f32_kernel + matvec_vl_kernel<" + WT + ",EPI_SWIGLU> (gate/up Vector-API-order matvec + SwiGLU, %dx%d x2)"
+        "rmsnorm_f32_kernel + matvec_vl_kernel<WT_" + WT.split("_F32")[0] + ",EPI_SWIGLU> (gate/up Vector-API-order matvec + SwiGLU, %dx%d x2)"
     roofline = dict(bound="hbm", kernel=kname % (cfg.hidden // world, cfg.dim),
                     achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(dom["gbs"] / HBM_PEAK_GBS, 4),
                     traffic=None, avg_us=dom["avg_us"], avg_us_instrumented_steps=dom.get("avg_us_instrumented_steps"),
@@ -276,7 +279,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle_c
-        o = oracle_c.COracle(model)
+        # the oracle in the plan's mode: Vector-API dot order (256-bit species) for F16 / Q4_0 / f32-activation Q8_0
+        o = oracle_c.COracle(model, vector_bits=0 if args.wtype == "q8_0" else 256, f32_activation=args.wtype == "q8_0_f32act")
         n_done, t1 = 0, time.perf_counter()
         while True:
             o.forward(toks[n_done], n_done)

@@ -86,7 +86,7 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
                 else if (epi == EPI_RESID) hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_RESID>), vg, vb, vs, s, v); \
                 else hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_SWIGLU>), vg, vb, vs, s, v); \
             } while (0)
-            if (w.fmt == GL3_TYPE_F16) GL3_VL(WT_F16); else GL3_VL(WT_Q4_0);
+            if (w.fmt == GL3_TYPE_F16) GL3_VL(WT_F16); else if (w.fmt == GL3_FMT_Q8V) GL3_VL(WT_Q8_0); else GL3_VL(WT_Q4_0);
 #undef GL3_VL
             return;
         }
@@ -193,12 +193,13 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
     hipStream_t s = ctx->stream;
     Prof pr{ctx, kt};
     const int rank = d.tp_rank;
-    const bool q8 = d.weight_type == GL3_TYPE_Q8_0;
+    const bool q8 = ctx->emb.fmt == GL3_TYPE_Q8_0;       // Q8T path (int8 activation)
     int32_t r;
 
     pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
     if (ctx->emb.fmt == GL3_TYPE_Q8_0) hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
     else if (ctx->emb.vl && ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_vl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
+    else if (ctx->emb.vl && ctx->emb.fmt == GL3_FMT_Q8V) hipLaunchKernelGGL((embed_vl_kernel<WT_Q8_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
     else if (ctx->emb.vl) hipLaunchKernelGGL((embed_vl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
     else if (ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_rl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
     else hipLaunchKernelGGL((embed_rl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
@@ -255,7 +256,8 @@ static int32_t dmalloc(gl3_ctx* ctx, T** p, size_t n) {
 
 static int32_t alloc_mat(gl3_ctx* ctx, Q8Mat& m, int rows, int k) {
     m.rows = rows; m.k = k; m.ng = ((k / 32) + 3) / 4; m.nstrips = (rows + 15) / 16; m.fmt = ctx->d.weight_type;
-    m.vl = m.fmt != GL3_TYPE_Q8_0 && !(ctx->d.flags & GL3_FLAG_SCALAR_DOT);
+    if (m.fmt == GL3_TYPE_Q8_0 && (ctx->d.flags & GL3_FLAG_F32_ACTIVATION)) m.fmt = GL3_FMT_Q8V;
+    m.vl = m.fmt == GL3_FMT_Q8V || (m.fmt != GL3_TYPE_Q8_0 && !(ctx->d.flags & GL3_FLAG_SCALAR_DOT));
     GL3_HIP(hipMalloc((void**)&m.w, m.bytes() + GL3_TAIL_PAD));
     if (m.fmt != GL3_TYPE_Q8_0) GL3_HIP(hipMemset(m.w, 0, m.bytes()));      // padded rows of the last 64-row group
     return GL3_OK;
@@ -309,6 +311,15 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     }
     if (d.weight_type != GL3_TYPE_Q8_0 && d.weight_type != GL3_TYPE_F16 && d.weight_type != GL3_TYPE_Q4_0)
         return bail(GL3_E_UNSUPPORTED, "matrix weight type must be Q8_0, F16 or Q4_0");
+    const bool q8v = d.weight_type == GL3_TYPE_Q8_0 && (d.flags & GL3_FLAG_F32_ACTIVATION);
+    if ((d.flags & GL3_FLAG_F32_ACTIVATION) && d.weight_type != GL3_TYPE_Q8_0)
+        return bail(GL3_E_ARG, "GL3_FLAG_F32_ACTIVATION applies to Q8_0 matrices");
+    if (q8v && (d.flags & GL3_FLAG_SCALAR_DOT))
+        return bail(GL3_E_UNSUPPORTED, "Q8_0 with f32 activation is built in the Vector-API order only");
+    if (q8v && (d.dim % 128 || d.hidden % 128 || (d.n_heads * d.head_size) % 128))
+        return bail(GL3_E_UNSUPPORTED, "Q8_0 with f32 activation needs inner dimensions that are multiples of 128");
+    if (q8v && d.tp_size > 1 && (d.vocab / d.tp_size) % 8)
+        return bail(GL3_E_UNSUPPORTED, "Q8_0 with f32 activation: vocab/tp_size must be a multiple of 8");
     if (d.weight_type != GL3_TYPE_Q8_0 && (d.dim % 64 || d.hidden % 64 || (d.n_heads * d.head_size) % 64))
         return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0 matrices need inner dimensions that are multiples of 64");
     if (d.weight_type != GL3_TYPE_Q8_0 && rl_smem_bytes(d.hidden > d.dim ? d.hidden : d.dim, EPI_STORE) > 150 * 1024)
@@ -398,7 +409,7 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP(hipHostMalloc((void**)&ctx->h_logits, (size_t)d.vocab * 4));
     TRYHIP(hipHostMalloc((void**)&ctx->h_argmax, sizeof(int)));
     // the batched (int8 MFMA) prefill exists for Q8_0 only; F16 / Q4_0 prefill token by token
-    if (d.max_batch > 1 && d.weight_type == GL3_TYPE_Q8_0) TRY(gl3_prefill_alloc(ctx));
+    if (d.max_batch > 1 && d.weight_type == GL3_TYPE_Q8_0 && !(d.flags & GL3_FLAG_F32_ACTIVATION)) TRY(gl3_prefill_alloc(ctx));
     TRYHIP(hipDeviceSynchronize());
 #undef TRY
 #undef TRYHIP
@@ -458,16 +469,17 @@ static int32_t upload_q8(gl3_ctx* ctx, Q8Mat& m, int dst_row0, int sub_rows, con
                          int k_full, long r0) {
     const int nb_full = k_full / 32;
     if (k_full != m.k) GL3_FAIL(GL3_E_ARG, "tensor inner dimension mismatch");
-    const size_t row_bytes = m.fmt == GL3_TYPE_Q8_0 ? (size_t)nb_full * 34 : m.fmt == GL3_TYPE_F16 ? (size_t)k_full * 2 : (size_t)nb_full * 18;
+    const size_t row_bytes = (m.fmt == GL3_TYPE_Q8_0 || m.fmt == GL3_FMT_Q8V) ? (size_t)nb_full * 34 : m.fmt == GL3_TYPE_F16 ? (size_t)k_full * 2 : (size_t)nb_full * 18;
     if (bytes != (uint64_t)rows_full * row_bytes) GL3_FAIL(GL3_E_ARG, "tensor byte size does not match its shape");
     const uint8_t* h = (const uint8_t*)host + (size_t)r0 * row_bytes;
     if (m.fmt != GL3_TYPE_Q8_0) {
         int32_t r = stage(ctx, h, (size_t)sub_rows * row_bytes);
         if (r != GL3_OK) return r;
         if (m.vl) {
-            const long total = (long)sub_rows * (m.fmt == GL3_TYPE_F16 ? k_full / 64 : k_full / 256) * 8;
+            const long total = (long)sub_rows * (m.fmt == GL3_TYPE_F16 ? k_full / 64 : m.fmt == GL3_FMT_Q8V ? k_full / 128 : k_full / 256) * 8;
             const dim3 grid((unsigned)((total + 255) / 256));
             if (m.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((repack_vl_kernel<WT_F16>), grid, dim3(256), 0, ctx->stream, ctx->staging, m.w, sub_rows, k_full, dst_row0);
+            else if (m.fmt == GL3_FMT_Q8V) hipLaunchKernelGGL((repack_vl_kernel<WT_Q8_0>), grid, dim3(256), 0, ctx->stream, ctx->staging, m.w, sub_rows, k_full, dst_row0);
             else hipLaunchKernelGGL((repack_vl_kernel<WT_Q4_0>), grid, dim3(256), 0, ctx->stream, ctx->staging, m.w, sub_rows, k_full, dst_row0);
             GL3_HIP(hipStreamSynchronize(ctx->stream));
             return GL3_OK;

@@ -16,22 +16,25 @@
 // past the end of a strip instead of clamping or guarding their addresses (gl3_bd_gemm.h).
 constexpr size_t GL3_TAIL_PAD = 256 * 1024;
 
-struct Q8Mat {               // one repacked matrix: Q8T tiles (gl3_decode_kernels.h) or F16 / Q4_0 row-lane (gl3_rowlane_kernels.h)
+// Internal format code of Q8_0 matrices run with an f32 activation (GL3_FLAG_F32_ACTIVATION): VL layout, gl3_veclane_kernels.h
+constexpr int GL3_FMT_Q8V = 108;
+
+struct Q8Mat {               // one repacked matrix: Q8T tiles (gl3_decode_kernels.h), VL groups (gl3_veclane_kernels.h) or row-lane groups
     uint8_t* w = nullptr;
     int rows = 0, k = 0;
     int ng = 0;              // Q8T: tile groups per strip = ceil(k/32 / 4)
     int nstrips = 0;         // Q8T: ceil(rows / 16)
-    int fmt = 8;             // GL3_TYPE_* of the source tensor (8 = Q8_0, 1 = F16, 2 = Q4_0)
-    bool vl = false;         // F16 / Q4_0: "VL" layout of the Vector-API-order kernels (gl3_veclane_kernels.h); false = row-lane
+    int fmt = 8;             // 8 = Q8_0 as Q8T tiles (int8 activation), 1 = F16, 2 = Q4_0, GL3_FMT_Q8V = Q8_0 with f32 activation
+    bool vl = false;         // "VL" layout of the Vector-API-order kernels; false (F16 / Q4_0 only) = row-lane, scalar order
     size_t rl_group_bytes() const { return fmt == 1 ? (size_t)(k / 8) * 1024 : (size_t)(k / 32) * 1152; }
-    size_t vl_group_bytes() const { return fmt == 1 ? (size_t)(k / 64) * 1024 : (size_t)(k / 256) * 1152; }
+    size_t vl_group_bytes() const { return fmt == 1 ? (size_t)(k / 64) * 1024 : fmt == 2 ? (size_t)(k / 256) * 1152 : (size_t)(k / 128) * 1088; }
     size_t bytes() const {
         if (fmt != 8 && vl) return (size_t)((rows + 7) / 8) * vl_group_bytes();
         if (fmt != 8) return (size_t)((rows + 63) / 64) * rl_group_bytes();
         return (size_t)(nstrips + (nstrips & 1)) * ng * 2176;            // even #strips: the prefill GEMM reads 32-row groups
     }
     size_t algo_bytes() const {                                          // GGUF bytes (no padding)
-        return fmt == 8 ? (size_t)rows * (k / 32) * 34 : fmt == 1 ? (size_t)rows * k * 2 : (size_t)rows * (k / 32) * 18;
+        return (fmt == 8 || fmt == GL3_FMT_Q8V) ? (size_t)rows * (k / 32) * 34 : fmt == 1 ? (size_t)rows * k * 2 : (size_t)rows * (k / 32) * 18;
     }
 };
 

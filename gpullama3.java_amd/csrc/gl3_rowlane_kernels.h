@@ -21,7 +21,7 @@
 
 namespace gl3 {
 
-enum { WT_F16 = 1, WT_Q4_0 = 2 };
+enum { WT_F16 = 1, WT_Q4_0 = 2, WT_Q8_0 = 3 };      // WT_Q8_0: Q8_0 with f32 activation (veclane kernels only)
 
 __host__ __device__ inline size_t rl_group_bytes(int wt, int k) {       // bytes of one 64-row group
     return wt == WT_F16 ? (size_t)(k / 8) * 1024 : (size_t)(k / 32) * 1152;

@@ -6,6 +6,10 @@
 //   Q4_0 : Q4_0FloatTensor.vectorDot, 256-bit branch (J/tensor/standard/Q4_0FloatTensor.java:82-133), per 32-element block j:
 //              s[l]   = ((x[j+l] * lo[l] + x[j+8+l] * lo[8+l]) + x[j+16+l] * hi[l]) + x[j+24+l] * hi[8+l]
 //              val[l] = fma(s[l], wScale, val[l])        lo / hi = (low / high nibbles of the 16 quant bytes) - 8 as floats
+//   Q8_0 with f32 activation (GL3_FLAG_F32_ACTIVATION = -Dllama.quantizeActivation=false): Q8_0FloatTensor.vectorDot, 256-bit
+//          branch (J/tensor/standard/Q8_0FloatTensor.java:125-175), per 32-element block j with int8 quants q:
+//              s[l]   = ((x[j+l] * q[l] + x[j+8+l] * q[8+l]) + x[j+16+l] * q[16+l]) + x[j+24+l] * q[24+l]
+//              val[l] = fma(s[l], wScale, val[l])
 //   result = reduceLanes(ADD) = ((((0 + val[0]) + val[1]) + ...) + val[7])     (lane order from 0: HotSpot evaluates float add reductions strictly in order on x86)
 // Eight independent accumulator chains per row make the row's K-long sum 8-way parallel, and that is also the natural GPU
 // mapping: lane = (row, accumulator lane), a wavefront = 8 rows x 8 accumulators.  Every lane runs a K/8-long chain of
@@ -15,6 +19,7 @@
 // Weight layout in HBM ("VL", built once at upload, same byte count as GGUF): rows in groups of 8; per group and chunk a
 // wavefront's loads are contiguous and each lane's 16 bytes are exactly what its chain consumes next:
 //   F16  chunk = 64 elements : [lane (r, l)][8 halfs w[r][64 c + 8 k + l], k = 0..7]                       1024 B
+//   Q8_0 chunk = 4 blocks    : [lane (r, l)][4 x (q[l], q[8+l], q[16+l], q[24+l]) of blocks 4c .. 4c+3] then [row r][4 x f16 d]   1024 + 64 B
 //   Q4_0 chunk = 8 blocks    : [lane (r, l)][A_0..A_7 | B_0..B_7]  (A_k = quant byte l of block 8c+k: nibbles of elements
 //                              l and 16+l; B_k = byte 8+l: elements 8+l and 24+l)  then [row r][8 x f16 d]   1024 + 128 B
 // The activation is staged in LDS transposed the same way (F16: xT[c][l][k]; Q4_0: xT[block][l][4]) so a lane reads its
@@ -28,14 +33,16 @@
 namespace gl3 {
 
 __host__ __device__ inline size_t vl_group_bytes(int wt, int k) {       // bytes of one 8-row group
-    return wt == WT_F16 ? (size_t)(k / 64) * 1024 : (size_t)(k / 256) * 1152;
+    return wt == WT_F16 ? (size_t)(k / 64) * 1024 : wt == WT_Q4_0 ? (size_t)(k / 256) * 1152 : (size_t)(k / 128) * 1088;
 }
+__host__ __device__ inline int vl_chunk_elems(int wt) { return wt == WT_F16 ? 64 : wt == WT_Q4_0 ? 256 : 128; }
+__host__ __device__ inline int vl_chunk_bytes(int wt) { return wt == WT_F16 ? 1024 : wt == WT_Q4_0 ? 1152 : 1088; }
 
 // GGUF row-major -> VL.  One thread per destination lane slot (row, chunk, l).
 template <int WT>
 static __global__ __launch_bounds__(256) void repack_vl_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int k,
                                                                int dst_row0) {
-    const int nch = WT == WT_F16 ? k / 64 : k / 256;
+    const int nch = k / vl_chunk_elems(WT);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)rows * nch * 8) return;
     const int l = (int)(i & 7), c = (int)((i >> 3) % nch), r = (int)((i >> 3) / nch);
@@ -46,6 +53,14 @@ static __global__ __launch_bounds__(256) void repack_vl_kernel(const uint8_t* __
         uint16_t* d = reinterpret_cast<uint16_t*>(gb + (size_t)c * 1024 + (rr * 8 + l) * 16);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) d[kk] = s[8 * kk];
+    } else if (WT == WT_Q8_0) {
+        const uint8_t* s = src + ((size_t)r * (k / 32) + 4 * c) * 34;        // 4 consecutive blocks of this row
+        uint8_t* d = gb + (size_t)c * 1088 + (rr * 8 + l) * 16;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[4 * kk + q] = s[kk * 34 + 2 + 8 * q + l];
+        if (l < 4) reinterpret_cast<uint16_t*>(gb + (size_t)c * 1088 + 1024 + rr * 8)[l] = *reinterpret_cast<const uint16_t*>(s + l * 34);
     } else {
         const uint8_t* s = src + ((size_t)r * (k / 32) + 8 * c) * 18;        // 8 consecutive blocks of this row
         uint8_t* d = gb + (size_t)c * 1152 + (rr * 8 + l) * 16;
@@ -66,6 +81,11 @@ static __global__ __launch_bounds__(256) void embed_vl_kernel(const uint8_t* __r
         if (WT == WT_F16) {
             const int c = i >> 6, e = i & 63, l = e & 7, kk = e >> 3;
             x[i] = h2f(reinterpret_cast<const uint16_t*>(gb + (size_t)c * 1024 + (rr * 8 + l) * 16)[kk]) * emb_scale;
+        } else if (WT == WT_Q8_0) {                      // getFloat: quant * scale (Q8_0FloatTensor.java:55-63)
+            const int b = i >> 5, j = i & 31, c = b >> 2, kk = b & 3, l = j & 7;
+            const uint8_t* cb = gb + (size_t)c * 1088;
+            const int q = (int8_t)cb[(rr * 8 + l) * 16 + 4 * kk + (j >> 3)];
+            x[i] = ((float)q * h2f(reinterpret_cast<const uint16_t*>(cb + 1024 + rr * 8)[kk])) * emb_scale;
         } else {
             const int b = i >> 5, j = i & 31, c = b >> 3, kk = b & 7, l = j & 7;
             const uint8_t* cb = gb + (size_t)c * 1152;
@@ -100,15 +120,15 @@ __device__ __forceinline__ float cvt_hi(uint32_t w) { return (float)__builtin_bi
 // Q4_0 is VALU-heavy (~5 instructions per weight: nibble extract, -8, convert, multiply, 3/4 add, 1/4 fma).  Two wavefronts
 // per SIMD (<= 256 VGPRs); capping the registers at 128 for four made the compiler spill 119 VGPRs and was 30 % slower.
 template <int WT, int EPI>
-static __global__ __launch_bounds__(64 * VL_WAVES, WT == WT_Q4_0 ? 2 : 1) void matvec_vl_kernel(const VlArgs a) {
+static __global__ __launch_bounds__(64 * VL_WAVES, WT == WT_F16 ? 1 : 2) void matvec_vl_kernel(const VlArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xT[];
     constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1;
     // Chunks in flight per wavefront (4 or 8 VGPRs each; 16 KB / 9 KB of the weight stream per wavefront and matrix)
-    constexpr int D = WT == WT_F16 ? (NM == 1 ? 16 : 8) : (NM == 1 ? 8 : 4);
+    constexpr int D = WT == WT_F16 ? (NM == 1 ? 16 : 8) : WT == WT_Q8_0 ? (NM == 1 ? 12 : 6) : (NM == 1 ? 8 : 4);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l = lane & 7, rr = lane >> 3;
     const int g = blockIdx.x * VL_WAVES + wave;              // 8-row group of this wavefront
     const int ngroups = (a.rows + 7) >> 3;
-    const int nch = WT == WT_F16 ? a.k / 64 : a.k / 256;
+    const int nch = a.k / vl_chunk_elems(WT);
     const size_t gbytes = vl_group_bytes(WT, a.k);
     const bool live = g < ngroups;
     const uint8_t* wb[NM];
@@ -118,21 +138,23 @@ static __global__ __launch_bounds__(64 * VL_WAVES, WT == WT_Q4_0 ? 2 : 1) void m
     // ---- weights first: D chunks per matrix are in flight before the activation is even staged
     int4 wq[NM][D];
     int4 wsc[NM][WT == WT_Q4_0 ? D : 1];
+    uint2 wsc8[NM][WT == WT_Q8_0 ? D : 1];              // Q8_0: the row's 4 block scales of a chunk
     auto issue = [&](int u, int c) {
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
-            const uint8_t* cb = wb[m] + (size_t)c * (WT == WT_F16 ? 1024 : 1152);
+            const uint8_t* cb = wb[m] + (size_t)c * vl_chunk_bytes(WT);
             wq[m][u] = ld16<true>(cb + 16 * lane);
             if (WT == WT_Q4_0) wsc[m][u] = ld16<true>(cb + 1024 + 16 * rr);
+            if (WT == WT_Q8_0) wsc8[m][u] = *reinterpret_cast<const uint2*>(cb + 1024 + 8 * rr);
         }
     };
 #pragma unroll
     for (int u = 0; u < D; ++u) {
 #pragma unroll
-        for (int m = 0; m < NM; ++m) { wq[m][u] = make_int4(0, 0, 0, 0); if (WT == WT_Q4_0) wsc[m][u] = make_int4(0, 0, 0, 0); }
+        for (int m = 0; m < NM; ++m) { wq[m][u] = make_int4(0, 0, 0, 0); if (WT == WT_Q4_0) wsc[m][u] = make_int4(0, 0, 0, 0); if (WT == WT_Q8_0) wsc8[m][u] = make_uint2(0u, 0u); }
         if (live && u < nch) issue(u, u);
     }
-    // ---- activation -> LDS, transposed: F16 xT[64 c + 8 l + k] = x[64 c + 8 k + l]; Q4_0 xT[32 b + 4 l + q] = x[32 b + 8 q + l]
+    // ---- activation -> LDS, transposed: F16 xT[64 c + 8 l + k] = x[64 c + 8 k + l]; Q4_0 / Q8_0 xT[32 b + 4 l + q] = x[32 b + 8 q + l]
     // 16 float4 per thread are requested at once (one L2 round trip per 32 KB of activation), then scattered
     {
         constexpr int XB = 16, NT = 64 * VL_WAVES;
@@ -182,6 +204,22 @@ static __global__ __launch_bounds__(64 * VL_WAVES, WT == WT_Q4_0 ? 2 : 1) void m
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk)       // thizVector.fma(thatVector, val); the conversion flushes subnormals (MODE)
                     acc[m] = __builtin_fmaf((kk & 1) ? cvt_hi(wd[kk >> 1]) : cvt_lo(wd[kk >> 1]), xs[kk], acc[m]);
+            }
+        } else if (WT == WT_Q8_0) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const uint32_t qw[4] = {(uint32_t)wq[m][u].x, (uint32_t)wq[m][u].y, (uint32_t)wq[m][u].z, (uint32_t)wq[m][u].w};   // one block each
+                const uint32_t sw[2] = {wsc8[m][u].x, wsc8[m][u].y};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float q0 = (float)(int8_t)(qw[kk] & 0xFFu), q1 = (float)(int8_t)((qw[kk] >> 8) & 0xFFu);      // castShape(F_SPECIES, i): exact
+                    const float q2 = (float)(int8_t)((qw[kk] >> 16) & 0xFFu), q3 = (float)(int8_t)(qw[kk] >> 24);
+                    const float ws = h2f((uint16_t)((kk & 1) ? (sw[kk >> 1] >> 16) : (sw[kk >> 1] & 0xFFFFu)));          // Float.float16ToFloat: IEEE, subnormals kept
+                    const float4 xk = *reinterpret_cast<const float4*>(xT + 32 * (4 * cq + kk) + 4 * l);   // x[j+l], x[j+8+l], x[j+16+l], x[j+24+l]
+                    const float s0 = xk.x * q0, s1 = xk.y * q1, s2 = xk.z * q2, s3 = xk.w * q3;
+                    const float sm = ((s0 + s1) + s2) + s3;                     // sum0.add(sum1).add(sum2).add(sum3)
+                    acc[m] = __builtin_fmaf(sm, ws, acc[m]);                    // .fma(wScale, val)
+                }
             }
         } else {
 #pragma unroll

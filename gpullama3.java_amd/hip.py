@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("GL3_LIB") or os.path.join(_DIR, "libgpullama_hip.so") 
 GL3_OK = 0
 ERR_NAMES = {0: "GL3_OK", -1: "GL3_E_ARG", -2: "GL3_E_UNSUPPORTED", -3: "GL3_E_OOM", -4: "GL3_E_HIP", -5: "GL3_E_RCCL",
              -6: "GL3_E_STATE"}
-FLAG_NO_GRAPH, FLAG_LAYER_TAPS, FLAG_FORCE_RCCL, FLAG_SCALAR_DOT = 1, 2, 4, 8
+FLAG_NO_GRAPH, FLAG_LAYER_TAPS, FLAG_FORCE_RCCL, FLAG_SCALAR_DOT, FLAG_F32_ACTIVATION = 1, 2, 4, 8, 16
 K_NAMES = ["matvec_qkv", "matvec_wo", "matvec_gateup", "matvec_down", "matvec_logits", "attention", "other", "collective"]
 
 T_IDS = {"token_embd.weight": 0, "output_norm.weight": 1, "output.weight": 2, "attn_norm.weight": 3,

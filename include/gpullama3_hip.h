@@ -100,6 +100,8 @@ enum {
                                      FloatTensor.scalarDot) instead of its default Vector-API order with a 256-bit species
                                      (FP16FloatTensor.vectorDot / Q4_0FloatTensor.vectorDot: 8 fused accumulator lanes).  Q8_0 is
                                      not affected: dotQ8Activation is scalar in both modes. */
+#define GL3_FLAG_F32_ACTIVATION 0x10u /* Q8_0 matrices: -Dllama.quantizeActivation=false — f32 activation x dequantised weights in the
+                                       * Vector-API order of Q8_0FloatTensor.vectorDot (256-bit species) instead of the int8 activation */
 
 /* Configuration (J/model/Configuration.java via LlamaModelLoader.java:47-63 / Qwen3ModelLoader.java:48-74)
  * plus the plan-selection knobs the reference reads from system properties

@@ -60,7 +60,8 @@ typedef struct { const void* p; int type; } orc_tensor;
 
 typedef struct {
     orc_config c;
-    int vector_bits;                      /* 0: scalar dots (-Dllama.VectorBitSize=0); 256: the Vector-API dots of F16 / Q4_0 */
+    int vector_bits;                      /* 0: scalar dots (-Dllama.VectorBitSize=0); 256: the Vector-API dots of F16 / Q4_0 (and Q8_0 with f32 activation) */
+    int f32_activation;                   /* 1: -Dllama.quantizeActivation=false — Q8_0 matrices take the f32 activation (vectorDot / scalarDot) */
     orc_tensor global[3];
     orc_tensor* layer[ORC_T_COUNT];       /* per-layer tensors, [id][layer] */
     const float *rope_cr, *rope_ci;       /* freq_cis_real / freq_cis_imag, [ctx * head_size/2] */
@@ -229,6 +230,34 @@ static float dot_q4_0_v256(const uint8_t* wrow, const float* x, int n) {
     return result;
 }
 
+/* Q8_0FloatTensor.vectorDot  J/tensor/standard/Q8_0FloatTensor.java:125-175, the 256-bit branch :145-152 (taken by dot() when
+ * llama.quantizeActivation=false and the Vector API is on):  val = sum0.add(sum1).add(sum2).add(sum3).fma(wScale, val),
+ * sum_i = x-vector i of the block * (int8 quants 8i .. 8i+7 cast to float); scalar tail for n % 32 (never taken: K % 32 == 0) */
+static float dot_q8_0_v256(const uint8_t* wrow, const float* x, int n) {
+    float val[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int ub = n / 32 * 32;
+    for (int j = 0; j < ub; j += 32) {
+        const uint8_t* blk = wrow + (j / 32) * 34;
+        float ws = orc_f16_to_f32(rd16(blk));
+        const int8_t* q = (const int8_t*)(blk + 2);
+        for (int l = 0; l < 8; l++) {
+            float sum0 = x[j + l] * (float)q[l], sum1 = x[j + 8 + l] * (float)q[8 + l];
+            float sum2 = x[j + 16 + l] * (float)q[16 + l], sum3 = x[j + 24 + l] * (float)q[24 + l];
+            float s = ((sum0 + sum1) + sum2) + sum3;
+            val[l] = fmaf(s, ws, val[l]);
+        }
+    }
+    float result = 0.f;
+    result += reduce_lanes8(val);
+    if (ub < n) {
+        orc_tensor t = {wrow, ORC_Q8_0};
+        float tl = 0.f;
+        for (int j = ub; j < n; j++) tl += t_get(&t, j) * x[j];
+        result += tl;
+    }
+    return result;
+}
+
 /* FloatTensor.matmul  J/tensor/standard/FloatTensor.java:98-100 (rows in parallel) */
 static void matmul(orc_ctx* o, const orc_tensor* w, const float* x, float* out, int d0, int d1) {
     if (o->vector_bits == 256 && (w->type == ORC_F16 || w->type == ORC_Q4_0)) {
@@ -239,7 +268,14 @@ static void matmul(orc_ctx* o, const orc_tensor* w, const float* x, float* out, 
             out[i] = w->type == ORC_F16 ? dot_f16_v256(base + (size_t)i * rb, x, d1) : dot_q4_0_v256(base + (size_t)i * rb, x, d1);
         return;
     }
-    if (w->type == ORC_Q8_0) {
+    if (w->type == ORC_Q8_0 && o->f32_activation && o->vector_bits == 256) {     /* Q8_0FloatTensor.dot :73-83 with QUANTIZE_ACTIVATION = false */
+        const uint8_t* base = (const uint8_t*)w->p;
+        size_t rb = (size_t)(d1 / 32) * 34;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < d0; i++) out[i] = dot_q8_0_v256(base + (size_t)i * rb, x, d1);
+        return;
+    }
+    if (w->type == ORC_Q8_0 && !o->f32_activation) {
         quantize_act(x, d1, o->aq, o->ascale);
         const uint8_t* base = (const uint8_t*)w->p;
         size_t rb = (size_t)(d1 / 32) * 34;
@@ -540,8 +576,11 @@ ORC_API int orc_set_vector_bits(orc_ctx* o, int bits) {
     return 0;
 }
 ORC_API float orc_dot_v256(const void* wrow, int type, const float* x, int n) {
-    return type == ORC_F16 ? dot_f16_v256((const uint8_t*)wrow, x, n) : dot_q4_0_v256((const uint8_t*)wrow, x, n);
+    return type == ORC_F16 ? dot_f16_v256((const uint8_t*)wrow, x, n) : type == ORC_Q8_0 ? dot_q8_0_v256((const uint8_t*)wrow, x, n)
+                                                                                        : dot_q4_0_v256((const uint8_t*)wrow, x, n);
 }
+/* 1 = -Dllama.quantizeActivation=false: Q8_0 matrices multiply the f32 activation (vector_bits 256: vectorDot, 0: scalarDot) */
+ORC_API int orc_set_f32_activation(orc_ctx* o, int on) { o->f32_activation = on ? 1 : 0; return 0; }
 ORC_API int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

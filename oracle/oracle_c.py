@@ -67,6 +67,7 @@ def lib():
         L.orc_softmax.argtypes = [C.c_void_p, C.c_int]
         L.orc_sample.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.orc_set_vector_bits.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_f32_activation.argtypes = [C.c_void_p, C.c_int]
         L.orc_dot_v256.restype = C.c_float
         L.orc_dot_v256.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         _lib = L
@@ -80,9 +81,11 @@ def _p(a: np.ndarray):
 class COracle:
     """Same call surface as the HIP plan: forward(token, pos) -> logits, prefill(tokens, start)."""
 
-    def __init__(self, model, vector_bits: int = 0):
+    def __init__(self, model, vector_bits: int = 0, f32_activation: bool = False):
         """model: gpullama3.java_amd synth.SynthModel-like (cfg, tensors name->(raw, type, ...), rope).
-        vector_bits: 0 = scalar dots everywhere (-Dllama.VectorBitSize=0), 256 = the Vector-API dots for F16 / Q4_0 matrices."""
+        vector_bits: 0 = scalar dots everywhere (-Dllama.VectorBitSize=0), 256 = the Vector-API dots for F16 / Q4_0 matrices.
+        f32_activation: -Dllama.quantizeActivation=false — Q8_0 matrices take the f32 activation (with vector_bits 256:
+        Q8_0FloatTensor.vectorDot)."""
         L = lib()
         c = model.cfg
         self.cfg = c
@@ -91,6 +94,7 @@ class COracle:
                        getattr(c, "logit_scale", 1.0))
         self._h = L.orc_create(C.byref(oc))
         assert L.orc_set_vector_bits(self._h, vector_bits) == 0
+        L.orc_set_f32_activation(self._h, 1 if f32_activation else 0)
         tensors = model.oracle_tensors() if hasattr(model, "oracle_tensors") else model.tensors      # phi3: fused tensors as row views
         self._keep = [model, tensors]
         for name, t in tensors.items():

@@ -132,6 +132,19 @@ def matmul_v256(w_raw, ggml_type: int, x: np.ndarray, d0: int, d1: int) -> np.nd
             sum3 = xb[b, 3][None, :] * hi[:, b, 8:16]
             sm = ((sum0 + sum1) + sum2) + sum3
             val = fma32(sm, ws[:, b][:, None], val)
+    elif ggml_type == GGML_Q8_0:                          # Q8_0FloatTensor.vectorDot, 256-bit branch (Q8_0FloatTensor.java:125-175)
+        nb = d1 // 32
+        blk = raw[: d0 * nb * 34].reshape(d0, nb, 34)
+        ws = blk[:, :, :2].copy().view(np.float16).astype(F32).reshape(d0, nb)
+        q = blk[:, :, 2:].view(np.int8).astype(F32)      # [d0, nb, 32]
+        xb = x.reshape(nb, 4, 8)
+        for b in range(nb):
+            sum0 = xb[b, 0][None, :] * q[:, b, 0:8]
+            sum1 = xb[b, 1][None, :] * q[:, b, 8:16]
+            sum2 = xb[b, 2][None, :] * q[:, b, 16:24]
+            sum3 = xb[b, 3][None, :] * q[:, b, 24:32]
+            sm = ((sum0 + sum1) + sum2) + sum3
+            val = fma32(sm, ws[:, b][:, None], val)
     else:
         raise ValueError(ggml_type)
     return seq_sum(val, axis=1)
@@ -166,10 +179,12 @@ def rope_table(ctx: int, head_size: int, theta: float):
 class NpOracle:
     """Holds config, raw GGUF-layout tensors and the State arrays (LlamaState.java:28-81)."""
 
-    def __init__(self, cfg: dict, tensors: dict, rope, vector_bits: int = 0):
-        """vector_bits: 0 = scalar dots (-Dllama.VectorBitSize=0); 256 = Vector-API dots for F16 / Q4_0 matrices."""
+    def __init__(self, cfg: dict, tensors: dict, rope, vector_bits: int = 0, f32_activation: bool = False):
+        """vector_bits: 0 = scalar dots (-Dllama.VectorBitSize=0); 256 = Vector-API dots for F16 / Q4_0 matrices.
+        f32_activation: -Dllama.quantizeActivation=false (Q8_0 matrices x f32 activation; needs vector_bits 256 here)."""
         assert vector_bits in (0, 256)
         self.vector_bits = vector_bits
+        self.f32_activation = f32_activation
         self.c = cfg
         self.t = tensors          # name -> (raw uint8 ndarray, ggml_type)
         self.cr, self.ci = rope
@@ -181,7 +196,7 @@ class NpOracle:
 
     def _mm(self, name, x, d0, d1):
         raw, ty = self.t[name]
-        if self.vector_bits == 256 and ty in (GGML_F16, GGML_Q4_0):
+        if self.vector_bits == 256 and (ty in (GGML_F16, GGML_Q4_0) or (ty == GGML_Q8_0 and self.f32_activation)):
             return matmul_v256(raw, ty, x, d0, d1)
         return matmul(raw, ty, x, d0, d1)
 

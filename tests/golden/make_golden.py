@@ -28,12 +28,14 @@ CASES = [  # (fixture, config, ggml type, seed, prompt tokens, greedy steps, vec
     ("tiny_phi3_q8_0", "tiny-phi3", 8, 23, 5, 12, 0),                # forwardJavaPhi3: fused attn_qkv / gate|up, NeoX RoPE
     ("tiny_llama_f16_v256", "tiny-llama", 1, 7, 4, 8, 256),          # Vector-API dots, 256-bit species (the reference's default order)
     ("tiny_llama_tied_q4_0_v256", "tiny-llama-tied", 2, 11, 4, 8, 256),
+    # Q8_0 weights with vector bits 256 = -Dllama.quantizeActivation=false: Q8_0FloatTensor.vectorDot on the f32 activation
+    ("tiny_llama_q8_0_f32act_v256", "tiny-llama", 8, 7, 4, 8, 256),
 ]
 
 
 def run_case(pkg, cfg_name, wtype, seed, n_prompt, n_greedy, vbits=0):
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg_name], wtype=wtype, seed=seed)
-    o = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope, vector_bits=vbits)
+    o = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope, vector_bits=vbits, f32_activation=(wtype == 8 and vbits == 256))
     prompt = pkg.javarand.bench_tokens(m.cfg.vocab, n_prompt)
     logits, lx = [], []
     tok_stream = list(prompt)

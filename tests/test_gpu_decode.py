@@ -31,14 +31,16 @@ def planmod():
 @pytest.mark.parametrize("fx,cfg,seed,wtype,scalar", [("tiny_llama_q8_0", "tiny-llama", 7, 8, False), ("tiny_qwen3_q8_0", "tiny-qwen3", 5, 8, False),
                                                       ("tiny_llama_f16", "tiny-llama", 7, 1, True), ("tiny_llama_tied_q4_0", "tiny-llama-tied", 11, 2, True),
                                                       ("tiny_qwen2_q8_0", "tiny-qwen2", 13, 8, False), ("tiny_granite_q8_0", "tiny-granite", 19, 8, False), ("tiny_phi3_q8_0", "tiny-phi3", 23, 8, False),
-                                                      ("tiny_llama_f16_v256", "tiny-llama", 7, 1, False), ("tiny_llama_tied_q4_0_v256", "tiny-llama-tied", 11, 2, False)])
+                                                      ("tiny_llama_f16_v256", "tiny-llama", 7, 1, False), ("tiny_llama_tied_q4_0_v256", "tiny-llama-tied", 11, 2, False),
+                                                      ("tiny_llama_q8_0_f32act_v256", "tiny-llama", 7, 8, "f32act")])
 def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed, wtype, scalar):
     """F16 / Q4_0: the *_v256 fixtures are the reference's default Vector-API dot order (the plan's default), the others its
     scalar order (GL3_FLAG_SCALAR_DOT)."""
     plan_mod, hip = planmod
     g = np.load(os.path.join(GOLD, fx + ".npz"))
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=seed)
-    plan = plan_mod.HipMasterPlan(m, flags=hip.FLAG_LAYER_TAPS | (hip.FLAG_SCALAR_DOT if scalar else 0))
+    mode = hip.FLAG_F32_ACTIVATION if scalar == "f32act" else hip.FLAG_SCALAR_DOT if scalar else 0      # f32act: -Dllama.quantizeActivation=false
+    plan = plan_mod.HipMasterPlan(m, flags=hip.FLAG_LAYER_TAPS | mode)
     toks = g["tokens"]
     n_prompt = len(g["prompt"])
     for pos in range(g["logits"].shape[0]):
@@ -89,6 +91,32 @@ def test_f16_and_q4_0_decode_match_c_oracle_live(pkg, orc, planmod, cfg, wtype, 
     plan.prefill(toks[:6], 0)
     o.prefill(toks[:6], 0)
     for pos in range(6, 14):
+        ref, lx = o.forward(toks[pos], pos, layer_x=True)
+        got = plan.tornadoVMForwardDecode(toks[pos], pos)
+        assert np.array_equal(got, ref), (pos, rel(got, ref))
+        for l in range(m.cfg.n_layers):
+            assert np.array_equal(plan.layer_x(l), lx[l])
+        assert plan.forward_decode_argmax(toks[pos], pos) == orc.argmax(ref)
+    for l in range(m.cfg.n_layers):
+        k, v = plan.kv(l, 3)
+        ko, vo = o.kv(l, 3)
+        assert np.array_equal(k, ko) and np.array_equal(v, vo)
+    plan.freeTornadoExecutionPlan()
+
+
+@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "tiny-llama-tied", "mid-qwen2", "mid-granite", "mid-phi3"])
+def test_q8_0_with_f32_activation_matches_c_oracle_live(pkg, orc, planmod, cfg):
+    """SURVEY 8 a4': Q8_0 matrices with -Dllama.quantizeActivation=false (GL3_FLAG_F32_ACTIVATION) = Q8_0FloatTensor.vectorDot on
+    the f32 activation, 256-bit species (matvec_vl_kernel<WT_Q8_0>).  Logits, per-layer x, device argmax and the KV cache after a
+    token-by-token prefill are bit-identical to the oracle in the same mode."""
+    plan_mod, hip = planmod
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=8, seed=29)
+    plan = plan_mod.HipMasterPlan(m, prefill_batch_size=16, flags=hip.FLAG_LAYER_TAPS | hip.FLAG_F32_ACTIVATION)
+    o = orc.COracle(m, vector_bits=256, f32_activation=True)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 12)
+    plan.prefill(toks[:5], 0)
+    o.prefill(toks[:5], 0)
+    for pos in range(5, 12):
         ref, lx = o.forward(toks[pos], pos, layer_x=True)
         got = plan.tornadoVMForwardDecode(toks[pos], pos)
         assert np.array_equal(got, ref), (pos, rel(got, ref))

@@ -12,14 +12,16 @@ CASES = [("tiny_llama_q8_0", "tiny-llama", 8, 7, 0), ("tiny_llama_f16", "tiny-ll
          ("tiny_llama_tied_q4_0", "tiny-llama-tied", 2, 11, 0), ("tiny_qwen3_q8_0", "tiny-qwen3", 8, 5, 0),
          ("tiny_qwen2_q8_0", "tiny-qwen2", 8, 13, 0), ("tiny_granite_q8_0", "tiny-granite", 8, 19, 0), ("tiny_phi3_q8_0", "tiny-phi3", 8, 23, 0),
          # Vector-API dot order (256-bit species) for F16 / Q4_0 matrices: FP16FloatTensor.vectorDot / Q4_0FloatTensor.vectorDot
-         ("tiny_llama_f16_v256", "tiny-llama", 1, 7, 256), ("tiny_llama_tied_q4_0_v256", "tiny-llama-tied", 2, 11, 256)]
+         ("tiny_llama_f16_v256", "tiny-llama", 1, 7, 256), ("tiny_llama_tied_q4_0_v256", "tiny-llama-tied", 2, 11, 256),
+         # Q8_0 + 256 = -Dllama.quantizeActivation=false: Q8_0FloatTensor.vectorDot on the f32 activation (SURVEY 8 a4')
+         ("tiny_llama_q8_0_f32act_v256", "tiny-llama", 8, 7, 256)]
 
 
 @pytest.mark.parametrize("fx,cfg,wt,seed,vbits", CASES)
 def test_c_oracle_matches_golden_bitwise(pkg, orc, fx, cfg, wt, seed, vbits):
     g = np.load(os.path.join(GOLD, fx + ".npz"))
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wt, seed=seed)
-    o = orc.COracle(m, vector_bits=vbits)
+    o = orc.COracle(m, vector_bits=vbits, f32_activation=(wt == 8 and vbits == 256))
     toks = g["tokens"]
     n_prompt = len(g["prompt"])
     assert toks[:n_prompt].tolist() == pkg.javarand.bench_tokens(m.cfg.vocab, n_prompt)
@@ -58,6 +60,21 @@ def test_vector_api_dot_order_numpy_and_c_agree_and_stay_close_to_scalar(pkg, or
             assert not np.array_equal(a, c)                                    # a different rounding order, visibly
             assert float(np.max(np.abs(a - c)) / np.max(np.abs(c))) < tol
             assert orc.argmax(a) == orc.argmax(c)
+
+
+def test_q8_0_f32_activation_vector_dot_numpy_and_c_agree(pkg, orc):
+    """SURVEY 8 a4': Q8_0FloatTensor.vectorDot (llama.quantizeActivation=false) in both restatements on a fresh seed, and against
+    the default int8-activation path: different arithmetic (no activation rounding), so logits differ at the 1e-2 level while the
+    greedy ids of these models agree."""
+    for cfg in ("tiny-llama", "tiny-qwen3", "tiny-granite"):
+        m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=8, seed=2468)
+        cv, cq = orc.COracle(m, vector_bits=256, f32_activation=True), orc.COracle(m)
+        nv = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope, vector_bits=256, f32_activation=True)
+        for pos, t in enumerate(pkg.javarand.bench_tokens(m.cfg.vocab, 4, seed=9)):
+            a, b, c = cv.forward(t, pos), nv.forward(t, pos), cq.forward(t, pos)
+            assert np.array_equal(a, b), (cfg, pos)
+            assert not np.array_equal(a, c)
+            assert float(np.max(np.abs(a - c)) / np.max(np.abs(c))) < 5e-2
 
 
 def test_fma32_emulation_is_correctly_rounded():
