@@ -443,14 +443,16 @@ __device__ __forceinline__ void rope_head(float* v, int hs, const float* cr, con
     }
 }
 
-// rmsnorm(v, v, w, hs) by ONE thread (strict order), InferenceCore.rmsnorm applied per head (:594-600)
-__device__ __forceinline__ void head_rmsnorm_1t(float* v, const float* w, int hs, float eps) {
-    float ss = 0.f;
-    for (int i = 0; i < hs; ++i) ss = ss + v[i] * v[i];
+// rmsnorm(v, v, w, hs) of one head held in LDS (InferenceCore.rmsnorm applied per head, :594-600) by one WAVEFRONT: every lane runs
+// the strict sum of squares (uniform addresses: LDS broadcast reads, pipelined float4s), then the lanes normalise their elements in
+// parallel.  (One thread per head did both loops alone: 2 x hs dependent LDS / global round trips, ~4 k cycles on the kernel's
+// critical path for head_size 128.)  v must be 16-byte aligned; the wavefront's reads for the sum precede its writes (LDS is in order).
+__device__ __forceinline__ void head_rmsnorm_wave(float* v, const float* __restrict__ w, int hs, float eps, int lane) {
+    float ss = seq_sum_lds<true>(v, hs);
     ss /= (float)hs;
     ss += eps;
     ss = (float)(1.0 / sqrt((double)ss));
-    for (int i = 0; i < hs; ++i) v[i] = w[i] * (ss * v[i]);
+    for (int i = lane; i < hs; i += 64) v[i] = w[i] * (ss * v[i]);
 }
 
 constexpr int ATT_TT = 64;   // timesteps per score workgroup
@@ -515,8 +517,9 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
     }
     __syncthreads();
     if (a.arch == 1) {
-        if (t < kvmul) head_rmsnorm_1t(q_s + t * hs, a.qnorm, hs, a.eps);
-        if (owns_pos && t == kvmul) head_rmsnorm_1t(krow, a.knorm, hs, a.eps);
+        const int nvec = kvmul + (owns_pos ? 1 : 0);              // the group's query heads (+ this position's key): one wavefront each
+        for (int vec = t >> 6; vec < nvec; vec += nthr >> 6)
+            head_rmsnorm_wave(vec < kvmul ? q_s + vec * hs : krow, vec < kvmul ? a.qnorm : a.knorm, hs, a.eps, t & 63);
         __syncthreads();
     }
     for (int h = 0; h < kvmul; ++h) rope_head(q_s + h * hs, hs, cr_s, ci_s, a.arch, t, nthr);
@@ -633,9 +636,9 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
     }
     __syncthreads();
     ATT_STAMP(1);
-    if (a.arch == 1) {                               // qwen3: per-head RMSNorm of q and k (one thread each, strict order)
-        if ((t & 31) == 0 && (t >> 5) < G) head_rmsnorm_1t(q_s + (t >> 5) * hs, a.qnorm, hs, a.eps);
-        if (t == 255) head_rmsnorm_1t(krow, a.knorm, hs, a.eps);
+    if (a.arch == 1) {                               // qwen3: per-head RMSNorm of q and k (strict-order sum, one wavefront per head)
+        for (int vec = wave; vec <= G; vec += 4)                   // G query heads + the key: one wavefront each
+            head_rmsnorm_wave(vec < G ? q_s + vec * hs : krow, vec < G ? a.qnorm : a.knorm, hs, a.eps, lane);
         __syncthreads();
     }
     for (int g = 0; g < G; ++g) rope_head(q_s + g * hs, hs, cr_s, ci_s, a.arch, t, 256);

@@ -416,7 +416,7 @@ struct RopeArgs {
 };
 
 __global__ __launch_bounds__(64) void pf_rope_kv_kernel(const RopeArgs a) {
-    __shared__ float v[256];
+    __shared__ __attribute__((aligned(16))) float v[256];
     const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, hs = a.hs;
     const int pos = a.pos[b];
     const size_t soff = (size_t)a.seq[b] * a.seq_stride;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64) void pf_rope_kv_kernel(const RopeArgs a) {
     for (int i = t; i < hs; i += 64) v[i] = bias ? src[i] + bias[hk * hs + i] : src[i];
     __syncthreads();
     if (a.arch == 1) {
-        if (t == 0) head_rmsnorm_1t(v, is_k ? a.knorm : a.qnorm, hs, a.eps);
+        head_rmsnorm_wave(v, is_k ? a.knorm : a.qnorm, hs, a.eps, t);      // the workgroup is one wavefront
         __syncthreads();
     }
     rope_head(v, hs, a.cr + (size_t)pos * (hs >> 1), a.ci + (size_t)pos * (hs >> 1), a.arch, t, 64);
