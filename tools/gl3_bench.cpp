@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
     std::string path;
     int n_prompt = 512, n_gen = 128, batch = 512, reps = 5;
     bool print_ids = false;
+    uint32_t flags = 0;              // the reference's arithmetic switches: --scalar-dot, --f32-activation
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() { return i + 1 < argc ? argv[++i] : (char*)"0"; };
@@ -52,7 +53,9 @@ int main(int argc, char** argv) {
         else if (a == "-b") batch = atoi(val());
         else if (a == "-r") reps = atoi(val());
         else if (a == "--ids") print_ids = true;
-        else { fprintf(stderr, "usage: gl3_bench -m model.gguf [-p N] [-n N] [-b N] [-r N] [--ids]\n"); return 2; }
+        else if (a == "--scalar-dot") flags |= GL3_FLAG_SCALAR_DOT;          // -Dllama.VectorBitSize=0 (F16 / Q4_0)
+        else if (a == "--f32-activation") flags |= GL3_FLAG_F32_ACTIVATION;  // -Dllama.quantizeActivation=false (Q8_0)
+        else { fprintf(stderr, "usage: gl3_bench -m model.gguf [-p N] [-n N] [-b N] [-r N] [--ids] [--scalar-dot] [--f32-activation]\n"); return 2; }
     }
     if (path.empty()) { fprintf(stderr, "gl3_bench: -m model.gguf is required\n"); return 2; }
     gl3_ctx* ctx = nullptr;
@@ -61,6 +64,7 @@ int main(int argc, char** argv) {
     opts.ctx = (n_prompt > n_gen ? n_prompt : n_gen) + n_gen + 8;       // LlamaBench: max(depth + tokens) + 8
     opts.max_batch = batch;
     opts.tp_size = 1;
+    opts.flags = flags;
     const double t_load = now_s();
     CK(gl3_load_gguf(path.c_str(), &opts, &ctx));
     double plan_ms = 0, copy_ms = 0;
