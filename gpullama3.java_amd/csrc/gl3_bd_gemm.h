@@ -19,7 +19,7 @@ struct GemmArgs {
     const uint8_t* w; const uint8_t* w2;  // Q8T matrices (w2: up projection for the SwiGLU epilogue)
     int rows, ng, nb;                     // valid rows, tile groups per strip, real blocks per row (k/32)
     const uint8_t* XQ; const float* XS; int maxk;
-    int tslots;                           // bdw_gemm_kernel: token slots of the XQ2 / XS2 layout (32); 0 = row layout
+    int tslots;                           // bdw_gemm_kernel: token slots of the XQ2 / XS2 layout (32 or 64); 0 = row layout
     int ntt, nrt;                         // token tiles, row tiles (grid = 8 * ceil(ntt * nrt / 8), see the XCD mapping)
     int ntok;
     float* out; int out_stride;           // EPI_STORE / EPI_SWIGLU: out[b*stride + row]; EPI_RESID: out +=
@@ -28,7 +28,7 @@ struct GemmArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// Static-batched decode, wave-owned form (<= 32 tokens).  One wavefront = one workgroup = 16 weight rows (one Q8T strip) x
+// Static-batched decode and small prefill chunks, wave-owned form (<= 64 tokens).  One wavefront = one workgroup = 16 weight rows (one Q8T strip) x
 // 16 tokens x ALL of K, result in registers, accumulated block by block in the reference's order.  No operand staging in LDS,
 // no barriers; grid = strips x token tiles.
 //   * one v_mfma_i32_16x16x32_i8 per (block, token tile).  The Q8T tile stores a block row as two 16-byte halves, so a
@@ -57,23 +57,22 @@ struct GemmArgs {
 // matrix); token tiles of a strip in one workgroup; rings deeper than 8 tiles; non-temporal weight loads (the token tiles
 // re-read the lines from L2); gate and up as separate wavefronts with silu(g) * u in the next quantiser (2432 single-matrix
 // wavefronts fetch the activations twice: 21-22 us vs 18.3 fused).
-// Activation layout (written by pf_norm_quant_kernel when tslots != 0), tslots = 32 token slots:
+// Activation layout (written by pf_norm_quant_kernel when tslots != 0), tslots = 32 or 64 token slots (template parameter TS):
 //   XS2[k / 128][tslots][4] f32 = the 4 block scales of a tile;
 //   XQ2[k / 64][tslots][64] int8 = blocks 2j, 2j + 1 of a token, already in the lanes' operand order: bytes 16g .. 16g + 7 =
 //   k-chunk c(g) of block 2j, bytes 16g + 8 .. 16g + 15 = the same chunk of block 2j + 1, with c(0..3) = k 0-7, 16-23, 8-15,
 //   24-31 (what the swap leaves in k-group g on the weight side) — bdq_offset() in gl3_decode_kernels.h.
-constexpr int BD_TS = 32;
+constexpr int BD_TS = 32, BD_TS_MAX = 64;            // token slots: 32 (<= 32 tokens) or 64 (33 .. 64)
 
 // grid: workgroup id -> (strip, token tile).  The token tiles of a strip stream the same weights, so they sit 8 ids apart: same
 // XCD (= id % 8), i.e. one L2, and dispatched together.
 __host__ __device__ inline int bdw_grid(int strips, int nt) { return ((strips + 7) / 8) * 8 * nt; }
 
-template <int EPI, int DA, int WPE, bool QOUT = false>
+template <int EPI, int DA, int WPE, bool QOUT = false, int TS = BD_TS>
 __global__ __launch_bounds__(QOUT ? 128 : 64, WPE) void bdw_gemm_kernel(const GemmArgs a) {
     static_assert(!QOUT || EPI == EPI_SWIGLU, "the quantising epilogue is the SwiGLU one");
     constexpr int NWV = QOUT ? 2 : 1;                  // QOUT: two wavefronts = the two strips of one 32-row activation block
     constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;
-    constexpr int TS = BD_TS;
     static_assert(DA % 2 == 0, "ring slots are static under the unroll");
     __shared__ __attribute__((aligned(16))) float wsl_all[NWV][4 * NM * 64];   // [tile & 3][matrix][block][row] weight scales
     __shared__ __attribute__((aligned(16))) float xsl_all[NWV][4 * 128];       // [tile & 3][blocks 01 | 23][token][2 blocks][2]: activation scale pairs, a token's float4s 16 B apart (no bank conflicts)

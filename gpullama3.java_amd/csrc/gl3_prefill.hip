@@ -760,13 +760,13 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
         GL3_HIP(hipMalloc((void**)&p->AO, M * ctx->q_dim * 4));
         GL3_HIP(hipMalloc((void**)&p->HB, M * d.hidden * 4));
     }
-    const size_t MQ = M < 64 ? 64 : M;      // the small-batch operand layout (bd_tslots) always spans its 32 / 64 token slots
+    const size_t MQ = M < BD_TS_MAX ? BD_TS_MAX : M;      // the small-batch operand layout (bd_tslots) always spans its 32 / 64 token slots
     GL3_HIP(hipMalloc((void**)&p->XQ, MQ * p->maxk + GL3_TAIL_PAD));
     GL3_HIP(hipMalloc((void**)&p->XS, MQ * (p->maxk / 32) * 4 + GL3_TAIL_PAD));
-    GL3_HIP(hipMalloc((void**)&p->XQb, (size_t)BD_TS * p->maxk + GL3_TAIL_PAD));
-    GL3_HIP(hipMalloc((void**)&p->XSb, (size_t)BD_TS * (p->maxk / 32) * 4 + GL3_TAIL_PAD));
-    GL3_HIP(hipMemsetAsync(p->XQb, 0, (size_t)BD_TS * p->maxk, ctx->stream));
-    GL3_HIP(hipMemsetAsync(p->XSb, 0, (size_t)BD_TS * (p->maxk / 32) * 4, ctx->stream));
+    GL3_HIP(hipMalloc((void**)&p->XQb, (size_t)BD_TS_MAX * p->maxk + GL3_TAIL_PAD));
+    GL3_HIP(hipMalloc((void**)&p->XSb, (size_t)BD_TS_MAX * (p->maxk / 32) * 4 + GL3_TAIL_PAD));
+    GL3_HIP(hipMemsetAsync(p->XQb, 0, (size_t)BD_TS_MAX * p->maxk, ctx->stream));
+    GL3_HIP(hipMemsetAsync(p->XSb, 0, (size_t)BD_TS_MAX * (p->maxk / 32) * 4, ctx->stream));
     GL3_HIP(hipMemsetAsync(p->XQ, 0, MQ * p->maxk, ctx->stream));
     GL3_HIP(hipMemsetAsync(p->XS, 0, MQ * (p->maxk / 32) * 4, ctx->stream));
     GL3_HIP(hipMalloc((void**)&p->QKV, M * (ctx->q_dim + 2 * ctx->kv_dim) * 4));
@@ -799,7 +799,7 @@ void gl3_prefill_free(gl3_ctx* ctx) {
 // (bdw_gemm_kernel), 0 = row layout + the tiled GEMMs.  The quantiser and the GEMM of a step must agree, so both ask here.
 static int bd_tslots(int n) {
     static const bool off = getenv("GL3_BD_GEMM") && atoi(getenv("GL3_BD_GEMM")) == 0;      // A/B switch: tiled GEMMs for small batches too
-    return (!off && n <= 32) ? BD_TS : 0;
+    return off ? 0 : n <= BD_TS ? BD_TS : n <= BD_TS_MAX ? BD_TS_MAX : 0;
 }
 
 template <int EPI>
@@ -813,14 +813,19 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     a.XQo = p->XQb; a.XSo = p->XSb;
     // 128-row tiles only when they still give >= 2 workgroups per CU; otherwise 64-row tiles, and 8 wavefronts per
     // workgroup when even those leave a single workgroup per CU
-    if (const int ts = bd_tslots(ntok)) {      // static-batched decode: one wavefront per (16-row strip, 16 tokens), all of K
+    if (const int ts = bd_tslots(ntok)) {      // static-batched decode / small chunks: one wavefront per (16-row strip, 16 tokens), all of K
         a.tslots = ts;
         const dim3 grid(bdw_grid((w.rows + 15) / 16, (ntok + 15) / 16));
-        if constexpr (EPI == EPI_SWIGLU) {
-            if (quantised_out)      // workgroup = the two strips of a 32-row block of hb; hb is written as the down projection's operand
-                hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 4, 2, true>), dim3(bdw_grid((w.rows + 31) / 32, (ntok + 15) / 16)), dim3(128), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 4, 2>), grid, dim3(64), 0, ctx->stream, a);
-        } else hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 8, 2>), grid, dim3(64), 0, ctx->stream, a);
+        const dim3 gridq(bdw_grid((w.rows + 31) / 32, (ntok + 15) / 16));      // quantised output: two strips per workgroup
+#define GL3_BDW(TS_) \
+        do { \
+            if constexpr (EPI == EPI_SWIGLU) { \
+                if (quantised_out) hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 4, 2, true, TS_>), gridq, dim3(128), 0, ctx->stream, a); \
+                else hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 4, 2, false, TS_>), grid, dim3(64), 0, ctx->stream, a); \
+            } else hipLaunchKernelGGL((bdw_gemm_kernel<EPI, 8, 2, false, TS_>), grid, dim3(64), 0, ctx->stream, a); \
+        } while (0)
+        if (ts == BD_TS) GL3_BDW(BD_TS); else GL3_BDW(BD_TS_MAX);
+#undef GL3_BDW
         return;
     }
     if (ntok <= 64) {      // 32-token tiles, 128 rows (x2 matrices for SwiGLU) per workgroup
