@@ -384,9 +384,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
                 const int rbase = row0 + wr * (32 * RF) + f * 32 + 4 * hi;
                 float4 old[4];
                 if (EPI == EPI_RESID) {
+                    // unconditional loads (a guarded load into an array is followed by s_waitcnt vmcnt(0): four serialised round trips
+                    // per fragment); rows past the end read the buffer's first element instead and are not used
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (rbase + 8 * q + 3 < a.rows) old[q] = *reinterpret_cast<const float4*>(o + 8 * q);
+                        old[q] = *reinterpret_cast<const float4*>(rbase + 8 * q + 3 < a.rows ? o + 8 * q : a.out);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
