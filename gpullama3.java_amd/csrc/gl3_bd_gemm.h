@@ -1,4 +1,5 @@
-// gl3_bd_gemm.h — the Q8_0 batched-matmul argument block and the static-batched-decode GEMM (<= 32 tokens).
+// gl3_bd_gemm.h — the Q8_0 batched-matmul argument block and the small-batch GEMM (static-batched decode, prefill chunks of <= 64
+// tokens).
 // (Round 1's producer / chain-wavefront kernel, 32 rows x 32 tokens per workgroup with an LDS ring and a barrier per 8 blocks,
 // is in the history: 106 us of GEMMs per Qwen3-4B layer at B = 32 against 53 us for the kernel below.)
 // Included by gl3_prefill.hip (product) and by scripts/probes/bd_probe.hip (stand-alone timing harness), both after
@@ -27,10 +28,11 @@ struct GemmArgs {
     uint8_t* XQo; float* XSo;             // bdw_gemm_kernel<EPI_SWIGLU, .., QOUT>: hb leaves the kernel quantised (XQ2 / XS2 layout)
 };
 
+
 // ---------------------------------------------------------------------------------------------------
 // Static-batched decode and small prefill chunks, wave-owned form (<= 64 tokens).  One wavefront = one workgroup = 16 weight rows (one Q8T strip) x
 // 16 tokens x ALL of K, result in registers, accumulated block by block in the reference's order.  No operand staging in LDS,
-// no barriers; grid = strips x token tiles.
+// no barriers; grid = strips x token tiles (the token tiles of a strip 8 workgroup ids apart: same XCD, one L2).
 //   * one v_mfma_i32_16x16x32_i8 per (block, token tile).  The Q8T tile stores a block row as two 16-byte halves, so a
 //     lane's natural load is 16 B: lane (row r, k-group g) loads half g & 1 of block 2j + (g >> 1) — two blocks per
 //     load — and two v_permlane32_swap turn that into the 8 B x 4 k-groups of block 2j (low registers) and of block
