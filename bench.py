@@ -63,6 +63,9 @@ def main():
                     "(e.g. --model qwen3-4b --decode-batch 32); prints its own JSON line instead of the tg/pp line")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_spawn(args.gpus)
+
     import numpy as np
     import torch
     import __graft_entry__ as ge
@@ -75,8 +78,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or run without WORLD_SIZE and let "
+                         "bench.py start the ranks itself)" % (args.gpus, world))
+    if world > 1 and not os.environ.get("GL3_BENCH_SHARE_GPU") and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) are visible to rank %d" % (world, torch.cuda.device_count(), rank))
     dist = None
     transport = os.environ.get("GL3_TP_TRANSPORT", "p2p")        # p2p: peer-write all-gather over xGMI (csrc/gl3_tp.hip); rccl: fall-back
     if os.environ.get("GL3_BENCH_SHARE_GPU"):                    # test hook: every rank on device 0 of a one-GPU box (IPC between processes)
@@ -124,26 +130,8 @@ def main():
             dist.barrier()                  # every rank's plan exists and is attached before the first gather
         return mdl, pl
 
+    transport = select_transport(transport, world, rank, local_rank, dist, pkg, plan_mod, hip, torch)
     model, plan = build_plan(transport)
-    if world > 1 and transport != "rccl":
-        # one decode step as a transport self-test: the peer-write gather reports a timeout / mapping problem as an error (its spin
-        # is bounded); if any rank saw one, every rank rebuilds its plan over RCCL instead of failing the run
-        ok = 1
-        try:
-            plan.forward_decode(toks[0], 0, copy=False)
-            torch.cuda.synchronize()
-        except Exception as e:              # noqa: BLE001
-            ok = 0
-            print("rank %d: peer-write transport failed its self-test (%s); falling back to RCCL" % (rank, e), file=sys.stderr)
-        flags = [None] * world
-        dist.all_gather_object(flags, ok)
-        if not all(flags):
-            try:
-                plan.freeTornadoExecutionPlan()
-            except Exception:               # noqa: BLE001
-                pass
-            transport = "rccl"
-            model, plan = build_plan(transport)
     torch.cuda.empty_cache()
     setup_s = time.time() - t0
 
@@ -331,6 +319,85 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def select_transport(want, world, rank, local_rank, dist, pkg, plan_mod, hip, torch):
+    """Pick the tensor-parallel transport BEFORE the full-size plan is built.  The peer-write gather needs (1) every peer device
+    addressable from this one (hipDeviceCanAccessPeer via gl3_tp_peer_access) and (2) hipIpcOpenMemHandle of a peer's uncached
+    arena plus a gather that completes: a one-layer probe model runs two tensor-parallel decode steps end to end and the ranks
+    compare their logits.  Any rank failing either check moves EVERY rank to RCCL.  With GL3_BENCH_SHARE_GPU (test hook: all ranks on
+    device 0 of a one-GPU box) RCCL cannot be the fall-back — a communicator rejects duplicate devices — so a failed probe is fatal."""
+    import ctypes as C
+    import numpy as np
+    if world == 1 or want == "rccl":
+        return want
+    share = bool(os.environ.get("GL3_BENCH_SHARE_GPU"))
+    ok, why = 1, ""
+    if not share:
+        peers = (C.c_int32 * world)(*range(world))       # one rank per local device ordinal
+        reach = C.c_int32()
+        rc = hip.lib().gl3_tp_peer_access(local_rank, peers, world, C.byref(reach))
+        if rc != 0 or reach.value != world:
+            ok, why = 0, "hipDeviceCanAccessPeer: %d of %d peers reachable (rc %d)" % (reach.value, world, rc)
+
+    def exchange(handle):
+        out = [None] * world
+        dist.all_gather_object(out, handle)
+        return out
+
+    flags = [None] * world
+    dist.all_gather_object(flags, ok)
+    if all(flags):
+        synth = pkg.synth
+        cfg = synth.ModelConfig("tp-probe", synth.ARCH_LLAMA, 512, 1024, 1, 16, 16, 32, 1024, 16, 1e-5, 10000.0, True)
+        # every collective of the probe sits OUTSIDE the try blocks: a rank that fails still meets its peers at the next one
+        probe, logits = None, None
+        try:
+            probe = plan_mod.HipMasterPlan(synth.make_numpy(cfg, seed=5), device=local_rank, tp_rank=rank, tp_size=world, p2p_exchange=exchange)
+        except Exception as e:                          # noqa: BLE001
+            ok, why = 0, "probe plan over IPC: %s" % e
+        dist.all_gather_object(flags, ok)
+        if all(flags):
+            try:
+                probe.forward_decode(3, 0)              # the gather kernel's spin is bounded: a dead link is an error, not a hang
+                logits = probe.forward_decode(5, 1)
+            except Exception as e:                      # noqa: BLE001
+                ok, why = 0, "probe decode step: %s" % e
+            sums = [None] * world
+            dist.all_gather_object(sums, None if logits is None else logits.tobytes())
+            if ok and any(x != sums[0] for x in sums):
+                ok, why = 0, "probe logits differ between ranks"
+            dist.all_gather_object(flags, ok)
+        if probe is not None:
+            probe.freeTornadoExecutionPlan()            # after the last collective: nobody unmaps an arena a peer still writes
+    if all(flags):
+        return want
+    if not ok:
+        print("rank %d: peer-write transport unavailable (%s)" % (rank, why), file=sys.stderr)
+    if share:
+        raise SystemExit("bench.py: peer-write transport failed with GL3_BENCH_SHARE_GPU set; RCCL cannot run several ranks on one device")
+    return "rccl"
+
+
+def self_spawn(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) through torch.distributed.run with
+    this command line and pass rank 0's JSON line through.  Fails loudly when fewer than N devices are visible: a run must never
+    print `n_gpus: 1` for `--gpus 8`."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("GL3_BENCH_SHARE_GPU"):
+        raise SystemExit("bench.py: --gpus %d requested but only %d device(s) are visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)" % (n, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: hipIpcGetMemHandle of the peer-write arena needs it
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def bench_decode_batch(args, cfg, synth, plan_mod, pkg, torch, np, dev):

@@ -182,6 +182,22 @@ int32_t gl3_tp_init(gl3_ctx* ctx, const void* unique_id, uint64_t bytes) {
     return GL3_OK;
 }
 
+int32_t gl3_tp_peer_access(int32_t device, const int32_t* peer_devices, int32_t n, int32_t* reachable) {
+    if (!peer_devices || !reachable || n < 0) return GL3_E_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return GL3_E_HIP;
+    if (device < 0 || device >= count) return GL3_E_ARG;
+    *reachable = 0;
+    for (int i = 0; i < n; ++i) {
+        const int p = peer_devices[i];
+        if (p < 0 || p >= count) return GL3_E_ARG;
+        int can = 1;                                     // a device reaches itself (ranks sharing one GPU in tests)
+        if (p != device && hipDeviceCanAccessPeer(&can, device, p) != hipSuccess) return GL3_E_HIP;
+        *reachable += can ? 1 : 0;
+    }
+    return GL3_OK;
+}
+
 int32_t gl3_tp_p2p_handle(gl3_ctx* ctx, void* out, uint64_t bytes) {
     if (!ctx) return GL3_E_ARG;
     if (!out || bytes < sizeof(hipIpcMemHandle_t)) GL3_FAIL(GL3_E_ARG, "handle buffer shorter than 64 bytes");

@@ -44,6 +44,7 @@ _SIGS = {  # symbol -> (restype, argtypes): exactly the declarations of include/
     "gl3_create": (C.c_int32, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "gl3_upload_tensor": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32]),
     "gl3_upload_rope": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "gl3_tp_peer_access": (C.c_int32, [C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "gl3_tp_p2p_handle": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "gl3_tp_p2p_attach": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "gl3_tp_unique_id": (C.c_int32, [C.c_void_p, C.c_uint64]),

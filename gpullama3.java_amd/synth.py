@@ -82,6 +82,9 @@ CONFIGS = {
     # projection on dim 4096, and two Qwen3-4B layers (K = 2560 ragged, head_size 128 != dim / heads, tied wcls)
     "8b-layer": ModelConfig("Llama-3-8B-1layer-random", ARCH_LLAMA, 4096, 14336, 1, 32, 8, 128, 2048, 648, 1e-5, 500000.0, False),
     "8b-vocab": ModelConfig("Llama-3-8B-vocab-random", ARCH_LLAMA, 4096, 1024, 1, 32, 8, 128, 128256, 64, 1e-5, 500000.0, False),
+    # BASELINE configs[1] at its own shape: one Llama-3.2-1B layer (hidden 8192: K = 8192 down projection = 64 tile groups on the
+    # 8-producer kernel; head_size 64) under the TIED 128256 x 2048 vocabulary projection
+    "1b-layer": ModelConfig("Llama-3.2-1B-1layer-random", ARCH_LLAMA, 2048, 8192, 1, 32, 8, 64, 128256, 648, 1e-5, 500000.0, True),
     "qwen3-4b-2l": ModelConfig("Qwen3-4B-2layer-random", ARCH_QWEN3, 2560, 9728, 2, 32, 8, 128, 4096, 64, 1e-6, 1000000.0, True),
 }
 

@@ -163,6 +163,9 @@ GL3_API int32_t gl3_upload_rope(gl3_ctx* ctx, const float* cr, const float* ci, 
  *     all_gather_object, a file, a socket) and hands all tp_size of them, in rank order, to gl3_tp_p2p_attach; one small
  *     kernel per gather then stores this rank's slice straight into the peers' buffers (csrc/gl3_tp.hip);
  *   RCCL (fall-back): `unique_id` is the id made by gl3_tp_unique_id on rank 0 and broadcast by the host. */
+/* Transport choice BEFORE any plan exists: *reachable = how many of the n `peer_devices` (HIP ordinals) `device` can address
+ * directly (hipDeviceCanAccessPeer; a device reaches itself).  reachable < n: use the RCCL transport (gl3_tp_init). */
+GL3_API int32_t gl3_tp_peer_access(int32_t device, const int32_t* peer_devices, int32_t n, int32_t* reachable);
 GL3_API int32_t gl3_tp_p2p_handle(gl3_ctx* ctx, void* out, uint64_t bytes);                  /* bytes >= 64 */
 GL3_API int32_t gl3_tp_p2p_attach(gl3_ctx* ctx, const void* handles, uint64_t bytes);        /* tp_size x 64 bytes */
 GL3_API int32_t gl3_tp_unique_id(void* out, uint64_t bytes);   /* bytes >= 128 */

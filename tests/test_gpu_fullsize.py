@@ -67,6 +67,102 @@ def test_llama3_8b_shaped_layer_prefill512_and_decode(pkg, orc, planmod):
     plan.freeTornadoExecutionPlan()
 
 
+def test_llama32_1b_shaped_layer_tied_vocab_decode_and_prefill512(pkg, orc, planmod):
+    """BASELINE configs[1] (Llama-3.2-1B Q8_0 tg128) at ITS OWN shape: dim 2048 / hidden 8192 / head_size 64 and the tied
+    128256 x 2048 head (wcls = token_embd): decode from position 0 with full logits, per-layer x and device argmax, a 512-token
+    batched prefill (pp512 -b 512) and decode steps on top of it, all against the C oracle."""
+    plan_mod, hip = planmod
+    m = _model(pkg, "1b-layer", 109)
+    assert m.cfg.tied and m.cfg.vocab == 128256 and m.cfg.hidden == 8192
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 516)
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=512, flags=hip.FLAG_LAYER_TAPS)
+    o = orc.COracle(m)
+    for pos in range(4):
+        ref, lx = o.forward(toks[pos], pos, layer_x=True)
+        got = plan.tornadoVMForwardDecode(toks[pos], pos)
+        assert got.shape == (128256,)
+        assert np.array_equal(got, ref), pos
+        assert np.array_equal(plan.layer_x(0), lx[0]), pos
+        assert plan.forward_decode_argmax(toks[pos], pos) == orc.argmax(ref)
+    plan.reset_kv()
+    o2 = orc.COracle(m)
+    plan.tornadoVMForwardBatchPrefill(toks[:512], 0)
+    o2.prefill(toks[:512], 0)
+    assert np.array_equal(plan.x(), o2.x())
+    for p in (0, 127, 128, 511):
+        k, v = plan.kv(0, p)
+        ko, vo = o2.kv(0, p)
+        assert np.array_equal(k, ko) and np.array_equal(v, vo), p
+    for pos in range(512, 515):
+        ref = o2.forward(toks[pos], pos)
+        assert np.array_equal(plan.tornadoVMForwardDecode(toks[pos], pos), ref), pos
+    plan.freeTornadoExecutionPlan()
+
+
+@pytest.mark.parametrize("wtype", [2, 1])
+def test_q4_0_and_f16_on_the_8b_layer_shape(pkg, orc, planmod, wtype):
+    """BASELINE configs[3] / configs[0] dtypes at the 8B layer shape: Q4_0 and F16 matrices with K = 4096 and K = 14336 (the VL
+    kernels' chunk loops at 16 / 56 chunks of 256 elements per row) in the reference's default Vector-API order; a 40-token prefill
+    in two ragged chunks (the batched Vector-API-order prefill), then decode steps, against the oracle in the same mode."""
+    plan_mod, hip = planmod
+    m = _model(pkg, "8b-layer", 113, wtype=wtype)
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=32, flags=hip.FLAG_LAYER_TAPS)
+    o = orc.COracle(m, vector_bits=256)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 46)
+    for pos in range(3):
+        ref, lx = o.forward(toks[pos], pos, layer_x=True)
+        got = plan.tornadoVMForwardDecode(toks[pos], pos)
+        assert np.array_equal(got, ref), pos
+        assert np.array_equal(plan.layer_x(0), lx[0]), pos
+        assert plan.forward_decode_argmax(toks[pos], pos) == orc.argmax(ref)
+    plan.reset_kv()
+    o2 = orc.COracle(m, vector_bits=256)
+    plan.prefill(toks[:40], 0)                     # chunks of 32 + 8
+    o2.prefill(toks[:40], 0)
+    assert np.array_equal(plan.x(), o2.x())
+    for p in (0, 31, 32, 39):
+        k, v = plan.kv(0, p)
+        ko, vo = o2.kv(0, p)
+        assert np.array_equal(k, ko) and np.array_equal(v, vo), p
+    for pos in range(40, 43):
+        ref = o2.forward(toks[pos], pos)
+        assert np.array_equal(plan.tornadoVMForwardDecode(toks[pos], pos), ref), pos
+    plan.freeTornadoExecutionPlan()
+
+
+def test_q4_0_tp8_on_the_8b_layer_shape(pkg, orc, planmod):
+    """BASELINE configs[3] (Llama-3-8B Q4_0, TP = 8) at the 8B layer shape inside one GPU: eight row-split ranks (one kv head, 1792
+    hidden units, 512 dim rows, 256 vocab rows each) as host threads over the peer-write gather; every rank's logits equal the
+    single-GPU CPU oracle's.  (Ranks on eight DEVICES are the driver's SCALE run; nothing here crosses an xGMI link.)"""
+    import threading
+    plan_mod, hip = planmod
+    tp = 8
+    m = _model(pkg, "8b-layer", 127, wtype=2)
+    o = orc.COracle(m, vector_bits=256)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 2)
+    ref = [o.forward(t, p) for p, t in enumerate(toks)]
+    grp = plan_mod.make_local_group(tp)
+    out, err = [None] * tp, [None] * tp
+
+    def rank_main(r):
+        try:
+            plan = plan_mod.HipMasterPlan(m, tp_rank=r, tp_size=tp, local_group=grp)
+            out[r] = [plan.forward_decode(t, p) for p, t in enumerate(toks)]
+            plan.freeTornadoExecutionPlan()
+        except Exception as e:   # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(tp)]
+    [t.start() for t in th]
+    [t.join(timeout=900) for t in th]
+    assert all(e is None for e in err), err
+    assert not any(t.is_alive() for t in th)
+    hip.lib().gl3_local_group_destroy(grp)
+    for r in range(tp):
+        for p in range(len(toks)):
+            assert np.array_equal(out[r][p], ref[p]), (r, p)
+
+
 def test_vocab_128256_projection(pkg, orc, planmod):
     plan_mod, hip = planmod
     m = _model(pkg, "8b-vocab", 103)
