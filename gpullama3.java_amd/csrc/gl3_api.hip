@@ -331,8 +331,8 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     if (d.dim <= 0 || d.dim % 32 || d.hidden % 32 || d.n_layers <= 0 || d.n_heads <= 0 || d.n_kv_heads <= 0 ||
         d.n_heads % d.n_kv_heads || d.vocab <= 0 || d.ctx <= 0)
         return bail(GL3_E_ARG, "bad model dimensions");
-    if (d.head_size != 32 && d.head_size != 64 && d.head_size != 128 && d.head_size != 256)
-        return bail(GL3_E_UNSUPPORTED, "head_size must be 32/64/128/256");
+    if (d.head_size < 32 || d.head_size > 256 || d.head_size % 32)       // 96: Phi-3-mini; 160 / 192 / 224 work the same way
+        return bail(GL3_E_UNSUPPORTED, "head_size must be a multiple of 32 between 32 and 256");
     const int tp = d.tp_size < 1 ? 1 : d.tp_size;
     ctx->d.tp_size = tp;
     if (d.tp_rank < 0 || d.tp_rank >= tp) return bail(GL3_E_ARG, "tp_rank out of range");
@@ -408,8 +408,23 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP(hipHostMalloc((void**)&ctx->h_dyn, 4 * sizeof(int)));
     TRYHIP(hipHostMalloc((void**)&ctx->h_logits, (size_t)d.vocab * 4));
     TRYHIP(hipHostMalloc((void**)&ctx->h_argmax, sizeof(int)));
-    // the batched (int8 MFMA) prefill exists for Q8_0 only; F16 / Q4_0 prefill token by token
-    if (d.max_batch > 1 && d.weight_type == GL3_TYPE_Q8_0 && !(d.flags & GL3_FLAG_F32_ACTIVATION)) TRY(gl3_prefill_alloc(ctx));
+    // batched prefill / static-batched decode: int8 MFMA GEMMs for Q8_0 (any tensor-parallel degree); f32-MFMA / VALU GEMMs in the
+    // Vector-API order for F16, Q4_0 and Q8_0 with the f32 activation on one rank (gl3_prefill_vl.h).  The scalar dot order
+    // (GL3_FLAG_SCALAR_DOT) and tensor-parallel ranks of those types prefill token by token.
+    {
+        const bool int8_path = d.weight_type == GL3_TYPE_Q8_0 && !(d.flags & GL3_FLAG_F32_ACTIVATION);
+        const bool vl_path = !int8_path && !(d.flags & GL3_FLAG_SCALAR_DOT) && tp == 1 && !(d.flags & GL3_FLAG_FORCE_RCCL);
+        if (d.max_batch > 1 && (int8_path || vl_path)) TRY(gl3_prefill_alloc(ctx));
+    }
+    if (getenv("GL3_DEBUG_ALLOC")) {
+        fprintf(stderr, "[gl3 alloc] ctx %p emb %p (+%zu) kcache %p vcache %p (%zu floats) x %p qkv %p xb %p hb %p logits %p att %p xn %p\n", (void*)ctx, (void*)ctx->emb.w,
+                ctx->emb.bytes(), (void*)ctx->kcache, (void*)ctx->vcache, kvn, (void*)ctx->x, (void*)ctx->qkv, (void*)ctx->xb, (void*)ctx->hb, (void*)ctx->logits, (void*)ctx->att, (void*)ctx->xn);
+        for (size_t l = 0; l < ctx->layers.size(); ++l) {
+            const gl3_layer& L = ctx->layers[l];
+            fprintf(stderr, "[gl3 alloc]   layer %zu wqkv %p (+%zu) wo %p (+%zu) w1 %p (+%zu) w3 %p w2 %p (+%zu)\n", l, (void*)L.wqkv.w, L.wqkv.bytes(), (void*)L.wo.w, L.wo.bytes(),
+                    (void*)L.w1.w, L.w1.bytes(), (void*)L.w3.w, (void*)L.w2.w, L.w2.bytes());
+        }
+    }
     TRYHIP(hipDeviceSynchronize());
 #undef TRY
 #undef TRYHIP
@@ -751,7 +766,7 @@ int32_t gl3_forward_decode_batch(gl3_ctx* ctx, const int32_t* tokens, const int3
     if (!ctx) return GL3_E_ARG;
     if (!tokens || !seq_ids || !positions || n <= 0) GL3_FAIL(GL3_E_ARG, "bad batch arrays");
     if (!ctx->finalized) GL3_FAIL(GL3_E_STATE, "forward before gl3_finalize");
-    if (!ctx->pf) GL3_FAIL(GL3_E_UNSUPPORTED, "batched decode needs max_batch > 1 and Q8_0 weights");
+    if (!ctx->pf) GL3_FAIL(GL3_E_UNSUPPORTED, "batched decode needs max_batch > 1 (and, for F16 / Q4_0 / f32-activation Q8_0, one rank in the Vector-API order)");
     if (n > ctx->d.max_batch) GL3_FAIL(GL3_E_ARG, "batch larger than max_batch");
     for (int i = 0; i < n; ++i) {
         if (tokens[i] < 0 || tokens[i] >= ctx->d.vocab) GL3_FAIL(GL3_E_ARG, "token id out of range");
@@ -822,6 +837,11 @@ int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* o
 int32_t gl3_pin_host_buffer(gl3_ctx* ctx, void* ptr, uint64_t bytes) {
     if (!ctx) return GL3_E_ARG;
     if (!ptr || !bytes) GL3_FAIL(GL3_E_ARG, "null buffer");
+    // Whole pages only.  hipHostRegister pins and GPU-maps the PAGES of the range and hipHostUnregister unmaps them again: a
+    // buffer in the middle of the C heap (a small numpy array, a malloc block) shares its pages with whatever the allocator
+    // puts beside it, and unmapping them under another registered range gave sporadic "Memory access fault by GPU" aborts in
+    // long test runs (round 3).  A page-aligned, page-padded buffer (mmap, posix_memalign, Arena.allocate(n, 4096)) owns its pages.
+    if (((uintptr_t)ptr & 4095) || (bytes & 4095)) GL3_FAIL(GL3_E_ARG, "gl3_pin_host_buffer: pointer and size must be multiples of 4096 (the buffer must own its pages)");
     GL3_HIP(hipSetDevice(ctx->d.device));
     GL3_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
     ctx->pinned.emplace_back(ptr, (size_t)bytes);

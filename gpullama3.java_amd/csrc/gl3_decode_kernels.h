@@ -574,7 +574,11 @@ __host__ __device__ inline size_t attn_head_smem(int hs, int group = 1) {
 static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads, half = hs >> 1, pitch = hs + 4, q4 = hs >> 2;
-    const int q4sh = __ffs(q4) - 1;                  // head sizes are powers of two
+    // float4 index -> (row, column quad) of a K / V tile: shift / mask for the power-of-two head sizes, division otherwise
+    // (head_size 96: Phi-3-mini / Phi-3.5-mini, forwardJavaPhi3 with headSize = dim / heads)
+    const int q4sh = (q4 & (q4 - 1)) == 0 ? __ffs(q4) - 1 : -1;
+    auto row_of = [&](int i) { return q4sh >= 0 ? i >> q4sh : i / q4; };
+    auto col_of = [&](int i, int row) { return q4sh >= 0 ? i & (q4 - 1) : i - row * q4; };
     const int G = a.group > 1 ? a.group : 1;
     float* q_s = sm;                                 // [G][hs]
     float* kt = q_s + G * hs;
@@ -605,8 +609,8 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
         kreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         vreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (u < per) {
-            const int i = min(t + u * 256, nk4 - 1);
-            const size_t off = (size_t)(i >> q4sh) * a.kv_dim + kvh * hs + 4 * (i & (q4 - 1));
+            const int i = min(t + u * 256, nk4 - 1), ri = row_of(i);
+            const size_t off = (size_t)ri * a.kv_dim + kvh * hs + 4 * col_of(i, ri);
             kreg[u] = *reinterpret_cast<const float4*>(kcache + off);
             vreg[u] = *reinterpret_cast<const float4*>(vcache + off);
         }
@@ -623,15 +627,17 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
         for (int u = 0; u < KMAX; ++u) {
             const int i = t + u * 256;
             if (i < nk4) {
-                *reinterpret_cast<float4*>(kt + (i >> q4sh) * pitch + 4 * (i & (q4 - 1))) = kreg[u];
-                *reinterpret_cast<float4*>(vt + (i >> q4sh) * hs + 4 * (i & (q4 - 1))) = vreg[u];
+                const int ri = row_of(i), ci = col_of(i, ri);
+                *reinterpret_cast<float4*>(kt + ri * pitch + 4 * ci) = kreg[u];
+                *reinterpret_cast<float4*>(vt + ri * hs + 4 * ci) = vreg[u];
             }
         }
     } else {                                         // head_size 256: straight to LDS
         for (int i = t; i < nk4; i += 256) {
-            const size_t off = (size_t)(i >> q4sh) * a.kv_dim + kvh * hs + 4 * (i & (q4 - 1));
-            *reinterpret_cast<float4*>(kt + (i >> q4sh) * pitch + 4 * (i & (q4 - 1))) = *reinterpret_cast<const float4*>(kcache + off);
-            *reinterpret_cast<float4*>(vt + (i >> q4sh) * hs + 4 * (i & (q4 - 1))) = *reinterpret_cast<const float4*>(vcache + off);
+            const int ri = row_of(i), ci = col_of(i, ri);
+            const size_t off = (size_t)ri * a.kv_dim + kvh * hs + 4 * ci;
+            *reinterpret_cast<float4*>(kt + ri * pitch + 4 * ci) = *reinterpret_cast<const float4*>(kcache + off);
+            *reinterpret_cast<float4*>(vt + ri * hs + 4 * ci) = *reinterpret_cast<const float4*>(vcache + off);
         }
     }
     __syncthreads();

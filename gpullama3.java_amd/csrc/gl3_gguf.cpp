@@ -29,6 +29,7 @@ struct MetaValue {
     std::string str;           // GT_STRING
     uint64_t array_len = 0;    // GT_ARRAY (elements are skipped, only the length is kept: vocabulary size)
     int array_type = -1;
+    const uint8_t* array_data = nullptr;   // fixed-size element types: the elements inside the mapping
 };
 
 struct TensorInfo {
@@ -121,6 +122,7 @@ bool read_value(Cursor& c, int ty, MetaValue& v) {
         if (v.array_type < 0 || v.array_type > GT_F64) return false;
         const uint64_t nb = v.array_len * fixed[v.array_type];
         if (nb > (uint64_t)(c.end - c.p)) return false;
+        v.array_data = c.p;
         c.p += nb;
     }
     return c.ok;
@@ -211,7 +213,9 @@ int32_t gl3_kquant_to_q8_0(int32_t src_type, const void* src, uint64_t n, void* 
         o[0] = (uint8_t)(h & 0xFF); o[1] = (uint8_t)(h >> 8);
         const float inv = scale != 0.f ? 1.0f / scale : 0.f;
         for (int i = 0; i < 32; ++i) {
-            int q = (int)std::floor(x[i] * inv + 0.5f);                            // Math.round(float): ties toward +infinity
+            // Math.round(float) = floor(a + 1/2) with the sum taken EXACTLY (ties toward +infinity): the f32 product is widened
+            // before the addition (a = 0.49999997f: a + 0.5f rounds to 1.0f in f32, Java gives 0)
+            int q = (int)std::floor((double)(x[i] * inv) + 0.5);
             q = q < -128 ? -128 : q > 127 ? 127 : q;
             o[2 + i] = (uint8_t)(int8_t)q;
         }
@@ -339,7 +343,23 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
         !need("attention.head_count", &nh) || !need("context_length", &ctx))
         return fail(g, GL3_E_ARG, "model shape keys missing from the metadata");
     need("attention.layer_norm_rms_epsilon", &eps);
-    if (!need("attention.head_count_kv", &nkv)) nkv = nh;
+    if (!need("attention.head_count_kv", &nkv)) {
+        // Granite 4.0 stores a per-layer int array; GraniteLoader.java:61-71 takes element 0 ("assuming uniform").  A uniform array
+        // is accepted the same way; a non-uniform one would give a wrong kv_dim for some layer, so it is refused.
+        nkv = nh;
+        auto kv = g->meta.find(a + ".attention.head_count_kv");
+        if (kv != g->meta.end() && kv->second.type == GT_ARRAY && kv->second.array_data && kv->second.array_len > 0 &&
+            (kv->second.array_type == GT_U32 || kv->second.array_type == GT_I32)) {
+            int32_t first = 0;
+            memcpy(&first, kv->second.array_data, 4);
+            for (uint64_t i = 1; i < kv->second.array_len; ++i) {
+                int32_t e = 0;
+                memcpy(&e, kv->second.array_data + 4 * i, 4);
+                if (e != first) return fail(g, GL3_E_UNSUPPORTED, "attention.head_count_kv differs between layers (per-layer kv heads are not implemented)");
+            }
+            nkv = first;
+        }
+    }
     need("rope.freq_base", &theta);
     if (!(dim >= 1 && dim <= (1 << 20)) || !(hid >= 1 && hid <= (1 << 24)) || !(nl >= 1 && nl <= 4096) || !(nh >= 1 && nh <= 4096) ||
         !(nkv >= 1 && nkv <= nh) || !(ctx >= 1 && ctx <= 2147483647.0))

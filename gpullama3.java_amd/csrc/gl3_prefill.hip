@@ -10,11 +10,15 @@
 // (Q8_0FloatTensor.java:90-123), and that is what the GEMM below does on CDNA4's int8 matrix cores:
 //   one v_mfma_i32_32x32x32_i8 = the int32 dot of one Q8_0 block for a 32-row x 32-token tile (exact), then
 //   acc = acc + float(isum) * (wScale * aScale) on the VALU, blocks ascending — the reference's f32 order.
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "gl3_ctx.h"
 #include <type_traits>
 #include "gl3_decode_kernels.h"
+
+#include "gl3_prefill_vl.h"
 
 using namespace gl3;
 #include "gl3_bd_gemm.h"      // GemmArgs, bdw_gemm_kernel (expects the gl3 names in scope)
@@ -37,7 +41,13 @@ struct gl3_prefill_state {
     std::vector<hipGraphExec_t> step_graphs;   // static-batched decode: one captured step per batch size (positions < AF_MAXN)
     bool in_arena = false;              // X / AO / HB / LOGITS are slices of the tensor-parallel arena (not freed here)
     int32_t* amax = nullptr;            // [M]
+    float* amx_v = nullptr;             // [M][AMX_SPLIT] partial maxima of the greedy scan
+    int* amx_i = nullptr;
     int maxk = 0;
+    // F16 / Q4_0 / Q8_0-with-f32-activation plans (gl3_prefill_vl.h): the GEMMs read f32 activations
+    bool vl = false;
+    float* XN = nullptr;                // [M][dim] RMS-normalised activations
+    float* HB2 = nullptr;               // [M][hidden] up projection (hb = silu(HB) * HB2)
 };
 
 
@@ -69,12 +79,13 @@ __global__ __launch_bounds__(256) void pf_embed_kernel(const uint8_t* __restrict
 // One workgroup of 256 threads per token (PQ_NORM) or per (token, 1024-element chunk) (the other modes: the blocks are
 // independent, and one workgroup per token left 32 tokens on 32 CUs).
 //   PQ_PLAIN:  quantise an f32 row;  PQ_NORM: RMSNorm, then quantise
-enum { PQ_PLAIN = 0, PQ_NORM = 1 };
+//   PQ_NORM_F32: RMSNorm only, f32 out (XS = [ntok][k] floats; the f32-activation weight types, gl3_prefill_vl.h)
+enum { PQ_PLAIN = 0, PQ_NORM = 1, PQ_NORM_F32 = 2 };
 template <int MODE>
 __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restrict__ in, int k, int in_stride,
                                                              const float* __restrict__ norm_w, float eps,
                                                              uint8_t* __restrict__ XQ, float* __restrict__ XS, int maxk, int tslots) {
-    constexpr bool NORM = MODE == PQ_NORM;
+    constexpr bool NORM = MODE != PQ_PLAIN;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* xf = reinterpret_cast<float*>(smem);                 // [k + 32]
     uint8_t* scratch = smem + (size_t)(k + 32) * 4;             // ss_scratch_bytes(k)
@@ -113,6 +124,7 @@ __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restr
         } else {
             v = xquad(qd);
         }
+        if (MODE == PQ_NORM_F32) { *reinterpret_cast<float4*>(XS + (size_t)b * k + 4 * qd) = v; continue; }
         if (tslots == 0) quantize_quad(v, qd, xq, xs);
         else {                                           // the wave-owned small-batch GEMM's operand layout (gl3_bd_gemm.h)
             float qs;
@@ -716,29 +728,46 @@ __global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, in
 }
 
 // Greedy id per sequence: first index of the maximum of each logits row (FloatTensor.argmax :138-151).
-// logits: rank-chunked [tp][rows][n / tp] (cc = n / tp; tp = 1: plain rows)
-__global__ __launch_bounds__(1024) void pf_argmax_rows_kernel(const float* __restrict__ logits, int n, int32_t* __restrict__ out, int cc) {
-    __shared__ float bv[16];
-    __shared__ int bi[16];
-    const int t = threadIdx.x, row = blockIdx.x, nrows = gridDim.x;
+// logits: rank-chunked [tp][rows][n / tp] (cc = n / tp, a multiple of 4; tp = 1: plain rows).
+// Two launches: (AMX_SPLIT segments x rows) workgroups scan their segment with float4 loads -> one (value, index) pair each; one
+// wavefront per row folds the pairs.  (Round 2: one 1024-thread workgroup per row with scalar strided loads, 75 us per step for a
+// 19 MB scan at B = 32 — 30x its HBM time.)
+constexpr int AMX_SPLIT = 32;
+__device__ __forceinline__ void amx_fold(float& best, int& idx, float ob, int oi) {
+    if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+}
+__global__ __launch_bounds__(256) void pf_argmax_part_kernel(const float* __restrict__ logits, int n, int cc, float* __restrict__ pv, int* __restrict__ pi) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int t = threadIdx.x, seg = blockIdx.x, row = blockIdx.y, nrows = gridDim.y;
+    const int nq = n >> 2, per = (nq + AMX_SPLIT - 1) / AMX_SPLIT;
+    const int q0 = seg * per, q1 = min(nq, q0 + per);
     float best = -INFINITY;
     int idx = 0x7FFFFFFF;
-    for (int i = t; i < n; i += 1024) {
-        const float f = logits[chunked(row, i, cc, nrows)];
-        if (f > best || (f == best && i < idx)) { best = f; idx = i; }
+    for (int q = q0 + t; q < q1; q += 256) {
+        const int i = 4 * q;
+        const float4 f = *reinterpret_cast<const float4*>(logits + chunked(row, i, cc, nrows));
+        if (f.x > best) { best = f.x; idx = i; }            // ascending i inside a thread: strict > keeps the first maximum
+        if (f.y > best) { best = f.y; idx = i + 1; }
+        if (f.z > best) { best = f.z; idx = i + 2; }
+        if (f.w > best) { best = f.w; idx = i + 3; }
     }
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float ob = __shfl_xor(best, m, 64);
-        const int oi = __shfl_xor(idx, m, 64);
-        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
-    }
+    if (seg == AMX_SPLIT - 1)                               // n is a multiple of 16 in every supported shape; kept for safety
+        for (int i = 4 * nq + t; i < n; i += 256) { const float f = logits[chunked(row, i, cc, nrows)]; if (f > best) { best = f; idx = i; } }
+    for (int m = 32; m >= 1; m >>= 1) amx_fold(best, idx, __shfl_xor(best, m, 64), __shfl_xor(idx, m, 64));
     if ((t & 63) == 0) { bv[t >> 6] = best; bi[t >> 6] = idx; }
     __syncthreads();
     if (t == 0) {
-        for (int w = 1; w < 16; ++w)
-            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-        out[blockIdx.x] = idx == 0x7FFFFFFF ? 0 : idx;
+        for (int w = 1; w < 4; ++w) amx_fold(best, idx, bv[w], bi[w]);
+        pv[row * AMX_SPLIT + seg] = best; pi[row * AMX_SPLIT + seg] = idx;
     }
+}
+__global__ __launch_bounds__(64) void pf_argmax_fold_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int32_t* __restrict__ out) {
+    const int row = blockIdx.x, t = threadIdx.x;
+    float best = t < AMX_SPLIT ? pv[row * AMX_SPLIT + t] : -INFINITY;
+    int idx = t < AMX_SPLIT ? pi[row * AMX_SPLIT + t] : 0x7FFFFFFF;
+    for (int m = 32; m >= 1; m >>= 1) amx_fold(best, idx, __shfl_xor(best, m, 64), __shfl_xor(idx, m, 64));
+    if (t == 0) out[row] = idx == 0x7FFFFFFF ? 0 : idx;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -748,6 +777,33 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     ctx->pf = p;
     p->max_batch = d.max_batch;
     const size_t M = d.max_batch;
+    p->vl = ctx->emb.vl;
+    if (p->vl) {       // f32-activation weight types on one rank (gl3_create admits nothing else here): plain f32 buffers
+        GL3_HIP(hipMalloc((void**)&p->tokens, M * sizeof(int32_t)));
+        GL3_HIP(hipMalloc((void**)&p->X, M * d.dim * 4));
+        GL3_HIP(hipMalloc((void**)&p->XN, M * d.dim * 4));
+        GL3_HIP(hipMalloc((void**)&p->AO, M * ctx->q_dim * 4));
+        GL3_HIP(hipMalloc((void**)&p->HB, M * d.hidden * 4));
+        GL3_HIP(hipMalloc((void**)&p->HB2, M * d.hidden * 4));
+        GL3_HIP(hipMalloc((void**)&p->QKV, M * (ctx->q_dim + 2 * ctx->kv_dim) * 4));
+        GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
+        GL3_HIP(hipMalloc((void**)&p->seqpos, 2 * M * sizeof(int32_t)));
+        GL3_HIP(hipMalloc((void**)&p->amax, M * sizeof(int32_t)));
+        GL3_HIP(hipMalloc((void**)&p->amx_v, M * AMX_SPLIT * sizeof(float)));
+        GL3_HIP(hipMalloc((void**)&p->amx_i, M * AMX_SPLIT * sizeof(int)));
+        if (getenv("GL3_DEBUG_ALLOC"))
+            fprintf(stderr, "[gl3 alloc vl] M %zu tokens %p X %p XN %p AO %p HB %p HB2 %p QKV %p ATT %p seqpos %p amax %p (dim %d hidden %d qdim %d ctx %d)\n", M, (void*)p->tokens,
+                    (void*)p->X, (void*)p->XN, (void*)p->AO, (void*)p->HB, (void*)p->HB2, (void*)p->QKV, (void*)p->ATT, (void*)p->seqpos, (void*)p->amax, d.dim, d.hidden, ctx->q_dim, d.ctx);
+        GL3_HIP(hipFuncSetAttribute((const void*)gemm_f16_mfma_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F16G_STAGE));
+        GL3_HIP(hipFuncSetAttribute((const void*)gemm_f16_mfma_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F16G_STAGE));
+        GL3_HIP(hipFuncSetAttribute((const void*)gemm_vlq_kernel<WT_Q4_0, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * vlq_stage_floats<WT_Q4_0>() * 4));
+        GL3_HIP(hipFuncSetAttribute((const void*)gemm_vlq_kernel<WT_Q4_0, EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * vlq_stage_floats<WT_Q4_0>() * 4));
+        GL3_HIP(hipFuncSetAttribute((const void*)gemm_vlq_kernel<WT_Q8_0, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * vlq_stage_floats<WT_Q8_0>() * 4));
+        GL3_HIP(hipFuncSetAttribute((const void*)gemm_vlq_kernel<WT_Q8_0, EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * vlq_stage_floats<WT_Q8_0>() * 4));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        return GL3_OK;
+    }
     p->maxk = d.hidden > ctx->q_dim ? d.hidden : ctx->q_dim;
     if (d.dim > p->maxk) p->maxk = d.dim;
     p->maxk = (p->maxk + 127) & ~127;
@@ -775,6 +831,8 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
     GL3_HIP(hipMalloc((void**)&p->seqpos, 2 * M * sizeof(int32_t)));
     GL3_HIP(hipMalloc((void**)&p->amax, M * sizeof(int32_t)));
+    GL3_HIP(hipMalloc((void**)&p->amx_v, M * AMX_SPLIT * sizeof(float)));
+    GL3_HIP(hipMalloc((void**)&p->amx_i, M * AMX_SPLIT * sizeof(int)));
 #define GL3_GEMM_LDS(...) GL3_HIP(hipFuncSetAttribute((const void*)pf_gemm_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gm_stage_bytes(128)))
     GL3_GEMM_LDS(EPI_STORE, 1, 4); GL3_GEMM_LDS(EPI_STORE, 2, 4); GL3_GEMM_LDS(EPI_STORE, 1, 8);
     GL3_GEMM_LDS(EPI_RESID, 1, 4); GL3_GEMM_LDS(EPI_RESID, 2, 4); GL3_GEMM_LDS(EPI_RESID, 1, 8);
@@ -791,7 +849,7 @@ void gl3_prefill_free(gl3_ctx* ctx) {
     if (!p) return;
     for (auto ge : p->step_graphs) if (ge) hipGraphExecDestroy(ge);
     auto f = [](void* q) { if (q) hipFree(q); };
-    f(p->tokens); f(p->XQ); f(p->XS); f(p->XQb); f(p->XSb); f(p->QKV); f(p->ATT); f(p->seqpos); f(p->amax);
+    f(p->tokens); f(p->XQ); f(p->XS); f(p->XQb); f(p->XSb); f(p->QKV); f(p->ATT); f(p->seqpos); f(p->amax); f(p->amx_v); f(p->amx_i); f(p->XN); f(p->HB2);
     if (!p->in_arena) { f(p->X); f(p->AO); f(p->HB); f(p->LOGITS); }
     delete p;
     ctx->pf = nullptr;
@@ -855,22 +913,127 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     }
 }
 
-// All layers for n tokens whose (token, sequence, position) are already on the device.  max_pos = largest position.
-// one_seq >= 0: all n tokens belong to that sequence at consecutive positions ending at max_pos (prefill).
-static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
+// RoPE + KV write + attention of layer l for the n tokens whose raw q | k | v rows are in p->QKV -> AOr (this rank's chunk of the
+// attention output).  fuse_q: static-batched decode on one rank writes the output as the wo projection's int8 operand instead.
+static void pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, float* AOr, bool fuse_q) {
     gl3_prefill_state* p = ctx->pf;
     const gl3_model_desc& d = ctx->d;
     hipStream_t s = ctx->stream;
+    gl3_layer& L = ctx->layers[l];
     const int32_t* seq = p->seqpos;
     const int32_t* pos = p->seqpos + p->max_batch;
     const int kvmul = d.n_heads / d.n_kv_heads;
-    // tensor parallel: this rank's heads / hidden units / dim rows; activations that are gathered use the rank-chunked layout
-    const int rank = d.tp_rank, H = ctx->heads_l, KVH = ctx->kv_heads_l, qd = ctx->q_dim_l, kvd = ctx->kv_dim_l;
-    const int hid = ctx->hidden_l, dml = ctx->dim_l;
+    const int H = ctx->heads_l, KVH = ctx->kv_heads_l, qd = ctx->q_dim_l, kvd = ctx->kv_dim_l;
     const int qkv_dim = qd + 2 * kvd;
     const size_t kv_layer = (size_t)d.ctx * kvd;
     // one workgroup per (kv head, token) serves the kv head's whole group of query heads when its LDS image fits
     const int bd_group = (kvmul <= 8 && attn_head_smem(d.head_size, kvmul) <= 150 * 1024) ? kvmul : 1;
+    const bool fused_decode = ctx->fused_attn_ok && max_pos < AF_MAXN && !(getenv("GL3_NO_FUSED_BD_ATTN") && atoi(getenv("GL3_NO_FUSED_BD_ATTN")));
+    RopeArgs ra{};
+    ra.QKV = p->QKV; ra.qkv_stride = qkv_dim; ra.kcache = ctx->kcache + l * kv_layer; ra.vcache = ctx->vcache + l * kv_layer;
+    ra.cr = ctx->rope_cr; ra.ci = ctx->rope_ci; ra.qnorm = L.qnorm; ra.knorm = L.knorm; ra.bq = L.bq; ra.bk = L.bk; ra.bv = L.bv; ra.n_heads = H;
+    ra.n_kv_heads = KVH; ra.hs = d.head_size; ra.q_dim = qd; ra.kv_dim = kvd;
+    ra.arch = ctx->rope_arch; ra.eps = d.rms_eps; ra.seq = seq; ra.pos = pos; ra.seq_stride = ctx->kv_seq_stride;
+    PfAttnArgs aa{};
+    aa.Q = p->QKV; aa.q_stride = qkv_dim; aa.kcache = ra.kcache; aa.vcache = ra.vcache; aa.att = p->ATT; aa.out = AOr;
+    aa.out_stride = qd; aa.n_heads = H; aa.n_kv_heads = KVH; aa.hs = d.head_size; aa.kv_dim = kvd;
+    aa.ctx = d.ctx; aa.seq = seq; aa.pos = pos; aa.seq_stride = ctx->kv_seq_stride; aa.att_mul = ctx->att_mul;
+    const int nsplit = (max_pos + 1 + ATT_TT - 1) / ATT_TT;
+    const int hs = d.head_size;
+    if (one_seq < 0 && fused_decode) {
+        // static-batched decode at positions < AF_MAXN: RoPE + KV write + scores + softmax + weighted V sum of every
+        // (token, head) in ONE launch (attn_head_kernel, grid = heads x tokens) instead of three per-token-grid kernels
+        AttnArgs ha{};
+        ha.qkv = p->QKV; ha.qkv_stride = qkv_dim; ha.kcache = ra.kcache; ha.vcache = ra.vcache; ha.rope_cr = ctx->rope_cr; ha.rope_ci = ctx->rope_ci;
+        ha.qnorm = L.qnorm; ha.knorm = L.knorm; ha.bq = L.bq; ha.bk = L.bk; ha.bv = L.bv; ha.dyn = ctx->dyn; ha.att = nullptr;
+        ha.xb = AOr; ha.xb_stride = qd; ha.n_heads = H; ha.n_kv_heads = KVH; ha.hs = hs; ha.q_dim = qd; ha.kv_dim = kvd; ha.ctx = d.ctx;
+        ha.eps = d.rms_eps; ha.arch = ctx->rope_arch; ha.att_mul = ctx->att_mul; ha.seqv = seq; ha.posv = pos; ha.seq_stride = ctx->kv_seq_stride;
+        ha.group = bd_group;
+        if (fuse_q) { ha.xq_out = p->XQ; ha.xs_out = p->XS; ha.xq_slots = bd_tslots(n); }
+        hipLaunchKernelGGL(attn_head_kernel, dim3(H / bd_group, n), dim3(256), attn_head_smem(hs, bd_group), s, ha);
+        return;
+    }
+    hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(H + KVH, n), dim3(64), 0, s, ra);
+    const bool tiled = one_seq >= 0 && kvmul <= 4 && (hs == 32 || hs == 64 || hs == 128) && (size_t)(max_pos + 1) * 4 <= 60 * 1024;
+    if (tiled) {
+        const int pos0 = max_pos + 1 - n, ntt = (n + PA_TB - 1) / PA_TB;
+        const size_t sms = (size_t)64 * (hs + 4) * 4;
+        const dim3 g1(nsplit, KVH, ntt), b1(64 * kvmul);
+        const float* kc1 = aa.kcache + (size_t)one_seq * ctx->kv_seq_stride;
+#define GL3_SCORES(HS_) hipLaunchKernelGGL((pf_scores_tiled_kernel<HS_>), g1, b1, sms, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul)
+        if (hs == 128) GL3_SCORES(128);
+        else if (hs == 64) GL3_SCORES(64);
+        else GL3_SCORES(32);
+#undef GL3_SCORES
+        const int npad = (max_pos + 1 + 63) & ~63;
+        int wpw = (int)((60 * 1024) / ((size_t)npad * 4));
+        wpw = wpw > 4 ? 4 : wpw;
+        hipLaunchKernelGGL(pf_softmax_kernel, dim3((n * H + wpw - 1) / wpw), dim3(256), (size_t)wpw * npad * 4, s, aa, n, wpw, npad);
+        if (hs > 64) hipLaunchKernelGGL((pf_pv_tiled_kernel<2>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
+        else hipLaunchKernelGGL((pf_pv_tiled_kernel<1>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
+    } else {
+        const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
+        hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, KVH, n), dim3(64 * kvmul), sm1, s, aa);
+        hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(H * ((d.head_size + 63) / 64), n), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
+    }
+}
+
+// Batched matmul of the f32-activation weight types (gl3_prefill_vl.h): out[b][row] (+)= dot(W[row], act[b]) in the Vector-API order
+template <int EPI>
+static void launch_gemm_vl(gl3_ctx* ctx, const Q8Mat& w, int ntok, const float* act, int act_stride, float* out, int out_stride, float out_scale = 1.0f) {
+    VlGemmArgs a{};
+    a.w = w.w; a.rows = w.rows; a.k = w.k; a.X = act; a.x_stride = act_stride; a.ntok = ntok; a.out = out; a.out_stride = out_stride; a.out_scale = out_scale;
+    a.nrt = (w.rows + 63) / 64;
+    if (w.fmt == GL3_TYPE_F16) {
+        a.ntt = (ntok + F16G_TOK - 1) / F16G_TOK;
+        hipLaunchKernelGGL((gemm_f16_mfma_kernel<EPI>), dim3(8 * ((a.nrt * a.ntt + 7) / 8)), dim3(256), 2 * F16G_STAGE, ctx->stream, a);
+    } else {
+        a.ntt = (ntok + VLQ_TOK - 1) / VLQ_TOK;
+        const dim3 g(8 * ((a.nrt * a.ntt + 7) / 8));
+        if (w.fmt == GL3_TYPE_Q4_0) hipLaunchKernelGGL((gemm_vlq_kernel<WT_Q4_0, EPI>), g, dim3(256), 2 * vlq_stage_floats<WT_Q4_0>() * 4, ctx->stream, a);
+        else hipLaunchKernelGGL((gemm_vlq_kernel<WT_Q8_0, EPI>), g, dim3(256), 2 * vlq_stage_floats<WT_Q8_0>() * 4, ctx->stream, a);
+    }
+}
+
+// The same layers for F16 / Q4_0 / Q8_0-with-f32-activation matrices on one rank: RMSNorm to f32 (exact sum of squares), GEMMs on
+// the f32 activations, gate and up as two GEMMs + an element-wise SwiGLU.
+static int32_t pf_layers_vl(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
+    gl3_prefill_state* p = ctx->pf;
+    const gl3_model_desc& d = ctx->d;
+    hipStream_t s = ctx->stream;
+    const int qkv_dim = ctx->q_dim + 2 * ctx->kv_dim;
+    if (ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((pf_embed_vl_kernel<WT_F16>), dim3(n), dim3(256), 0, s, ctx->emb.w, d.dim, p->tokens, p->X, ctx->emb_scale);
+    else if (ctx->emb.fmt == GL3_TYPE_Q4_0) hipLaunchKernelGGL((pf_embed_vl_kernel<WT_Q4_0>), dim3(n), dim3(256), 0, s, ctx->emb.w, d.dim, p->tokens, p->X, ctx->emb_scale);
+    else hipLaunchKernelGGL((pf_embed_vl_kernel<WT_Q8_0>), dim3(n), dim3(256), 0, s, ctx->emb.w, d.dim, p->tokens, p->X, ctx->emb_scale);
+    const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
+    for (int l = 0; l < d.n_layers; ++l) {
+        gl3_layer& L = ctx->layers[l];
+        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM_F32>), dim3(n), dim3(256), nq, s, p->X, d.dim, d.dim, L.attn_norm, d.rms_eps, (uint8_t*)nullptr, p->XN, 0, 0);
+        launch_gemm_vl<EPI_STORE>(ctx, L.wqkv, n, p->XN, d.dim, p->QKV, qkv_dim);
+        pf_attention(ctx, l, n, max_pos, one_seq, p->AO, false);
+        launch_gemm_vl<EPI_RESID>(ctx, L.wo, n, p->AO, ctx->q_dim, p->X, d.dim, ctx->resid_scale);
+        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM_F32>), dim3(n), dim3(256), nq, s, p->X, d.dim, d.dim, L.ffn_norm, d.rms_eps, (uint8_t*)nullptr, p->XN, 0, 0);
+        launch_gemm_vl<EPI_STORE>(ctx, L.w1, n, p->XN, d.dim, p->HB, d.hidden);
+        launch_gemm_vl<EPI_STORE>(ctx, L.w3, n, p->XN, d.dim, p->HB2, d.hidden);
+        const size_t ne = (size_t)n * d.hidden;
+        hipLaunchKernelGGL(pf_swiglu_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, p->HB, p->HB2, ne);
+        launch_gemm_vl<EPI_RESID>(ctx, L.w2, n, p->HB, d.hidden, p->X, d.dim, ctx->resid_scale);
+    }
+    GL3_HIP(hipGetLastError());
+    return GL3_OK;
+}
+
+// All layers for n tokens whose (token, sequence, position) are already on the device.  max_pos = largest position.
+// one_seq >= 0: all n tokens belong to that sequence at consecutive positions ending at max_pos (prefill).
+static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
+    gl3_prefill_state* p = ctx->pf;
+    if (p->vl) return pf_layers_vl(ctx, n, max_pos, one_seq);
+    const gl3_model_desc& d = ctx->d;
+    hipStream_t s = ctx->stream;
+    // tensor parallel: this rank's heads / hidden units / dim rows; activations that are gathered use the rank-chunked layout
+    const int rank = d.tp_rank, qd = ctx->q_dim_l, kvd = ctx->kv_dim_l;
+    const int hid = ctx->hidden_l, dml = ctx->dim_l;
+    const int qkv_dim = qd + 2 * kvd;
     const bool fused_decode = ctx->fused_attn_ok && max_pos < AF_MAXN && !(getenv("GL3_NO_FUSED_BD_ATTN") && atoi(getenv("GL3_NO_FUSED_BD_ATTN")));
     // small batch on one rank: the attention output and hb leave their kernels already quantised for the next GEMM (no
     // separate quantise launches; under tensor parallelism the f32 vectors are gathered first, so the launches stay)
@@ -887,55 +1050,10 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.attn_norm, d.rms_eps,
                            p->XQ, p->XS, p->maxk, bd_tslots(n));
         launch_gemm<EPI_STORE>(ctx, L.wqkv, nullptr, n, p->QKV, qkv_dim);
-        RopeArgs ra{};
-        ra.QKV = p->QKV; ra.qkv_stride = qkv_dim; ra.kcache = ctx->kcache + l * kv_layer; ra.vcache = ctx->vcache + l * kv_layer;
-        ra.cr = ctx->rope_cr; ra.ci = ctx->rope_ci; ra.qnorm = L.qnorm; ra.knorm = L.knorm; ra.bq = L.bq; ra.bk = L.bk; ra.bv = L.bv; ra.n_heads = H;
-        ra.n_kv_heads = KVH; ra.hs = d.head_size; ra.q_dim = qd; ra.kv_dim = kvd;
-        ra.arch = ctx->rope_arch; ra.eps = d.rms_eps; ra.seq = seq; ra.pos = pos; ra.seq_stride = ctx->kv_seq_stride;
-        PfAttnArgs aa{};
-        aa.Q = p->QKV; aa.q_stride = qkv_dim; aa.kcache = ra.kcache; aa.vcache = ra.vcache; aa.att = p->ATT; aa.out = AOr;
-        aa.out_stride = qd; aa.n_heads = H; aa.n_kv_heads = KVH; aa.hs = d.head_size; aa.kv_dim = kvd;
-        aa.ctx = d.ctx; aa.seq = seq; aa.pos = pos; aa.seq_stride = ctx->kv_seq_stride; aa.att_mul = ctx->att_mul;
-        const int nsplit = (max_pos + 1 + ATT_TT - 1) / ATT_TT;
-        const int hs = d.head_size;
-        if (one_seq < 0 && fused_decode) {
-            // static-batched decode at positions < AF_MAXN: RoPE + KV write + scores + softmax + weighted V sum of every
-            // (token, head) in ONE launch (attn_head_kernel, grid = heads x tokens) instead of three per-token-grid kernels
-            AttnArgs ha{};
-            ha.qkv = p->QKV; ha.qkv_stride = qkv_dim; ha.kcache = ra.kcache; ha.vcache = ra.vcache; ha.rope_cr = ctx->rope_cr; ha.rope_ci = ctx->rope_ci;
-            ha.qnorm = L.qnorm; ha.knorm = L.knorm; ha.bq = L.bq; ha.bk = L.bk; ha.bv = L.bv; ha.dyn = ctx->dyn; ha.att = nullptr;
-            ha.xb = AOr; ha.xb_stride = qd; ha.n_heads = H; ha.n_kv_heads = KVH; ha.hs = hs; ha.q_dim = qd; ha.kv_dim = kvd; ha.ctx = d.ctx;
-            ha.eps = d.rms_eps; ha.arch = ctx->rope_arch; ha.att_mul = ctx->att_mul; ha.seqv = seq; ha.posv = pos; ha.seq_stride = ctx->kv_seq_stride;
-            ha.group = bd_group;
-            if (fuse_q) { ha.xq_out = p->XQ; ha.xs_out = p->XS; ha.xq_slots = bd_tslots(n); }
-            hipLaunchKernelGGL(attn_head_kernel, dim3(H / bd_group, n), dim3(256), attn_head_smem(hs, bd_group), s, ha);
-        } else {
-        hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(H + KVH, n), dim3(64), 0, s, ra);
-        const bool tiled = one_seq >= 0 && kvmul <= 4 && (hs == 32 || hs == 64 || hs == 128) && (size_t)(max_pos + 1) * 4 <= 60 * 1024;
-        if (tiled) {
-            const int pos0 = max_pos + 1 - n, ntt = (n + PA_TB - 1) / PA_TB;
-            const size_t sms = (size_t)64 * (hs + 4) * 4;
-            const dim3 g1(nsplit, KVH, ntt), b1(64 * kvmul);
-            const float* kc1 = aa.kcache + (size_t)one_seq * ctx->kv_seq_stride;
-#define GL3_SCORES(HS_) hipLaunchKernelGGL((pf_scores_tiled_kernel<HS_>), g1, b1, sms, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul)
-            if (hs == 128) GL3_SCORES(128);
-            else if (hs == 64) GL3_SCORES(64);
-            else GL3_SCORES(32);
-#undef GL3_SCORES
-            const int npad = (max_pos + 1 + 63) & ~63;
-            int wpw = (int)((60 * 1024) / ((size_t)npad * 4));
-            wpw = wpw > 4 ? 4 : wpw;
-            hipLaunchKernelGGL(pf_softmax_kernel, dim3((n * H + wpw - 1) / wpw), dim3(256), (size_t)wpw * npad * 4, s, aa, n, wpw, npad);
-            if (hs > 64) hipLaunchKernelGGL((pf_pv_tiled_kernel<2>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
-            else hipLaunchKernelGGL((pf_pv_tiled_kernel<1>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
-        } else {
-            const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
-            hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, KVH, n), dim3(64 * kvmul), sm1, s, aa);
-            hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(H * ((d.head_size + 63) / 64), n), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
-        }
-        }
+        const bool quantised_ao = fuse_q && one_seq < 0 && fused_decode;
+        pf_attention(ctx, l, n, max_pos, one_seq, AOr, quantised_ao);
         if ((r = gl3_all_gather(ctx, GB_PF_AO, (size_t)n * qd)) != GL3_OK) return r;
-        if (!(fuse_q && one_seq < 0 && fused_decode))
+        if (!quantised_ao)
             hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN>), dim3(n, (ctx->q_dim / 4 + 255) / 256), dim3(256), 0, s, p->AO, ctx->q_dim, qd, (const float*)nullptr,
                                0.f, p->XQ, p->XS, p->maxk, bd_tslots(n));
         launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, Xr, dml, ctx->resid_scale);
@@ -1019,11 +1137,17 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
         int32_t rr = pf_layers(ctx, n, mp, -1);
         if (rr != GL3_OK) return rr;
         const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
+        if (p->vl) {
+            hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM_F32>), dim3(n), dim3(256), nq, s, p->X, d.dim, d.dim, ctx->out_norm, d.rms_eps, (uint8_t*)nullptr, p->XN, 0, 0);
+            launch_gemm_vl<EPI_STORE>(ctx, ctx->wcls, n, p->XN, d.dim, p->LOGITS, d.vocab, ctx->logit_scale);
+        } else {
         hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk, bd_tslots(n));
         // vocab rows are split across ranks: this rank's logits are the chunk [n][vocab / tp] of the rank-chunked buffer
         launch_gemm<EPI_STORE>(ctx, ctx->wcls, nullptr, n, p->LOGITS + (size_t)d.tp_rank * n * vl, vl, ctx->logit_scale);
+        }
         if ((rr = gl3_all_gather(ctx, GB_PF_LOGITS, (size_t)n * vl)) != GL3_OK) return rr;
-        hipLaunchKernelGGL(pf_argmax_rows_kernel, dim3(n), dim3(1024), 0, s, p->LOGITS, d.vocab, p->amax, vl);
+        hipLaunchKernelGGL(pf_argmax_part_kernel, dim3(AMX_SPLIT, n), dim3(256), 0, s, p->LOGITS, d.vocab, vl, p->amx_v, p->amx_i);
+        hipLaunchKernelGGL(pf_argmax_fold_kernel, dim3(n), dim3(64), 0, s, p->amx_v, p->amx_i, p->amax);
         return GL3_OK;
     };
     // ~400 launches per step: replay them as one hipGraph per batch size.  Nothing position-dependent is baked in when every
@@ -1062,7 +1186,7 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
 int32_t gl3_prefill_profile(gl3_ctx* ctx, int klass, int n, int iters, double* out_us, uint64_t* int8_ops) {
     gl3_prefill_state* p = ctx->pf;
     const gl3_model_desc& d = ctx->d;
-    if (!p) GL3_FAIL(GL3_E_UNSUPPORTED, "batched prefill needs max_batch > 1 and Q8_0 weights");
+    if (!p || p->vl) GL3_FAIL(GL3_E_UNSUPPORTED, "the int8 GEMM profile needs max_batch > 1 and Q8_0 weights with the int8 activation");
     if (n < 1 || n > p->max_batch) GL3_FAIL(GL3_E_ARG, "token count outside 1..max_batch");
     GL3_HIP(hipSetDevice(d.device));
     const int qkv_dim = ctx->q_dim_l + 2 * ctx->kv_dim_l;

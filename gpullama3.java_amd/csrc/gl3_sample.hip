@@ -156,8 +156,7 @@ static int topp_sample(const float* p, int n, float topp, float coin, std::vecto
     return idx[last];
 }
 
-int32_t gl3_sample_alloc(gl3_ctx* ctx) {
-    if (ctx->sm_probs) return GL3_OK;
+static int32_t sample_alloc_all(gl3_ctx* ctx) {
     const int nchunks = (ctx->d.vocab + SM_CHUNK - 1) / SM_CHUNK;
     GL3_HIP(hipMalloc((void**)&ctx->sm_probs, (size_t)ctx->d.vocab * 4));
     GL3_HIP(hipMalloc((void**)&ctx->sm_aux, (size_t)(SM_BLOCKS + nchunks + 8) * 4));
@@ -165,6 +164,16 @@ int32_t gl3_sample_alloc(gl3_ctx* ctx) {
     GL3_HIP(hipFuncSetAttribute((const void*)smp_seqsum_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)smp_seqsum_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     return GL3_OK;
+}
+
+// All three buffers or none: a partial allocation (out of memory half way) is released, so the next call starts over instead of
+// launching kernels on null pointers.
+int32_t gl3_sample_alloc(gl3_ctx* ctx) {
+    if (ctx->sm_probs && ctx->sm_aux && ctx->h_probs) return GL3_OK;
+    gl3_sample_free(ctx);
+    const int32_t r = sample_alloc_all(ctx);
+    if (r != GL3_OK) gl3_sample_free(ctx);
+    return r;
 }
 
 void gl3_sample_free(gl3_ctx* ctx) {
@@ -189,9 +198,11 @@ int32_t gl3_sample_run(gl3_ctx* ctx, const float* logits_dev, float temperature,
     hipLaunchKernelGGL(smp_exp_kernel, dim3(SM_BLOCKS), dim3(256), 0, s, ctx->sm_probs, n, blockmax, SM_BLOCKS);
     hipLaunchKernelGGL(smp_seqsum_kernel<false>, dim3(1), dim3(256), smem, s, ctx->sm_probs, n, total, chunk_end, 0.f, picked);
     hipLaunchKernelGGL(smp_div_kernel, dim3(SM_BLOCKS), dim3(256), 0, s, ctx->sm_probs, n, total);
+    GL3_HIP(hipGetLastError());
     const bool use_topp = topp > 0.f && topp < 1.f;                  // Sampler.java:88-98
     if (!use_topp) {
         hipLaunchKernelGGL(smp_seqsum_kernel<true>, dim3(1), dim3(256), smem, s, ctx->sm_probs, n, (float*)nullptr, chunk_end, coin, picked);
+        GL3_HIP(hipGetLastError());
         GL3_HIP(hipMemcpyAsync(ctx->h_argmax, picked, sizeof(int), hipMemcpyDeviceToHost, s));
         GL3_HIP(hipStreamSynchronize(s));
         *token_out = *ctx->h_argmax;

@@ -78,14 +78,19 @@ class HipMasterPlan:
         except Exception:
             self.freeTornadoExecutionPlan()
             raise
-        self._logits = np.empty(c.vocab, np.float32)
         self._arg = C.c_int32()
         self._pin_logits()
 
     def _pin_logits(self):
-        # the logits buffer is reused on every step: page-lock it once so the D2H copy lands in it directly
+        """The logits buffer is reused on every step: page-lock it once so the D2H copy lands in it directly.  Registration pins
+        whole pages, so the buffer is an anonymous mapping of its own (page-aligned, padded to whole pages) — never a slice
+        of the C heap, whose pages it would share with unrelated allocations."""
+        import mmap
+        nbytes = (self.cfg.vocab * 4 + 4095) & ~4095
+        self._logits_map = mmap.mmap(-1, nbytes)
+        self._logits = np.frombuffer(self._logits_map, np.float32, self.cfg.vocab)
         try:
-            hip.check(hip.lib().gl3_pin_host_buffer(self._ctx, _p(self._logits), self._logits.nbytes), self._ctx)
+            hip.check(hip.lib().gl3_pin_host_buffer(self._ctx, _p(self._logits), nbytes), self._ctx)
         except hip.Gl3Error:
             pass                                      # not fatal: the plan falls back to its own staging buffer
 
@@ -121,7 +126,6 @@ class HipMasterPlan:
         self._ctx = C.c_void_p()
         hip.check_gguf(L.gl3_load_gguf(path.encode(), C.byref(opts), C.byref(self._ctx)))
         self.tp_size, self.tp_rank, self.max_batch = 1, 0, prefill_batch_size
-        self._logits = np.empty(self.cfg.vocab, np.float32)
         self._arg = C.c_int32()
         self._pin_logits()
         return self

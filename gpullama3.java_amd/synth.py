@@ -76,6 +76,8 @@ CONFIGS = {
     # Phi-3 shape: fused attn_qkv / gate|up tensors, NeoX RoPE, multi-head attention (Phi-3-mini: 32 / 32 heads)
     "tiny-phi3": ModelConfig("tiny-phi3-random", ARCH_PHI3, 256, 512, 2, 8, 8, 32, 512, 64, 1e-5, 10000.0, False),
     "mid-phi3": ModelConfig("mid-phi3-random", ARCH_PHI3, 1536, 4096, 2, 12, 4, 128, 2048, 160, 1e-5, 10000.0, False),
+    # Phi-3-mini / Phi-3.5-mini head layout: head_size = dim / heads = 96 (not a power of two), multi-head attention
+    "phi3-hs96": ModelConfig("phi3-hs96-random", ARCH_PHI3, 768, 2048, 2, 8, 8, 96, 1024, 160, 1e-5, 10000.0, False),
     "mha-llama": ModelConfig("mha-llama-random", ARCH_LLAMA, 1024, 2048, 2, 8, 8, 128, 1024, 160, 1e-5, 10000.0, False),
     # full-size SHAPES of the BASELINE models with few layers / a small vocabulary, so that the CPU oracle finishes in seconds:
     # one Llama-3-8B layer (K = 14336: 112 tile groups, activation quads == 14 * 256 exactly), the 128256-row vocabulary

@@ -203,7 +203,9 @@ GL3_API int32_t gl3_get_sample_probs(gl3_ctx* ctx, float* out);
 
 /* Optional: page-lock a caller-owned host buffer (e.g. the MemorySegment the Java shim passes as logits_out on every step) so
  * that gl3_forward_decode copies the logits straight into it instead of going through the plan's pinned staging buffer and a
- * host memcpy.  The buffer must stay allocated until gl3_unpin_host_buffer / gl3_destroy. */
+ * host memcpy.  The buffer must stay allocated until gl3_unpin_host_buffer / gl3_destroy.  `ptr` and `bytes` must be multiples
+ * of 4096: registration pins and maps whole pages, so the buffer has to own its pages (mmap / posix_memalign /
+ * Arena.allocate(bytes, 4096) with the size rounded up); anything else returns GL3_E_ARG and the plan keeps staging. */
 GL3_API int32_t gl3_pin_host_buffer(gl3_ctx* ctx, void* ptr, uint64_t bytes);
 GL3_API int32_t gl3_unpin_host_buffer(gl3_ctx* ctx, void* ptr);
 

@@ -73,7 +73,7 @@ def to_q8_0(x):
     scale = (max_abs / F32(127.0)).astype(F32)
     with np.errstate(divide="ignore"):
         inv = np.where(scale != 0, F32(1.0) / scale, F32(0)).astype(F32)
-    q = np.floor((xb * inv[:, None]).astype(F32) + F32(0.5))       # Math.round(float)
+    q = np.floor((xb * inv[:, None]).astype(F32).astype(np.float64) + 0.5)       # Math.round(float): floor(a + 1/2), the sum exact
     q = np.clip(q, -128, 127).astype(np.int8)
     out = np.empty((xb.shape[0], 34), np.uint8)
     out[:, :2] = scale.astype(np.float16).view(np.uint8).reshape(-1, 2)

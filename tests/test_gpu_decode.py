@@ -55,7 +55,8 @@ def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed, wtype, scala
     plan.freeTornadoExecutionPlan()
 
 
-@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "tiny-llama-tied", "tiny-qwen2", "mid-qwen2", "mha-llama", "tiny-granite", "mid-granite", "tiny-phi3", "mid-phi3"])
+@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "tiny-llama-tied", "tiny-qwen2", "mid-qwen2", "mha-llama", "tiny-granite", "mid-granite", "tiny-phi3", "mid-phi3",
+                                 "phi3-hs96"])      # head_size 96 = Phi-3-mini's dim / heads (not a power of two)
 def test_decode_matches_c_oracle_live(pkg, orc, planmod, cfg):
     """Shapes with full 64-block chunks, ragged chunk tails (K = 2560), head sizes 32/64/128, tied wcls, and multi-head
     attention (kvMul = 1 with head_size 128: the KV write must cover head_size > 64 * kvMul)."""
@@ -145,7 +146,7 @@ def test_graph_and_eager_launches_agree_bitwise(pkg, orc, planmod):
     a.freeTornadoExecutionPlan(); b.freeTornadoExecutionPlan()
 
 
-@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "mid-qwen2", "mha-llama", "mid-granite"])   # head sizes 64 / 128, kvMul 4 / 6 / 1
+@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "mid-qwen2", "mha-llama", "mid-granite", "phi3-hs96"])   # head sizes 64 / 128 / 96, kvMul 4 / 6 / 1
 def test_fused_short_context_attention_and_the_handover_at_128(pkg, orc, planmod, cfg):
     """Positions < 128 run attn_head_kernel (one launch per layer, one workgroup per query head), later ones the scores +
     softmax/PV pair; both must reproduce the oracle bit for bit, also across the handover, and agree with each other."""
@@ -206,15 +207,15 @@ def test_error_behaviour(pkg, planmod):
         plan_mod.HipMasterPlan(m4)                            # F32 matrices: GL3_E_UNSUPPORTED (Q8_0 / F16 / Q4_0 only)
     assert e.value.code == -2
     m5 = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], wtype=2, seed=7)
-    plan = plan_mod.HipMasterPlan(m5, prefill_batch_size=8, n_seqs=2)
-    with pytest.raises(hip.Gl3Error) as e:                    # static batched decode is a Q8_0 (int8 MFMA) feature
+    plan = plan_mod.HipMasterPlan(m5, prefill_batch_size=8, n_seqs=2, flags=hip.FLAG_SCALAR_DOT)
+    with pytest.raises(hip.Gl3Error) as e:                    # the scalar dot order has no batched path (one K-long chain per row)
         plan.forward_decode_batch([1, 2], [0, 1], [0, 0])
     assert e.value.code == -2
     plan.freeTornadoExecutionPlan()
 
 
 @pytest.mark.parametrize("cfg,batch,chunks", [("tiny-llama", 8, [8, 8, 5]), ("mid-llama", 64, [40, 64, 3]), ("mid-qwen3", 32, [30, 7]), ("mid-qwen2", 64, [50, 9]), ("mid-granite", 64, [33, 20]), ("mid-phi3", 64, [41, 6]),
-                                             ("tiny-llama-tied", 512, [37])])
+                                             ("tiny-llama-tied", 512, [37]), ("phi3-hs96", 64, [50, 14])])
 def test_batched_prefill_is_bit_identical_to_the_cpu_path(pkg, orc, planmod, cfg, batch, chunks):
     """tornadoVMForwardBatchPrefill (MFMA int8 GEMM path) vs batchForwardJavaPrefill: same KV cache, same x of the
     last token, and the decode step that follows returns the same logits — all bit for bit.  Ragged chunk sizes
@@ -243,7 +244,67 @@ def test_batched_prefill_is_bit_identical_to_the_cpu_path(pkg, orc, planmod, cfg
     plan.freeTornadoExecutionPlan()
 
 
-@pytest.mark.parametrize("cfg,nseq", [("tiny-qwen3", 5), ("mid-llama", 3), ("mid-granite", 4)])
+@pytest.mark.parametrize("cfg,wtype,f32act,batch,chunks", [("mid-llama", 1, False, 64, [40, 23, 3]), ("mid-llama", 2, False, 64, [40, 23, 3]),
+                                                          ("mid-qwen3", 1, False, 32, [30, 7]), ("mid-qwen3", 2, False, 32, [17, 20]),
+                                                          ("mid-llama", 8, True, 64, [33, 31]), ("mid-qwen2", 8, True, 16, [16, 5]),
+                                                          ("tiny-llama-tied", 1, False, 512, [37]), ("mid-granite", 2, False, 64, [35, 2]),
+                                                          ("mid-phi3", 1, False, 64, [64, 1])])
+def test_batched_prefill_of_the_f32_activation_types(pkg, orc, planmod, cfg, wtype, f32act, batch, chunks):
+    """SURVEY 8 a15 for F16 / Q4_0 / Q8_0-with-f32-activation: tornadoVMForwardBatchPrefill on the Vector-API-order GEMMs
+    (gl3_prefill_vl.h: f32 MFMA FMA chains for F16, VALU for the block formats) vs batchForwardJavaPrefill of the oracle in the same
+    mode: x of the last token, KV rows and the decode steps that follow, bit for bit; ragged chunks at non-zero start positions."""
+    plan_mod, hip = planmod
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=35)
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=batch, flags=hip.FLAG_F32_ACTIVATION if f32act else 0)
+    o = orc.COracle(m, vector_bits=256, f32_activation=f32act)
+    n = sum(chunks)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, n + 2)
+    pos = 0
+    for c in chunks:
+        plan.tornadoVMForwardBatchPrefill(toks[pos:pos + c], pos)
+        o.prefill(toks[pos:pos + c], pos)
+        pos += c
+        assert np.array_equal(plan.x(), o.x()), (pos, rel(plan.x(), o.x()))
+    for l in range(m.cfg.n_layers):
+        for p in (0, 1, n // 2, n - 1):
+            k, v = plan.kv(l, p)
+            ko, vo = o.kv(l, p)
+            assert np.array_equal(k, ko) and np.array_equal(v, vo), (l, p)
+    for i in range(2):
+        assert np.array_equal(plan.tornadoVMForwardDecode(toks[n + i], n + i), o.forward(toks[n + i], n + i))
+    plan.freeTornadoExecutionPlan()
+
+
+@pytest.mark.parametrize("cfg,wtype,f32act,nseq", [("mid-llama", 1, False, 3), ("mid-llama", 2, False, 5), ("mid-qwen3", 8, True, 3), ("tiny-llama-tied", 1, False, 17)])
+def test_static_batched_decode_of_the_f32_activation_types(pkg, orc, planmod, cfg, wtype, f32act, nseq):
+    """gl3_forward_decode_batch for F16 / Q4_0 / Q8_0-with-f32-activation: n sequences advance one token per step through the
+    Vector-API-order GEMMs; logits and greedy ids of every sequence equal its own oracle run."""
+    plan_mod, hip = planmod
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=45)
+    plan = plan_mod.HipMasterPlan(m, prefill_batch_size=max(16, nseq), n_seqs=nseq, flags=hip.FLAG_F32_ACTIVATION if f32act else 0)
+    oracles = [orc.COracle(m, vector_bits=256, f32_activation=f32act) for _ in range(nseq)]
+    rng = np.random.default_rng(5)
+    lens = [2 + (i % 4) for i in range(nseq)]
+    for s_ in range(nseq):
+        prompt = rng.integers(0, m.cfg.vocab, lens[s_]).tolist()
+        plan.prefill_seq(s_, prompt, 0)
+        oracles[s_].prefill(prompt, 0)
+    cur = [int(rng.integers(0, m.cfg.vocab)) for _ in range(nseq)]
+    pos = list(lens)
+    for step in range(3):
+        order = list(range(nseq))
+        if step % 2:
+            order.reverse()
+        logits, ids = plan.forward_decode_batch([cur[s_] for s_ in order], order, [pos[s_] for s_ in order])
+        for row, s_ in enumerate(order):
+            ref = oracles[s_].forward(cur[s_], pos[s_])
+            assert np.array_equal(logits[row], ref), (step, s_)
+            assert ids[row] == orc.argmax(ref)
+            cur[s_], pos[s_] = int(ids[row]), pos[s_] + 1
+    plan.freeTornadoExecutionPlan()
+
+
+@pytest.mark.parametrize("cfg,nseq", [("tiny-qwen3", 5), ("mid-llama", 3), ("mid-granite", 4), ("phi3-hs96", 3)])
 def test_static_batched_decode_matches_independent_cpu_runs(pkg, orc, planmod, cfg, nseq):
     """BASELINE config 5 shape of work: n independent sequences (own KV caches, different prompt lengths) advance one
     token per step through ONE batched GEMM pass; every sequence's logits must equal its own CPU run bit for bit."""
