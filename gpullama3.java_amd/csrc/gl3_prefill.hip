@@ -287,15 +287,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
         const uint8_t* Bq = base + GM_KB * 2 * AROWS * 16 + GM_KB * AROWS * 4;
         const float* Bs = reinterpret_cast<const float*>(Bq + GM_KB * 2 * TOK * 16);
         // operand fragments of one Q8_0 block for this wavefront
-        struct Frag { v4i_t bf[TF]; v2f_t xsc[TF]; v4i_t af[NF]; v2f_t wsf[NF][8]; };
+        // MFMA_SCALES (single-fragment variants: wo / down at 512 tokens): the scale products wScale * aScale of the 32 x 32 tile
+        // come from the MATRIX pipe: one v_mfma_f32_32x32x2_f32 with A = wScale (k = 0 | 0), B = aScale (k = 0 | 0), C = 0 gives
+        // D[i][j] = fl(wScale_i * aScale_j) in the layout of the int8 tile — the f32 MFMA rounds once per step like fmaf
+        // (MI355X_MICROARCH.md), fma(0, 0, fl(w a)) = fl(w a), and both scales are >= +0 so no -0 arises.  The VALU keeps three
+        // operations per output and block (subtract, multiply, add) instead of four: down 145 -> 132 us, wo 46 -> 43 us at 512
+        // tokens.  With two or four fragments per wavefront the extra 64-cycle MFMAs sit in front of the dependent VALU work and
+        // the same change LOST time (gate/up 236 -> 275 us, qkv 73 -> 79 us), so those variants multiply on the VALU.
+        constexpr bool MFMA_SCALES = NF * TF == 1;
+        struct Frag { v4i_t bf[TF]; v2f_t xsc[TF]; v4i_t af[NF]; v2f_t wsf[NF][MFMA_SCALES ? 1 : 8]; };
         auto fload_a = [&](Frag& fr, int blk, int f) {
             const int lrow = NM == 2 ? f * RPM + wr * 32 : wr * (32 * RF) + f * 32;    // local row of this fragment
             fr.af[f] = *reinterpret_cast<const v4i_t*>(Aq + ((size_t)(blk * 2 + hi) * AROWS + lrow + tl) * 16);
+            if constexpr (MFMA_SCALES) {
+                const float w = As[blk * AROWS + lrow + tl];
+                fr.wsf[f][0] = v2f_t{hi ? 0.f : w, 0.f};        // A operand: lane = row in k = 0, zeros in k = 1
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 w4 = *reinterpret_cast<const float4*>(As + blk * AROWS + lrow + 8 * q + 4 * hi);
-                fr.wsf[f][2 * q] = v2f_t{w4.x, w4.y};
-                fr.wsf[f][2 * q + 1] = v2f_t{w4.z, w4.w};
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(As + blk * AROWS + lrow + 8 * q + 4 * hi);
+                    fr.wsf[f][2 * q] = v2f_t{w4.x, w4.y};
+                    fr.wsf[f][2 * q + 1] = v2f_t{w4.z, w4.w};
+                }
             }
         };
         auto fload = [&](Frag& fr, int blk, bool with_a) {
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
                 const int tk = wc * (32 * TF) + tf * 32 + tl;
                 fr.bf[tf] = *reinterpret_cast<const v4i_t*>(Bq + ((size_t)(blk * 2 + hi) * TOK + (tk ^ (blk * 2 + hi))) * 16);
                 const float x = Bs[blk * TOK + tk];
-                fr.xsc[tf] = v2f_t{x, x};
+                fr.xsc[tf] = MFMA_SCALES ? v2f_t{hi ? 0.f : x, 0.f} : v2f_t{x, x};
             }
             if (with_a) {
 #pragma unroll
@@ -327,8 +340,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void pf_gemm_kernel(const
 #pragma unroll
                     for (int r = 0; r < 8; ++r)
                         cf[r] = v2f_t{__int_as_float(c[tf][2 * r]), __int_as_float(c[tf][2 * r + 1])} - v2f_t{12582912.f, 12582912.f};
+                    if constexpr (MFMA_SCALES) {
+                        const v16f_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        const v16f_t p16 = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.wsf[f][0][0], fr.xsc[tf][0], zero16, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) pr[r] = fr.wsf[f][r] * fr.xsc[tf];
+                        for (int r = 0; r < 8; ++r) pr[r] = v2f_t{p16[2 * r], p16[2 * r + 1]};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) pr[r] = fr.wsf[f][r] * fr.xsc[tf];
+                    }
 #pragma unroll
                     for (int r = 0; r < 8; ++r) cf[r] = cf[r] * pr[r];       // isum * (wScale * aScale)
 #pragma unroll
