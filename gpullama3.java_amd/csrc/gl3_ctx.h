@@ -82,6 +82,8 @@ struct gl3_ctx {
     // derived (local = this tensor-parallel rank's share)
     int q_dim = 0, kv_dim = 0, heads_l = 0, kv_heads_l = 0, q_dim_l = 0, kv_dim_l = 0, hidden_l = 0, vocab_l = 0, dim_l = 0;
     int n_tsplit = 1;        // ceil(ctx / 64) score tiles
+    bool wo_replicated = false;   // tensor parallel: every rank holds all rows of Wo (3 gathers per layer instead of 4)
+    int wo_rows = 0;              // rows of Wo held by this rank: dim (replicated) or dim / tp
     // Granite (InferenceCore.forwardGranite): embedding / residual / logit multipliers (1 otherwise) and the score multiplier
     // (0 = divide by sqrt(head_size)); rope_arch = RoPE / per-head-norm flavour of the kernels (0 adjacent pairs, 1 qwen3, 2 NeoX)
     float emb_scale = 1.f, resid_scale = 1.f, logit_scale = 1.f, att_mul = 0.f;

@@ -1076,8 +1076,18 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         if (!quantised_ao)
             hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN>), dim3(n, (ctx->q_dim / 4 + 255) / 256), dim3(256), 0, s, p->AO, ctx->q_dim, qd, (const float*)nullptr,
                                0.f, p->XQ, p->XS, p->maxk, bd_tslots(n));
-        launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, Xr, dml, ctx->resid_scale);
-        if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
+        if (ctx->wo_replicated) {
+            // every rank holds all of Wo: one GEMM per rank chunk of the rank-chunked X (rows [c dml, (c + 1) dml) -> chunk c), no gather
+            for (int c = 0; c < d.tp_size; ++c) {
+                Q8Mat sub = L.wo;
+                sub.rows = dml; sub.nstrips = (dml + 15) / 16;
+                sub.w = L.wo.w + (size_t)(c * dml / 16) * L.wo.ng * TILE_BYTES;
+                launch_gemm<EPI_RESID>(ctx, sub, nullptr, n, p->X + (size_t)c * n * dml, dml, ctx->resid_scale);
+            }
+        } else {
+            launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, Xr, dml, ctx->resid_scale);
+            if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
+        }
         hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.ffn_norm, d.rms_eps,
                            p->XQ, p->XS, p->maxk, bd_tslots(n));
         if (fuse_q) {
@@ -1215,7 +1225,7 @@ int32_t gl3_prefill_profile(gl3_ctx* ctx, int klass, int n, int iters, double* o
             gl3_layer& L = ctx->layers[l];
             switch (klass) {
             case GL3_K_MATVEC_QKV: launch_gemm<EPI_STORE>(ctx, L.wqkv, nullptr, n, p->QKV, qkv_dim); break;
-            case GL3_K_MATVEC_WO: launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, p->X, ctx->dim_l); break;
+            case GL3_K_MATVEC_WO: launch_gemm<EPI_RESID>(ctx, L.wo, nullptr, n, p->X, ctx->wo_rows); break;
             case GL3_K_MATVEC_GATEUP: launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, p->HB, ctx->hidden_l); break;
             default: launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, p->X, ctx->dim_l); break;
             }

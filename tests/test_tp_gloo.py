@@ -83,11 +83,11 @@ def _worker(rank, world, port, cfg_name, out_q):
                 att[h * hs:(h + 1) * hs] = onp.seq_sum(a[:, None] * vc[l, :pos + 1, (h // kvmul) * hs:(h // kvmul + 1) * hs], axis=0)
             xb_full = gather(att)                                                        # all-gather 1
             dl = cfg.dim // world
-            x = gather(x[rank * dl:(rank + 1) * dl] + mm(p + "attn_output.weight", xb_full, cfg.q_dim))   # all-gather 2
+            x = x + mm(p + "attn_output.weight", xb_full, cfg.q_dim)                      # Wo is replicated: every rank, all rows, no gather
             xb = onp.rmsnorm(x, onp.dequant(tensors[p + "ffn_norm.weight"][0], 0, cfg.dim), cfg.rms_eps)
             g, u = mm(p + "ffn_gate.weight", xb, cfg.dim), mm(p + "ffn_up.weight", xb, cfg.dim)
-            hb = gather(((g / (1.0 + np.exp(-g.astype(np.float64))).astype(np.float32)) * u).astype(np.float32))   # all-gather 3
-            x = gather(x[rank * dl:(rank + 1) * dl] + mm(p + "ffn_down.weight", hb, cfg.hidden))   # all-gather 4
+            hb = gather(((g / (1.0 + np.exp(-g.astype(np.float64))).astype(np.float32)) * u).astype(np.float32))   # all-gather 2
+            x = gather(x[rank * dl:(rank + 1) * dl] + mm(p + "ffn_down.weight", hb, cfg.hidden))   # all-gather 3
         xn = onp.rmsnorm(x, onp.dequant(tensors["output_norm.weight"][0], 0, cfg.dim), cfg.rms_eps)
         logits_all.append(gather(mm("output.weight", xn, cfg.dim)))
     if rank == 0:
@@ -121,7 +121,8 @@ def test_partition_table_matches_library_rules(pkg):
     c = pkg.synth.CONFIGS["llama-3-8b"]
     for n in (1, 2, 4, 8):
         s = [tp.row_slices(c, n, r) for r in range(n)]
-        for name, full in (("attn_q.weight", c.q_dim), ("attn_k.weight", c.kv_dim), ("attn_output.weight", c.dim),
+        assert all(x["attn_output.weight"] == (0, c.dim) for x in s)              # replicated
+        for name, full in (("attn_q.weight", c.q_dim), ("attn_k.weight", c.kv_dim),
                            ("ffn_gate.weight", c.hidden), ("ffn_down.weight", c.dim), ("output.weight", c.vocab)):
             assert sum(x[name][1] for x in s) == full and all(x[name][0] % 16 == 0 for x in s)
             assert [x[name][0] for x in s] == [r * full // n for r in range(n)]
@@ -186,4 +187,4 @@ def test_chunked_layout_round_trip(pkg):
         assert np.array_equal(tp.from_chunked(flat, n, 7, 24), x)
         assert all(flat[tp.chunked_index(b, j, 24 // n, 7)] == x[b, j] for b in range(7) for j in range(24))
     c = pkg.synth.CONFIGS["llama-3-8b"]
-    assert tp.prefill_gather_points(c, 8, 512) == [("AO", 512 * 512), ("X", 512 * 512), ("HB", 512 * 1792), ("X", 512 * 512)]
+    assert tp.prefill_gather_points(c, 8, 512) == [("AO", 512 * 512), ("HB", 512 * 1792), ("X", 512 * 512)]

@@ -1,8 +1,9 @@
 """TEST HELPER — tensor-parallel partition of the forward pass (a Python description of what gl3_create / gl3_upload_tensor do,
 used only by tests/test_tp_gloo.py to check the scheme on CPU over gloo; the product code is csrc/gl3_api.hip).
 
-Every matrix is split by OUTPUT rows so that each dot product stays whole and in the reference's order on one
-rank (bit-identical results); activations are re-assembled with all-gathers.  The same table drives the C++
+Every matrix except Wo is split by OUTPUT rows so that each dot product stays whole and in the reference's order on one
+rank (bit-identical results); activations are re-assembled with all-gathers.  Wo (attn_output) is REPLICATED: every rank
+computes the whole projection from the gathered attention output, so no gather follows it (3 per layer: xb, hb, x).  The same table drives the C++
 upload slicing (csrc/gl3_api.hip: gl3_upload_tensor) and the CPU test of the scheme (tests/test_tp_gloo.py).
 """
 from __future__ import annotations
@@ -24,7 +25,8 @@ def row_slices(cfg, tp: int, rank: int) -> dict:
     hl, dl, vl = cfg.hidden // tp, cfg.dim // tp, cfg.vocab // tp
     return {
         "attn_q.weight": (rank * ql, ql), "attn_k.weight": (rank * kvl, kvl), "attn_v.weight": (rank * kvl, kvl),
-        "attn_output.weight": (rank * dl, dl), "ffn_gate.weight": (rank * hl, hl), "ffn_up.weight": (rank * hl, hl),
+        "attn_output.weight": (0, cfg.dim),        # replicated
+        "ffn_gate.weight": (rank * hl, hl), "ffn_up.weight": (rank * hl, hl),
         "ffn_down.weight": (rank * dl, dl), "output.weight": (rank * vl, vl),
     }
 
@@ -32,7 +34,7 @@ def row_slices(cfg, tp: int, rank: int) -> dict:
 # all-gather points of one layer, in order: (buffer, floats per rank)
 def gather_points(cfg, tp: int):
     hs = cfg.head_size
-    return [("xb", cfg.n_heads // tp * hs), ("x", cfg.dim // tp), ("hb", cfg.hidden // tp), ("x", cfg.dim // tp)]
+    return [("xb", cfg.n_heads // tp * hs), ("hb", cfg.hidden // tp), ("x", cfg.dim // tp)]
 
 
 # ---- batched prefill: rank-chunked activations (csrc/gl3_prefill.hip `chunked`) ----------------------------------------
@@ -59,5 +61,4 @@ def from_chunked(flat, tp: int, ntok: int, cols: int):
 def prefill_gather_points(cfg, tp: int, ntok: int):
     """all-gathers of one prefill layer: (buffer, floats per rank)."""
     hs = cfg.head_size
-    return [("AO", ntok * (cfg.n_heads // tp * hs)), ("X", ntok * (cfg.dim // tp)), ("HB", ntok * (cfg.hidden // tp)),
-            ("X", ntok * (cfg.dim // tp))]
+    return [("AO", ntok * (cfg.n_heads // tp * hs)), ("HB", ntok * (cfg.hidden // tp)), ("X", ntok * (cfg.dim // tp))]
