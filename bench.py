@@ -243,16 +243,17 @@ def main():
                                 "output per block beside each 32-cycle MFMA; MfmaUtil from rocprofv3 --pmc is in profiles/ (separate pass)",
                            gemms=pk, method="one HIP event pair around 3 sweeps x %d layers per GEMM class" % cfg.n_layers)
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read in-process; take the FETCH_SIZE figure of the
-    # committed rocprofv3 --pmc pass of this same command (profiles/rNN_pmc_fetch_summary.csv, x2 gfx950 correction)
+    # HBM traffic of the dominant kernel: PMC counters cannot be read in-process, so `traffic` stays null in this line.  The figure of
+    # the round's SEPARATE rocprofv3 --pmc FETCH_SIZE pass over this same command (profiles/rNN_pmc_fetch_summary.csv, x2 gfx950
+    # correction) is attached under a key that says so.
     try:
         import csv
         import glob
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_summary.csv")))[-1]
         for r in csv.reader(open(f)):
             if "matvec_q8t_kernel<0, 2" in r[0] and world == 1 and args.model == "llama-3-8b" and args.wtype == "q8_0":
-                roofline["traffic"] = int(r[-1])
-                roofline["traffic_source"] = os.path.relpath(f, ROOT) + " (FETCH_SIZE, separate rocprofv3 --pmc pass)"
+                roofline["traffic_not_measured_in_this_run"] = dict(bytes_per_launch=int(r[-1]), source=os.path.relpath(f, ROOT) +
+                                                                   " (FETCH_SIZE x 2, separate rocprofv3 --pmc pass of this command)")
     except Exception:
         pass
 

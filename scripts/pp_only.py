@@ -7,9 +7,10 @@ from importlib import import_module
 plan_mod = import_module(ge.PKG_NAME + ".plan")
 name = sys.argv[1] if len(sys.argv) > 1 else "llama-3-8b"
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+wtype = int(sys.argv[3]) if len(sys.argv) > 3 else 8          # ggml type of the matrices: 8 = Q8_0, 1 = F16, 2 = Q4_0
 base = pkg.synth.CONFIGS[name]
 cfg = pkg.synth.ModelConfig(**{**base.__dict__, "n_layers": nl, "vocab": 4096, "ctx": 648})
-m = pkg.synth.make_torch(cfg, seed=1, device="cuda")
+m = pkg.synth.make_torch(cfg, wtype=wtype, seed=1, device="cuda")
 plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=512)
 toks = pkg.javarand.bench_tokens(cfg.vocab, 512)
 plan.prefill(toks, 0)
