@@ -70,7 +70,10 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
                           const float* norm_w, float* out, const float* resid_in, float out_scale = 1.0f) {
     if (w.fmt != GL3_TYPE_Q8_0) {      // F16 / Q4_0: element-wise chains, one output row per lane (gl3_rowlane_kernels.h)
         hipStream_t s = ctx->stream;
-        if (pro == PRO_RMS) {
+        // Vector-order kernels normalise in their own prologue (matvec_vl_kernel<.., RMS>); GL3_VL_RMS=0: separate rmsnorm launch
+        static const bool vl_rms = env_flag("GL3_VL_RMS", true);
+        const bool fuse_rms = pro == PRO_RMS && w.vl && vl_rms && vl_rms_fusable(w.k) && epi != EPI_RESID;
+        if (pro == PRO_RMS && !fuse_rms) {
             const size_t sm = (size_t)(w.k + 32) * 4 + ss_scratch_bytes(w.k) + 64;
             hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3(1), dim3(256), sm, s, x, w.k, norm_w, ctx->d.rms_eps, ctx->xn);
             x = ctx->xn;
@@ -80,13 +83,38 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
             v.w = w.w; v.w2 = w2 ? w2->w : nullptr; v.rows = w.rows; v.k = w.k; v.x = x; v.out = out; v.resid_in = resid_in; v.out_scale = out_scale;
             const dim3 vg(((w.rows + 7) / 8 + VL_WAVES - 1) / VL_WAVES), vb(64 * VL_WAVES);
             const size_t vs = vl_smem_bytes(w.k);
+            if (fuse_rms) {
+                v.norm_w = norm_w; v.eps = ctx->d.rms_eps;
+                const dim3 rg(((w.rows + 7) / 8 + VL_RMS_WAVES - 1) / VL_RMS_WAVES), rb(64 * VL_RMS_WAVES);
+                const size_t rs = vl_rms_smem_bytes(w.k);
+#define GL3_VLR(WT_) \
+                do { \
+                    if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_STORE, true, VL_RMS_WAVES>), rg, rb, rs, s, v); \
+                    else hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_SWIGLU, true, VL_RMS_WAVES>), rg, rb, rs, s, v); \
+                } while (0)
+                if (w.fmt == GL3_TYPE_F16) GL3_VLR(WT_F16); else if (w.fmt == GL3_FMT_Q8V) GL3_VLR(WT_Q8_0); else GL3_VLR(WT_Q4_0);
+#undef GL3_VLR
+                return;
+            }
 #define GL3_VL(WT_) \
             do { \
                 if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_STORE>), vg, vb, vs, s, v); \
                 else if (epi == EPI_RESID) hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_RESID>), vg, vb, vs, s, v); \
                 else hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_SWIGLU>), vg, vb, vs, s, v); \
             } while (0)
-            if (w.fmt == GL3_TYPE_F16) GL3_VL(WT_F16); else if (w.fmt == GL3_FMT_Q8V) GL3_VL(WT_Q8_0); else GL3_VL(WT_Q4_0);
+            // Q4_0 / Q8_0-f32act: four wavefronts split K of one 8-row group (matvec_vlq_kernel); GL3_VLQ=0 keeps the one-wavefront kernel
+            static const bool ksplit = env_flag("GL3_VLQ", true);
+#define GL3_VLQ(WT_) \
+            do { \
+                const dim3 qg((w.rows + 7) / 8), qb(64 * VQ_WAVES); \
+                if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_vlq_kernel<WT_, EPI_STORE>), qg, qb, vq_smem_bytes<WT_>(1), s, v); \
+                else if (epi == EPI_RESID) hipLaunchKernelGGL((matvec_vlq_kernel<WT_, EPI_RESID>), qg, qb, vq_smem_bytes<WT_>(1), s, v); \
+                else hipLaunchKernelGGL((matvec_vlq_kernel<WT_, EPI_SWIGLU>), qg, qb, vq_smem_bytes<WT_>(2), s, v); \
+            } while (0)
+            if (w.fmt == GL3_TYPE_F16) GL3_VL(WT_F16);
+            else if (w.fmt == GL3_FMT_Q8V) { if (ksplit) GL3_VLQ(WT_Q8_0); else GL3_VL(WT_Q8_0); }
+            else { if (ksplit) GL3_VLQ(WT_Q4_0); else GL3_VL(WT_Q4_0); }
+#undef GL3_VLQ
 #undef GL3_VL
             return;
         }

@@ -102,10 +102,15 @@ struct VlArgs {
     const float* x;                         // f32[k] activation (normalised where the reference normalises)
     float* out; const float* resid_in;      // EPI_RESID: out[i] = resid_in[i] + result
     float out_scale;                        // result *= out_scale first (Granite residual / logit scaling; 1 otherwise)
+    const float* norm_w; float eps;         // RMS variant: x is the raw residual stream, normalised in the kernel's prologue
 };
 
 constexpr int VL_WAVES = 2;                 // 16 rows per workgroup: 4096-row matrices still give one workgroup per CU
+constexpr int VL_RMS_WAVES = 4;             // RMS variant: the exact sum of squares runs on 256 threads
 __host__ __device__ inline size_t vl_smem_bytes(int k) { return (size_t)k * 4; }
+// RMS variant: xT[k] | xf[k + 32] (natural order, zero padded) | exact-sum scratch | red
+__host__ __device__ inline size_t vl_rms_smem_bytes(int k) { return (size_t)k * 4 + (size_t)(k + 32) * 4 + ss_scratch_bytes(k) + 16; }
+__host__ __device__ inline bool vl_rms_fusable(int k) { return k >= 1024 && k <= 5120 && (k & 3) == 0; }    // exact_sumsq_lds range, LDS <= 64 KB
 
 // F16 -> f32 with subnormal inputs flushed to signed zero = the reference's bit trick (FP16FloatTensor.java:72-100, "emulate
 // DAZ"): the wavefront runs its main loop with MODE.FP_DENORM[3:2] (the f16 / f64 field) = 0 (flush), so one v_cvt_f32_f16
@@ -117,11 +122,58 @@ __device__ __forceinline__ void set_f16_denorm_flush(bool flush) {
 __device__ __forceinline__ float cvt_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); }
 __device__ __forceinline__ float cvt_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
 
+// Q4_0 nibbles -> (nibble - 8) without integer arithmetic or conversions: (w & 0x000F000F) | 0x64006400 is the f16 pair
+// (1024 + n_lo, 1024 + n_hi) (f16 counts in units of 1 from 1024 to 2047), one v_pk_add_f16 of -1032 makes it the exact pair
+// (n - 8), and v_fma_mix_f32 takes an f16 half as a multiplicand: fma(x, (float)h, -0) = fl(x * (n - 8)), the same single rounding
+// as the reference's float multiply (the -0 addend keeps the sign of a zero product).  Per dword of four quant bytes: 3 shifts,
+// 4 and-or, 4 packed adds for 8 values (the integer path took and / shift, add, convert = 3 per value).
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+struct Q4Consts { uint32_t magic; float negzero; };      // VGPR-resident operands (v_and_or_b32 takes one literal only)
+__device__ __forceinline__ Q4Consts q4_consts() {
+    Q4Consts c{0x64006400u, -0.0f};
+    asm volatile("" : "+v"(c.magic), "+v"(c.negzero));
+    return c;
+}
+__device__ __forceinline__ uint32_t q4_plane(uint32_t w_shifted, uint32_t magic) {
+    uint32_t bits;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(bits) : "v"(w_shifted), "s"(0x000F000Fu), "v"(magic));    // VOP3 on gfx9: no literal, one SGPR
+    const h2_t v = __builtin_bit_cast(h2_t, bits) + h2_t{(_Float16)-1032.0f, (_Float16)-1032.0f};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float mul_f16lo(float x, uint32_t hpair, float negzero) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(x), "v"(hpair), "v"(negzero));
+    return r;
+}
+__device__ __forceinline__ float mul_f16hi(float x, uint32_t hpair, float negzero) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(x), "v"(hpair), "v"(negzero));
+    return r;
+}
+// the four planes of a dword of quant bytes b0..b3: [0] = low nibbles of (b0, b2), [1] = high nibbles of (b0, b2),
+// [2] = low nibbles of (b1, b3), [3] = high nibbles of (b1, b3); byte j's low / high nibble = plane[2 (j & 1) + 0 / 1], half j >> 1
+struct Q4Planes { uint32_t p[4]; };
+__device__ __forceinline__ Q4Planes q4_planes(uint32_t w, uint32_t magic) {
+    Q4Planes r;
+    r.p[0] = q4_plane(w, magic); r.p[1] = q4_plane(w >> 4, magic); r.p[2] = q4_plane(w >> 8, magic); r.p[3] = q4_plane(w >> 12, magic);
+    return r;
+}
+template <int J, int HI>      // (nibble - 8) of byte J (0..3), low (HI = 0) or high nibble, times x
+__device__ __forceinline__ float q4_mul(float x, const Q4Planes& pl, float negzero) {
+    const uint32_t hp = pl.p[2 * (J & 1) + HI];
+    return (J >> 1) ? mul_f16hi(x, hp, negzero) : mul_f16lo(x, hp, negzero);
+}
+
 // Q4_0 is VALU-heavy (~5 instructions per weight: nibble extract, -8, convert, multiply, 3/4 add, 1/4 fma).  Two wavefronts
 // per SIMD (<= 256 VGPRs); capping the registers at 128 for four made the compiler spill 119 VGPRs and was 30 % slower.
-template <int WT, int EPI>
-static __global__ __launch_bounds__(64 * VL_WAVES, WT == WT_F16 ? 1 : 2) void matvec_vl_kernel(const VlArgs a) {
+// RMS = true (qkv, gate / up, logits): InferenceCore.rmsnorm (:39-48) runs in the prologue — every workgroup computes the exact
+// in-order sum of squares of the residual stream itself (gl3_seqsum.h, 256 threads) while its first weight chunks are in flight,
+// instead of a one-workgroup rmsnorm_f32_kernel launch in front of the matvec (9.3 us + a launch boundary, twice per layer).
+template <int WT, int EPI, bool RMS = false, int VW = VL_WAVES>
+static __global__ __launch_bounds__(64 * VW, WT == WT_F16 ? 1 : 2) void matvec_vl_kernel(const VlArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xT[];
+    static_assert(!RMS || VW == 4, "exact_sumsq_lds: 256 threads");
+    constexpr int VL_WAVES = VW;
     constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1;
     // Chunks in flight per wavefront (4 or 8 VGPRs each; 16 KB / 9 KB of the weight stream per wavefront and matrix)
     constexpr int D = WT == WT_F16 ? (NM == 1 ? 16 : 8) : WT == WT_Q8_0 ? (NM == 1 ? 12 : 6) : (NM == 1 ? 8 : 4);
@@ -155,8 +207,40 @@ static __global__ __launch_bounds__(64 * VL_WAVES, WT == WT_F16 ? 1 : 2) void ma
         if (live && u < nch) issue(u, u);
     }
     // ---- activation -> LDS, transposed: F16 xT[64 c + 8 l + k] = x[64 c + 8 k + l]; Q4_0 / Q8_0 xT[32 b + 4 l + q] = x[32 b + 8 q + l]
-    // 16 float4 per thread are requested at once (one L2 round trip per 32 KB of activation), then scattered
-    {
+    if constexpr (RMS) {
+        constexpr int NT = 64 * VL_WAVES, RQ = 5;               // k <= 5120: at most 5 quads per thread
+        float* xf = xT + a.k;                                    // [k + 32] natural order
+        uint8_t* scratch = reinterpret_cast<uint8_t*>(xf + a.k + 32);
+        const int nq = a.k >> 2;
+        float4 xr[RQ], nw[RQ];
+#pragma unroll
+        for (int u = 0; u < RQ; ++u) xr[u] = *reinterpret_cast<const float4*>(a.x + 4 * min(u * NT + t, nq - 1));
+#pragma unroll
+        for (int u = 0; u < RQ; ++u) nw[u] = *reinterpret_cast<const float4*>(a.norm_w + 4 * min(u * NT + t, nq - 1));
+#pragma unroll
+        for (int u = 0; u < RQ; ++u) if (u * NT + t < nq) *reinterpret_cast<float4*>(xf + 4 * (u * NT + t)) = xr[u];
+        if (t < 32) xf[a.k + t] = 0.f;
+        __syncthreads();
+        BlockBarrier bb;
+        float ss = exact_sumsq_lds(xf, a.k, scratch, t, bb);
+        ss /= (float)a.k;
+        ss += a.eps;
+        const float scale = (float)(1.0 / sqrt((double)ss));
+#pragma unroll
+        for (int u = 0; u < RQ; ++u) {
+            const int qd = u * NT + t;
+            if (qd < nq) {
+                const float vv[4] = {nw[u].x * (scale * xr[u].x), nw[u].y * (scale * xr[u].y), nw[u].z * (scale * xr[u].z), nw[u].w * (scale * xr[u].w)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * qd + e;
+                    if (WT == WT_F16) xT[(i & ~63) + 8 * (i & 7) + ((i >> 3) & 7)] = vv[e];
+                    else xT[(i & ~31) + 4 * (i & 7) + ((i >> 3) & 3)] = vv[e];
+                }
+            }
+        }
+    } else {
+        // 16 float4 per thread are requested at once (one L2 round trip per 32 KB of activation), then scattered
         constexpr int XB = 16, NT = 64 * VL_WAVES;
         const int nq = a.k >> 2;
         for (int base = 0; base < nq; base += XB * NT) {
@@ -187,6 +271,7 @@ static __global__ __launch_bounds__(64 * VL_WAVES, WT == WT_F16 ? 1 : 2) void ma
     float acc[NM];
 #pragma unroll
     for (int m = 0; m < NM; ++m) acc[m] = 0.f;
+    const Q4Consts qc = q4_consts();
     // One chunk of the 8 accumulator chains.  The chunk's activation operands (xa) were fetched from LDS while the previous
     // chunk was computed; this call fetches the next chunk's (xb).
     constexpr int XV = 2;                             // F16: float4 operands per chunk and lane (Q4_0 reads its operands per block)
@@ -225,21 +310,20 @@ static __global__ __launch_bounds__(64 * VL_WAVES, WT == WT_F16 ? 1 : 2) void ma
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 // quant bytes of the chunk's 8 blocks: A_0..3 | A_4..7 | B_0..3 | B_4..7; nibble planes of four bytes at once
-                const uint32_t aw[2] = {(uint32_t)wq[m][u].x, (uint32_t)wq[m][u].y}, bw[2] = {(uint32_t)wq[m][u].z, (uint32_t)wq[m][u].w};
+                const Q4Planes pa[2] = {q4_planes((uint32_t)wq[m][u].x, qc.magic), q4_planes((uint32_t)wq[m][u].y, qc.magic)};
+                const Q4Planes pb[2] = {q4_planes((uint32_t)wq[m][u].z, qc.magic), q4_planes((uint32_t)wq[m][u].w, qc.magic)};
                 const uint32_t sw[4] = {(uint32_t)wsc[m][u].x, (uint32_t)wsc[m][u].y, (uint32_t)wsc[m][u].z, (uint32_t)wsc[m][u].w};
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const uint32_t alo = aw[kk >> 2] & 0x0F0F0F0Fu, ahi = (aw[kk >> 2] >> 4) & 0x0F0F0F0Fu;
-                    const uint32_t blo = bw[kk >> 2] & 0x0F0F0F0Fu, bhi = (bw[kk >> 2] >> 4) & 0x0F0F0F0Fu;
-                    const int sh = 8 * (kk & 3);
-                    const float lo0 = (float)((alo >> sh) & 0xFFu) - 8.0f, hi0 = (float)((ahi >> sh) & 0xFFu) - 8.0f;    // v_cvt_f32_ubyteN; exact
-                    const float lo1 = (float)((blo >> sh) & 0xFFu) - 8.0f, hi1 = (float)((bhi >> sh) & 0xFFu) - 8.0f;
-                    const float ws = (kk & 1) ? cvt_hi(sw[kk >> 1]) : cvt_lo(sw[kk >> 1]);
-                    const float4 xk = *reinterpret_cast<const float4*>(xT + 32 * (8 * cq + kk) + 4 * l);   // x[j+l], x[j+8+l], x[j+16+l], x[j+24+l]
-                    const float s0 = xk.x * lo0, s1 = xk.y * lo1, s2 = xk.z * hi0, s3 = xk.w * hi1;
-                    const float sm = ((s0 + s1) + s2) + s3;                     // sum0.add(sum1).add(sum2).add(sum3)
-                    acc[m] = __builtin_fmaf(sm, ws, acc[m]);                    // .fma(wScale, val)
+#define VL_Q4_BLOCK(KK)                                                                                                            \
+                {                                                                                                                  \
+                    const float ws = ((KK) & 1) ? cvt_hi(sw[(KK) >> 1]) : cvt_lo(sw[(KK) >> 1]);                                   \
+                    const float4 xk = *reinterpret_cast<const float4*>(xT + 32 * (8 * cq + (KK)) + 4 * l);   /* x[j+l], x[j+8+l], x[j+16+l], x[j+24+l] */ \
+                    const float s0 = q4_mul<(KK) & 3, 0>(xk.x, pa[(KK) >> 2], qc.negzero), s1 = q4_mul<(KK) & 3, 0>(xk.y, pb[(KK) >> 2], qc.negzero);   \
+                    const float s2 = q4_mul<(KK) & 3, 1>(xk.z, pa[(KK) >> 2], qc.negzero), s3 = q4_mul<(KK) & 3, 1>(xk.w, pb[(KK) >> 2], qc.negzero);   \
+                    const float sm = ((s0 + s1) + s2) + s3;                     /* sum0.add(sum1).add(sum2).add(sum3) */          \
+                    acc[m] = __builtin_fmaf(sm, ws, acc[m]);                    /* .fma(wScale, val) */                            \
                 }
+                VL_Q4_BLOCK(0) VL_Q4_BLOCK(1) VL_Q4_BLOCK(2) VL_Q4_BLOCK(3) VL_Q4_BLOCK(4) VL_Q4_BLOCK(5) VL_Q4_BLOCK(6) VL_Q4_BLOCK(7)
+#undef VL_Q4_BLOCK
             }
         }
     };
@@ -278,6 +362,188 @@ static __global__ __launch_bounds__(64 * VL_WAVES, WT == WT_F16 ? 1 : 2) void ma
 #pragma unroll
         for (int j = 0; j < 8; ++j) r = r + __shfl(acc[m], (lane & ~7) + j, 64);
         res[m] = r;
+    }
+    const int row = g * 8 + rr;
+    if (l == 0 && row < a.rows) {
+        if (EPI == EPI_STORE) a.out[row] = res[0] * a.out_scale;
+        if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + res[0] * a.out_scale : res[0] * a.out_scale;
+        if (EPI == EPI_SWIGLU) {                               // InferenceCore.java:155-158, exp in double
+            const float gte = res[0] / (float)(1.0 + exp(-(double)res[0]));
+            a.out[row] = gte * res[NM - 1];
+        }
+    }
+}
+
+// ---- Q4_0 / Q8_0-with-f32-activation, K split over the wavefronts of a workgroup.
+// In these two dot products only ONE operation per 32-element block is on the row's dependent chain: val[l] = fma(s[l], wScale,
+// val[l]).  The block sum s[l] (nibble / byte extraction, conversions, 4 multiplies, 3 adds: ~17 of the ~18 VALU instructions
+// per block and lane) depends on the block alone.  matvec_vl_kernel gives a whole 8-row group to one wavefront, so a 4096-row
+// matrix runs 512 wavefronts on 1024 SIMDs, each issuing alone on its SIMD (~2.4 ns per instruction instead of ~1.1 with two
+// wavefronts interleaved): the Llama-3-8B Q4_0 down projection took 33 us for 33 MB.  Here a workgroup of four wavefronts owns
+// one 8-row group; per round wavefront w computes the block sums of its contiguous K range (<= 64 blocks, kept in registers),
+// then the four wavefronts run their part of the fma chain one after the other, passing the 64 chain values (8 rows x 8
+// accumulator lanes) through LDS.  Same arithmetic in the same order -> same bits.  Each wavefront stages only its own slice
+// of the activation (wave-private LDS, no workgroup barrier before the compute phase).
+constexpr int VQ_WAVES = 4;
+template <int WT>
+__host__ __device__ constexpr int vq_round_chunks(int nm) { return (WT == WT_Q4_0 ? 8 : 12) / nm; }    // per wavefront: 64 (Q4_0) / 48 (Q8_0: 16-byte quants cost more registers) blocks, split over the nm matrices
+template <int WT>
+__host__ __device__ constexpr size_t vq_smem_bytes(int nm) {
+    return (size_t)VQ_WAVES * vq_round_chunks<WT>(nm) * (WT == WT_Q4_0 ? 256 : 128) * 4 + (size_t)nm * 64 * 4;
+}
+
+template <int WT, int EPI>
+static __global__ __launch_bounds__(64 * VQ_WAVES, 2) void matvec_vlq_kernel(const VlArgs a) {
+    static_assert(WT == WT_Q4_0 || WT == WT_Q8_0, "K-split kernel: block-sum types only");
+    extern __shared__ __attribute__((aligned(16))) float vq_smem[];
+    constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1;
+    constexpr int CB = WT == WT_Q4_0 ? 8 : 4;                  // blocks per chunk
+    constexpr int CE = CB * 32;                                // elements per chunk
+    constexpr int RCM = vq_round_chunks<WT>(NM);               // chunks per wavefront and round
+    constexpr int CBYTES = WT == WT_Q4_0 ? 1152 : 1088;
+    const int t = threadIdx.x, lane = t & 63, l = lane & 7, rr = lane >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);    // scalar: every per-wavefront bound below is an SGPR compare, not an exec mask
+    const int g = blockIdx.x;                                   // 8-row group of this workgroup
+    const int nch = a.k / CE;
+    const int nrounds = (nch + VQ_WAVES * RCM - 1) / (VQ_WAVES * RCM);
+    const int rc = (nch + VQ_WAVES * nrounds - 1) / (VQ_WAVES * nrounds);      // chunks per wavefront and round (<= RCM)
+    float* xT = vq_smem + wave * (RCM * CE);                    // this wavefront's activation slice, transposed per block
+    float* accx = vq_smem + VQ_WAVES * RCM * CE;                // [NM][64] chain hand-over
+    const size_t gbytes = vl_group_bytes(WT, a.k);
+    const uint8_t* wb[NM];
+    wb[0] = a.w + (size_t)g * gbytes;
+    if (NM == 2) wb[NM - 1] = a.w2 + (size_t)g * gbytes;
+
+    int4 wq[NM][RCM];
+    int4 wsc4[NM][WT == WT_Q4_0 ? RCM : 1];
+    uint2 wsc8[NM][WT == WT_Q8_0 ? RCM : 1];
+    float4 xr[RCM * CE / 256];                                  // RCM * CE floats = (RCM * CE / 256) float4 per lane
+    float sm[NM][RCM * CB];
+    constexpr int XQ = RCM * CE / 256;
+
+    // loads of one round: the activation slice first (it is waited for first), then the wavefront's chunks of every matrix
+#define VQ_ISSUE(R_)                                                                                                     \
+    do {                                                                                                                 \
+        const int c_lo_ = ((R_) * VQ_WAVES + wave) * rc;                                                                 \
+        const int nc_ = max(0, min(rc, nch - c_lo_));                                                                    \
+        const int nq_ = nc_ * (CE / 4);                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < XQ; ++u)                                                                   \
+            if (u * 64 < nq_) xr[u] = *reinterpret_cast<const float4*>(a.x + (size_t)c_lo_ * CE + 4 * min(u * 64 + lane, nq_ - 1)); \
+        _Pragma("unroll") for (int u = 0; u < RCM; ++u)                                                                  \
+            if (u < nc_) {                                                                                               \
+                _Pragma("unroll") for (int m = 0; m < NM; ++m) {                                                         \
+                    const uint8_t* cb = wb[m] + (size_t)(c_lo_ + u) * CBYTES;                                            \
+                    wq[m][u] = ld16<true>(cb + 16 * lane);                                                               \
+                    if (WT == WT_Q4_0) wsc4[m][u] = ld16<true>(cb + 1024 + 16 * rr);                                     \
+                    if (WT == WT_Q8_0) wsc8[m][u] = *reinterpret_cast<const uint2*>(cb + 1024 + 8 * rr);                 \
+                }                                                                                                        \
+            }                                                                                                            \
+    } while (0)
+
+    VQ_ISSUE(0);
+    const Q4Consts qc = q4_consts();
+    float acc[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[m] = 0.f;
+    for (int r = 0; r < nrounds; ++r) {
+        const int c_lo = (r * VQ_WAVES + wave) * rc;
+        const int nc = max(0, min(rc, nch - c_lo));
+        const int nq = nc * (CE / 4);
+        // ---- activation slice -> wave-private LDS, transposed: xT[32 b + 4 l + q] = x[32 b + 8 q + l]
+#pragma unroll
+        for (int u = 0; u < XQ; ++u) {
+            const int qd = u * 64 + lane;
+            if (qd < nq) {
+                const float vv[4] = {xr[u].x, xr[u].y, xr[u].z, xr[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * qd + e;
+                    xT[(i & ~31) + 4 * (i & 7) + ((i >> 3) & 3)] = vv[e];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- block sums of this wavefront's chunks
+#pragma unroll
+        for (int u = 0; u < RCM; ++u) {
+            if (u < nc) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    if (WT == WT_Q8_0) {
+                        const uint32_t qw[4] = {(uint32_t)wq[m][u].x, (uint32_t)wq[m][u].y, (uint32_t)wq[m][u].z, (uint32_t)wq[m][u].w};   // one block each
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const float q0 = (float)(int8_t)(qw[kk] & 0xFFu), q1 = (float)(int8_t)((qw[kk] >> 8) & 0xFFu);      // castShape(F_SPECIES, i): exact
+                            const float q2 = (float)(int8_t)((qw[kk] >> 16) & 0xFFu), q3 = (float)(int8_t)(qw[kk] >> 24);
+                            const float4 xk = *reinterpret_cast<const float4*>(xT + 32 * (4 * u + kk) + 4 * l);   // x[j+l], x[j+8+l], x[j+16+l], x[j+24+l]
+                            const float s0 = xk.x * q0, s1 = xk.y * q1, s2 = xk.z * q2, s3 = xk.w * q3;
+                            sm[m][4 * u + kk] = ((s0 + s1) + s2) + s3;          // sum0.add(sum1).add(sum2).add(sum3)
+                        }
+                    } else {
+                        // quant bytes of the chunk's 8 blocks: A_0..3 | A_4..7 | B_0..3 | B_4..7; nibble planes of four bytes at once
+                        const Q4Planes pa[2] = {q4_planes((uint32_t)wq[m][u].x, qc.magic), q4_planes((uint32_t)wq[m][u].y, qc.magic)};
+                        const Q4Planes pb[2] = {q4_planes((uint32_t)wq[m][u].z, qc.magic), q4_planes((uint32_t)wq[m][u].w, qc.magic)};
+#define VQ_Q4_BLOCK(KK)                                                                                                            \
+                        {                                                                                                          \
+                            const float4 xk = *reinterpret_cast<const float4*>(xT + 32 * (8 * u + (KK)) + 4 * l);   /* x[j+l], x[j+8+l], x[j+16+l], x[j+24+l] */ \
+                            const float s0 = q4_mul<(KK) & 3, 0>(xk.x, pa[(KK) >> 2], qc.negzero), s1 = q4_mul<(KK) & 3, 0>(xk.y, pb[(KK) >> 2], qc.negzero);   \
+                            const float s2 = q4_mul<(KK) & 3, 1>(xk.z, pa[(KK) >> 2], qc.negzero), s3 = q4_mul<(KK) & 3, 1>(xk.w, pb[(KK) >> 2], qc.negzero);   \
+                            sm[m][8 * u + (KK)] = ((s0 + s1) + s2) + s3;       /* sum0.add(sum1).add(sum2).add(sum3) */           \
+                        }
+                        VQ_Q4_BLOCK(0) VQ_Q4_BLOCK(1) VQ_Q4_BLOCK(2) VQ_Q4_BLOCK(3) VQ_Q4_BLOCK(4) VQ_Q4_BLOCK(5) VQ_Q4_BLOCK(6) VQ_Q4_BLOCK(7)
+#undef VQ_Q4_BLOCK
+                    }
+                }
+            }
+        }
+        // ---- the chain, wavefront after wavefront (K order); the scales stay packed until their fma
+        for (int w = 0; w < VQ_WAVES; ++w) {
+            if (wave == w && nc > 0) {
+                if (!(r == 0 && w == 0)) {
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) acc[m] = accx[m * 64 + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < RCM; ++u) {
+                    if (u < nc) {
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+#pragma unroll
+                            for (int kk = 0; kk < CB; ++kk) {
+                                float ws;
+                                if (WT == WT_Q8_0) {
+                                    const uint32_t sw = (kk >> 1) ? wsc8[m][u].y : wsc8[m][u].x;
+                                    ws = h2f((uint16_t)((kk & 1) ? (sw >> 16) : (sw & 0xFFFFu)));     // Float.float16ToFloat: IEEE, subnormals kept
+                                } else {
+                                    const uint32_t sw4[4] = {(uint32_t)wsc4[m][u].x, (uint32_t)wsc4[m][u].y, (uint32_t)wsc4[m][u].z, (uint32_t)wsc4[m][u].w};
+                                    ws = (kk & 1) ? cvt_hi(sw4[kk >> 1]) : cvt_lo(sw4[kk >> 1]);
+                                }
+                                acc[m] = __builtin_fmaf(sm[m][CB * u + kk], ws, acc[m]);          // .fma(wScale, val)
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < NM; ++m) accx[m * 64 + lane] = acc[m];
+            }
+            // next round's loads once the wavefront's own scales are used up: they fly during the remaining chain phases
+            if (wave == w && r + 1 < nrounds) VQ_ISSUE(r + 1);
+            __syncthreads();
+        }
+    }
+#undef VQ_ISSUE
+    if (wave != 0) return;
+    // ---- reduceLanes(ADD) in lane order from 0, then the epilogue on the row's first lane
+    float res[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const float v = accx[m * 64 + lane];
+        float rsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rsum = rsum + __shfl(v, (lane & ~7) + j, 64);
+        res[m] = rsum;
     }
     const int row = g * 8 + rr;
     if (l == 0 && row < a.rows) {
