@@ -104,17 +104,24 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
             } while (0)
             // Q4_0 / Q8_0-f32act: four wavefronts split K of one 8-row group (matvec_vlq_kernel); GL3_VLQ=0 keeps the one-wavefront kernel
             static const bool ksplit = env_flag("GL3_VLQ", true);
+#define GL3_VLQ_E(WT_, MAXW_) \
+            do { \
+                const size_t qs = vq_smem_bytes<WT_, MAXW_>(w.k, epi == EPI_SWIGLU ? 2 : 1, nw); \
+                if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_vlq_kernel<WT_, EPI_STORE, MAXW_>), qg, qb, qs, s, v); \
+                else if (epi == EPI_RESID) hipLaunchKernelGGL((matvec_vlq_kernel<WT_, EPI_RESID, MAXW_>), qg, qb, qs, s, v); \
+                else hipLaunchKernelGGL((matvec_vlq_kernel<WT_, EPI_SWIGLU, MAXW_>), qg, qb, qs, s, v); \
+            } while (0)
 #define GL3_VLQ(WT_) \
             do { \
-                const dim3 qg((w.rows + 7) / 8), qb(64 * VQ_WAVES); \
-                if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_vlq_kernel<WT_, EPI_STORE>), qg, qb, vq_smem_bytes<WT_>(1), s, v); \
-                else if (epi == EPI_RESID) hipLaunchKernelGGL((matvec_vlq_kernel<WT_, EPI_RESID>), qg, qb, vq_smem_bytes<WT_>(1), s, v); \
-                else hipLaunchKernelGGL((matvec_vlq_kernel<WT_, EPI_SWIGLU>), qg, qb, vq_smem_bytes<WT_>(2), s, v); \
+                const int ngroups = (w.rows + 7) / 8, nw = vq_waves<WT_>(w.k, epi == EPI_SWIGLU ? 2 : 1, ngroups); \
+                const dim3 qg(ngroups), qb(64 * nw); \
+                if (nw == 16) GL3_VLQ_E(WT_, 16); else GL3_VLQ_E(WT_, 8); \
             } while (0)
             if (w.fmt == GL3_TYPE_F16) GL3_VL(WT_F16);
             else if (w.fmt == GL3_FMT_Q8V) { if (ksplit) GL3_VLQ(WT_Q8_0); else GL3_VL(WT_Q8_0); }
             else { if (ksplit) GL3_VLQ(WT_Q4_0); else GL3_VL(WT_Q4_0); }
 #undef GL3_VLQ
+#undef GL3_VLQ_E
 #undef GL3_VL
             return;
         }
@@ -437,7 +444,8 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     if ((size_t)d.ctx * 4 + (size_t)PV_ROWS * PV_COLS * 4 + 64 > 150 * 1024) return bail(GL3_E_UNSUPPORTED, "context length above 20k not supported by the decode attention kernel");
     TRY(dmalloc(ctx, &ctx->dyn, 4));
     ctx->dyn_cur = ctx->dyn;
-    TRY(dmalloc(ctx, &ctx->argmax, 1));
+    TRY(dmalloc(ctx, &ctx->argmax, 2 + 2 * AMX_WGS));          // result, ticket, (value, index) pairs of argmax_kernel
+    TRYHIP(hipMemset(ctx->argmax, 0, (2 + 2 * AMX_WGS) * sizeof(int)));
     if (d.flags & GL3_FLAG_LAYER_TAPS) TRY(dmalloc(ctx, &ctx->taps, (size_t)d.n_layers * d.dim));
     TRYHIP(hipHostMalloc((void**)&ctx->h_dyn, 4 * sizeof(int)));
     TRYHIP(hipHostMalloc((void**)&ctx->h_logits, (size_t)d.vocab * 4));
@@ -713,7 +721,7 @@ int32_t gl3_forward_decode(gl3_ctx* ctx, int32_t token, int32_t pos, float* logi
     if (ctx->graph_exec && want_logits) GL3_HIP(hipGraphLaunch(short_ctx && ctx->graph_exec_s ? ctx->graph_exec_s : ctx->graph_exec, ctx->stream));
     else if ((r = enqueue_decode(ctx, want_logits, nullptr, short_ctx)) != GL3_OK) return r;
     if (argmax_out) {
-        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->logits, ctx->d.vocab, ctx->argmax);
+        hipLaunchKernelGGL(argmax_kernel, dim3(AMX_WGS), dim3(256), 0, ctx->stream, ctx->logits, ctx->d.vocab, ctx->argmax);
         GL3_HIP(hipMemcpyAsync(ctx->h_argmax, ctx->argmax, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     }
     // logits D2H: straight into the caller's buffer when it is page-locked (gl3_pin_host_buffer), else through the plan's pinned

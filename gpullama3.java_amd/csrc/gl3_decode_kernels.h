@@ -848,27 +848,64 @@ static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnA
 // Greedy sampling on the device: first index of the maximum (strict >), FloatTensor.argmax
 // J/tensor/standard/FloatTensor.java:138-151 — NOT the strided-scan tie-break of the reference's
 // argmaxLogits (TransformerComputeKernels.java:25-59).
-static __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ v, int n, int* __restrict__ out) {
-    __shared__ float bv[16];
-    __shared__ int bi[16];
-    const int t = threadIdx.x;
+// One launch, AMX_WGS workgroups: each scans a contiguous slice (float4 loads), publishes its (value, index) pair and takes a
+// ticket; the LAST workgroup to arrive (no spinning: whoever draws the final ticket) folds the pairs in slice order and resets the
+// ticket for the next token.  ws = int[2 + 2 * AMX_WGS]: [0] result, [1] ticket (zero at allocation), then the pairs.
+// (One 1024-thread workgroup took 45 us for the 128256 logits of Llama-3.)
+constexpr int AMX_WGS = 64;
+__device__ __forceinline__ void amx_take(float& best, int& idx, float f, int i) {
+    if (f > best || (f == best && i < idx)) { best = f; idx = i; }
+}
+static __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ v, int n, int* __restrict__ ws) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    __shared__ int last;
+    const int t = threadIdx.x, b = blockIdx.x;
+    const int per = (((n + AMX_WGS - 1) / AMX_WGS) + 3) & ~3;          // slice length, multiple of 4 (n % 4 == 0 is not required)
+    const int lo = b * per, hi = min(n, lo + per);
     float best = -INFINITY;
     int idx = 0x7FFFFFFF;
-    for (int i = t; i < n; i += 1024) {
-        const float f = v[i];
-        if (f > best || (f == best && i < idx)) { best = f; idx = i; }
+    const bool vec = (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+    if (vec) {
+        for (int i = lo + 4 * t; i < hi; i += 1024) {
+            if (i + 4 <= hi) {
+                const float4 f = *reinterpret_cast<const float4*>(v + i);
+                amx_take(best, idx, f.x, i); amx_take(best, idx, f.y, i + 1); amx_take(best, idx, f.z, i + 2); amx_take(best, idx, f.w, i + 3);
+            } else {
+                for (int j = i; j < hi; ++j) amx_take(best, idx, v[j], j);
+            }
+        }
+    } else {
+        for (int i = lo + t; i < hi; i += 256) amx_take(best, idx, v[i], i);
     }
     for (int m = 32; m >= 1; m >>= 1) {
         const float ob = __shfl_xor(best, m, 64);
         const int oi = __shfl_xor(idx, m, 64);
-        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+        amx_take(best, idx, ob, oi);
     }
     if ((t & 63) == 0) { bv[t >> 6] = best; bi[t >> 6] = idx; }
     __syncthreads();
     if (t == 0) {
-        for (int w = 1; w < 16; ++w)
-            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-        *out = idx == 0x7FFFFFFF ? 0 : idx;
+        for (int w = 1; w < 4; ++w) amx_take(best, idx, bv[w], bi[w]);
+        __hip_atomic_store(ws + 2 + 2 * b, __builtin_bit_cast(int, best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ws + 3 + 2 * b, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ticket = __hip_atomic_fetch_add(ws + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = ticket == AMX_WGS - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    if (t < 64) {                                   // AMX_WGS = 64 pairs: one per lane
+        best = __builtin_bit_cast(float, __hip_atomic_load(ws + 2 + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        idx = __hip_atomic_load(ws + 3 + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ob = __shfl_xor(best, m, 64);
+            const int oi = __shfl_xor(idx, m, 64);
+            amx_take(best, idx, ob, oi);
+        }
+        if (t == 0) {
+            ws[0] = idx == 0x7FFFFFFF ? 0 : idx;
+            __hip_atomic_store(ws + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

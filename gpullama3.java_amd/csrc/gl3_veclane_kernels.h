@@ -379,36 +379,59 @@ static __global__ __launch_bounds__(64 * VW, WT == WT_F16 ? 1 : 2) void matvec_v
 // val[l]).  The block sum s[l] (nibble / byte extraction, conversions, 4 multiplies, 3 adds: ~17 of the ~18 VALU instructions
 // per block and lane) depends on the block alone.  matvec_vl_kernel gives a whole 8-row group to one wavefront, so a 4096-row
 // matrix runs 512 wavefronts on 1024 SIMDs, each issuing alone on its SIMD (~2.4 ns per instruction instead of ~1.1 with two
-// wavefronts interleaved): the Llama-3-8B Q4_0 down projection took 33 us for 33 MB.  Here a workgroup of four wavefronts owns
-// one 8-row group; per round wavefront w computes the block sums of its contiguous K range (<= 64 blocks, kept in registers),
-// then the four wavefronts run their part of the fma chain one after the other, passing the 64 chain values (8 rows x 8
-// accumulator lanes) through LDS.  Same arithmetic in the same order -> same bits.  Each wavefront stages only its own slice
-// of the activation (wave-private LDS, no workgroup barrier before the compute phase).
-constexpr int VQ_WAVES = 4;
+// wavefronts interleaved): the Llama-3-8B Q4_0 down projection took 33 us for 33 MB.  Here a workgroup of 4 / 8 / 16 wavefronts
+// owns one 8-row group; per round wavefront w computes the block sums of its contiguous K range (<= 64 blocks, kept in registers),
+// then the wavefronts run their part of the fma chain one after the other, passing the 64 chain values (8 rows x 8 accumulator
+// lanes) through LDS.  Same arithmetic in the same order -> same bits.  Each wavefront stages only its own slice of the activation
+// (wave-private LDS, no workgroup barrier before the compute phase).  Loads are unconditional with clamped indices so that the
+// waits are exact vmcnt counts (slice scattered while the weights fly, chunk u consumed while chunks u + 1 .. are in flight).
+// Wavefronts per group (launcher, vq_waves): enough for >= 2 wavefronts per SIMD over the launch — a rank of a tensor-parallel
+// group holds rows / tp rows — and for one round to cover K.  MAXW = 8: <= 256 VGPRs, 64 (Q4_0) / 48 (Q8_0) blocks of sums per
+// wavefront and round; MAXW = 16: <= 128 VGPRs, half of that.
+// Used for the residual projections (wo, down).  Variants that were measured and dropped (8B Q4_0, 8 layers + logits, us / token;
+// this kernel: 734): a persistent version looping over groups with the RMSNorm in its prologue for qkv / gate-up / logits (1198:
+// one exposed load latency per group); whole-workgroup staging of x (755); loads under wavefront-uniform branches (809).  This
+// kernel's register allocation is fragile (hipcc, ROCm 7.2): equivalent restructurings of the chain loop spilled 130 - 330 bytes.
+template <int WT, int MAXW>
+__host__ __device__ constexpr int vq_round_chunks(int nm) { return (WT == WT_Q4_0 ? 8 : 12) / (MAXW == 16 ? 2 : 1) / nm; }
+template <int WT, int MAXW>
+__host__ __device__ inline int vq_rc(int k, int nm, int nw) {
+    const int nch = k / (WT == WT_Q4_0 ? 256 : 128), cap = nw * vq_round_chunks<WT, MAXW>(nm);
+    const int nrounds = (nch + cap - 1) / cap;
+    return (nch + nw * nrounds - 1) / (nw * nrounds);
+}
+template <int WT, int MAXW>
+__host__ __device__ inline size_t vq_smem_bytes(int k, int nm, int nw) {
+    return (size_t)nm * 64 * 4 + (size_t)nw * vq_rc<WT, MAXW>(k, nm, nw) * (WT == WT_Q4_0 ? 256 : 128) * 4;
+}
 template <int WT>
-__host__ __device__ constexpr int vq_round_chunks(int nm) { return (WT == WT_Q4_0 ? 8 : 12) / nm; }    // per wavefront: 64 (Q4_0) / 48 (Q8_0: 16-byte quants cost more registers) blocks, split over the nm matrices
-template <int WT>
-__host__ __device__ constexpr size_t vq_smem_bytes(int nm) {
-    return (size_t)VQ_WAVES * vq_round_chunks<WT>(nm) * (WT == WT_Q4_0 ? 256 : 128) * 4 + (size_t)nm * 64 * 4;
+__host__ inline int vq_waves(int k, int nm, int ngroups) {
+    const int nch = k / (WT == WT_Q4_0 ? 256 : 128);
+    int nw = 4;
+    while (nw < 16 && (long)ngroups * nw < 2048) nw *= 2;
+    if (nw == 4 && nch > 4 * vq_round_chunks<WT, 8>(nm)) nw = 8;
+    while (nw > 4 && nch < nw) nw /= 2;
+    return nw;
 }
 
-template <int WT, int EPI>
-static __global__ __launch_bounds__(64 * VQ_WAVES, 2) void matvec_vlq_kernel(const VlArgs a) {
+template <int WT, int EPI, int MAXW>
+static __global__ __launch_bounds__(64 * MAXW) void matvec_vlq_kernel(const VlArgs a) {
     static_assert(WT == WT_Q4_0 || WT == WT_Q8_0, "K-split kernel: block-sum types only");
     extern __shared__ __attribute__((aligned(16))) float vq_smem[];
     constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1;
     constexpr int CB = WT == WT_Q4_0 ? 8 : 4;                  // blocks per chunk
     constexpr int CE = CB * 32;                                // elements per chunk
-    constexpr int RCM = vq_round_chunks<WT>(NM);               // chunks per wavefront and round
+    constexpr int RCM = vq_round_chunks<WT, MAXW>(NM);         // chunks per wavefront and round
     constexpr int CBYTES = WT == WT_Q4_0 ? 1152 : 1088;
     const int t = threadIdx.x, lane = t & 63, l = lane & 7, rr = lane >> 3;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);    // scalar: every per-wavefront bound below is an SGPR compare, not an exec mask
-    const int g = blockIdx.x;                                   // 8-row group of this workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int VQ_WAVES = blockDim.x >> 6;
+    const int g = blockIdx.x;
     const int nch = a.k / CE;
     const int nrounds = (nch + VQ_WAVES * RCM - 1) / (VQ_WAVES * RCM);
-    const int rc = (nch + VQ_WAVES * nrounds - 1) / (VQ_WAVES * nrounds);      // chunks per wavefront and round (<= RCM)
-    float* xT = vq_smem + wave * (RCM * CE);                    // this wavefront's activation slice, transposed per block
-    float* accx = vq_smem + VQ_WAVES * RCM * CE;                // [NM][64] chain hand-over
+    const int rc = (nch + VQ_WAVES * nrounds - 1) / (VQ_WAVES * nrounds);
+    float* accx = vq_smem;
+    float* xT = vq_smem + NM * 64 + wave * (rc * CE);
     const size_t gbytes = vl_group_bytes(WT, a.k);
     const uint8_t* wb[NM];
     wb[0] = a.w + (size_t)g * gbytes;
@@ -417,27 +440,25 @@ static __global__ __launch_bounds__(64 * VQ_WAVES, 2) void matvec_vlq_kernel(con
     int4 wq[NM][RCM];
     int4 wsc4[NM][WT == WT_Q4_0 ? RCM : 1];
     uint2 wsc8[NM][WT == WT_Q8_0 ? RCM : 1];
-    float4 xr[RCM * CE / 256];                                  // RCM * CE floats = (RCM * CE / 256) float4 per lane
+    float4 xr[RCM * CE / 256];
     float sm[NM][RCM * CB];
     constexpr int XQ = RCM * CE / 256;
 
-    // loads of one round: the activation slice first (it is waited for first), then the wavefront's chunks of every matrix
 #define VQ_ISSUE(R_)                                                                                                     \
     do {                                                                                                                 \
-        const int c_lo_ = ((R_) * VQ_WAVES + wave) * rc;                                                                 \
-        const int nc_ = max(0, min(rc, nch - c_lo_));                                                                    \
+        const int c_lo_ = min(((R_) * VQ_WAVES + wave) * rc, nch - 1);                                                   \
+        const int nc_ = max(1, min(rc, nch - c_lo_));                                                                    \
         const int nq_ = nc_ * (CE / 4);                                                                                  \
         _Pragma("unroll") for (int u = 0; u < XQ; ++u)                                                                   \
-            if (u * 64 < nq_) xr[u] = *reinterpret_cast<const float4*>(a.x + (size_t)c_lo_ * CE + 4 * min(u * 64 + lane, nq_ - 1)); \
-        _Pragma("unroll") for (int u = 0; u < RCM; ++u)                                                                  \
-            if (u < nc_) {                                                                                               \
-                _Pragma("unroll") for (int m = 0; m < NM; ++m) {                                                         \
-                    const uint8_t* cb = wb[m] + (size_t)(c_lo_ + u) * CBYTES;                                            \
-                    wq[m][u] = ld16<true>(cb + 16 * lane);                                                               \
-                    if (WT == WT_Q4_0) wsc4[m][u] = ld16<true>(cb + 1024 + 16 * rr);                                     \
-                    if (WT == WT_Q8_0) wsc8[m][u] = *reinterpret_cast<const uint2*>(cb + 1024 + 8 * rr);                 \
-                }                                                                                                        \
+            xr[u] = *reinterpret_cast<const float4*>(a.x + (size_t)c_lo_ * CE + 4 * min(u * 64 + lane, nq_ - 1));       \
+        _Pragma("unroll") for (int u = 0; u < RCM; ++u) {                                                                \
+            _Pragma("unroll") for (int m = 0; m < NM; ++m) {                                                             \
+                const uint8_t* cb = wb[m] + (size_t)(c_lo_ + min(u, nc_ - 1)) * CBYTES;                                  \
+                wq[m][u] = ld16<true>(cb + 16 * lane);                                                                   \
+                if (WT == WT_Q4_0) wsc4[m][u] = ld16<true>(cb + 1024 + 16 * rr);                                         \
+                if (WT == WT_Q8_0) wsc8[m][u] = *reinterpret_cast<const uint2*>(cb + 1024 + 8 * rr);                     \
             }                                                                                                            \
+        }                                                                                                                \
     } while (0)
 
     VQ_ISSUE(0);
