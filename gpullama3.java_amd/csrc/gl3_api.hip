@@ -72,7 +72,13 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
         hipStream_t s = ctx->stream;
         // Vector-order kernels normalise in their own prologue (matvec_vl_kernel<.., RMS>); GL3_VL_RMS=0: separate rmsnorm launch
         static const bool vl_rms = env_flag("GL3_VL_RMS", true);
-        const bool fuse_rms = pro == PRO_RMS && w.vl && vl_rms && vl_rms_fusable(w.k) && epi != EPI_RESID;
+        // ... except for the K-split types when the launch has few 8-row groups (a tensor-parallel rank's slice): the fused kernel
+        // keeps one wavefront per group whatever the row count, so a 224-group gate/up slice would take as long as the whole
+        // matrix; there the one-workgroup rmsnorm launch + the K-split kernel (16 wavefronts per group) is the faster pair.
+        static const bool ksplit_on = env_flag("GL3_VLQ", true);
+        const bool ksplit_type = ksplit_on && w.vl && (w.fmt == GL3_FMT_Q8V || w.fmt == GL3_TYPE_Q4_0);
+        const long vl_waves = (long)((w.rows + 7) / 8) * (epi == EPI_SWIGLU ? 2 : 1);
+        const bool fuse_rms = pro == PRO_RMS && w.vl && vl_rms && vl_rms_fusable(w.k) && epi != EPI_RESID && !(ksplit_type && vl_waves <= 512);
         if (pro == PRO_RMS && !fuse_rms) {
             const size_t sm = (size_t)(w.k + 32) * 4 + ss_scratch_bytes(w.k) + 64;
             hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3(1), dim3(256), sm, s, x, w.k, norm_w, ctx->d.rms_eps, ctx->xn);

@@ -3,7 +3,7 @@
 // i.e. InferenceCore.rmsnorm's `x.reduce(0f, (acc, xi) -> acc + xi * xi)` (J/inference/InferenceCore.java:41),
 // bit for bit, without a 4096-step dependent chain (13 cycles / element on gfx950 = 22 us for dim 4096).
 //
-// Idea (CPU mirror with 120k adversarial trials: scripts/probes/seqsum_proto2.c): while the running sum stays
+// Idea (CPU mirror with adversarial trials: tests/test_seqsum_mirror.py): while the running sum stays
 // inside one binade it is N*u with an integer N, and adding a_k adds an integer that depends only on a_k
 // (and, on an exact rounding tie, on the parity of N).  So a segment of m elements that (i) starts in the
 // binade predicted by an approximate prefix sum, (ii) does not leave it and (iii) gives the same increment D
