@@ -30,11 +30,6 @@ static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static bool env_flag(const char* name, bool dflt) {
-    const char* v = getenv(name);
-    if (!v || !*v) return dflt;
-    return atoi(v) != 0;
-}
 
 // ------------------------------------------------------------------------------------------------ matvec launch
 static size_t matvec_smem(int pro, int epi, const Q8Mat& w) {

@@ -17,6 +17,13 @@
 constexpr size_t GL3_TAIL_PAD = 256 * 1024;
 
 // Internal format code of Q8_0 matrices run with an f32 activation (GL3_FLAG_F32_ACTIVATION): VL layout, gl3_veclane_kernels.h
+// diagnostic switches: environment variable as a flag (unset / empty = default)
+static inline bool env_flag(const char* name, bool dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v) != 0;
+}
+
 constexpr int GL3_FMT_Q8V = 108;
 
 struct Q8Mat {               // one repacked matrix: Q8T tiles (gl3_decode_kernels.h), VL groups (gl3_veclane_kernels.h) or row-lane groups
