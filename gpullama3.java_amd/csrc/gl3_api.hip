@@ -214,7 +214,8 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
     aa.eps = d.rms_eps; aa.arch = ctx->rope_arch; aa.att_mul = ctx->att_mul;
     const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 4) + d.head_size) * 4;
     const int pv_rows = d.ctx < PV_ROWS ? d.ctx : PV_ROWS;
-    const size_t sm2 = ((size_t)((d.ctx + 3) & ~3) + (size_t)pv_rows * PV_COLS) * 4;
+    aa.win = ctx->attn_win;
+    const size_t sm2 = ((size_t)ctx->attn_win + (size_t)pv_rows * PV_COLS) * 4;
     if (which == 0 && short_ctx && ctx->fused_attn_ok) {      // positions < AF_MAXN: one launch
         hipLaunchKernelGGL(attn_head_kernel, dim3(ctx->heads_l), dim3(256), attn_head_smem(d.head_size), ctx->stream, aa);
         return;
@@ -231,6 +232,7 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
     const int rank = d.tp_rank;
     const bool q8 = ctx->emb.fmt == GL3_TYPE_Q8_0;       // Q8T path (int8 activation)
     int32_t r;
+    Gl3Range step_range("gl3 decode step");
 
     pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
     if (ctx->emb.fmt == GL3_TYPE_Q8_0) hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
@@ -243,38 +245,41 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
 
     for (int l = 0; l < d.n_layers; ++l) {
         gl3_layer& L = ctx->layers[l];
+        Gl3Range layer_range("layer", l);
         pr.begin(GL3_K_MATVEC_QKV, mv_bytes(L.wqkv) + d.dim * 4, q8);
-        launch_matvec(ctx, PRO_RMS, EPI_STORE, L.wqkv, nullptr, ctx->x, L.attn_norm, ctx->qkv, nullptr);
+        { Gl3Range g("rmsnorm + qkv"); launch_matvec(ctx, PRO_RMS, EPI_STORE, L.wqkv, nullptr, ctx->x, L.attn_norm, ctx->qkv, nullptr); }
         pr.end();
 
         pr.begin(GL3_K_ATTENTION, 0);
-        launch_attention(ctx, l, 0, short_ctx);
+        { Gl3Range g("rope + kv write + attention"); launch_attention(ctx, l, 0, short_ctx); }
         pr.end();
         if ((r = all_gather(ctx, GB_XB, ctx->q_dim_l, pr)) != GL3_OK) return r;
 
         // x[rows of this rank] += Wo[rows, :] . xb — all rows on every rank when Wo is replicated (no gather behind it)
         const size_t wo_off = ctx->wo_replicated ? 0 : (size_t)rank * ctx->dim_l;
         pr.begin(GL3_K_MATVEC_WO, mv_bytes(L.wo), q8);
-        launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->x + wo_off, ctx->x + wo_off, ctx->resid_scale);
+        { Gl3Range g("wo + residual"); launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->x + wo_off, ctx->x + wo_off, ctx->resid_scale); }
         pr.end();
         if (!ctx->wo_replicated && (r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
 
         pr.begin(GL3_K_MATVEC_GATEUP, mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4, q8);
-        launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr);
+        { Gl3Range g("rmsnorm + gate/up + swiglu"); launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr); }
         pr.end();
         if ((r = all_gather(ctx, GB_HB, ctx->hidden_l, pr)) != GL3_OK) return r;
 
         pr.begin(GL3_K_MATVEC_DOWN, mv_bytes(L.w2), q8);
-        launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->x + (size_t)rank * ctx->dim_l,
-                      ctx->x + (size_t)rank * ctx->dim_l, ctx->resid_scale);
+        { Gl3Range g("down + residual");
+          launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->x + (size_t)rank * ctx->dim_l,
+                        ctx->x + (size_t)rank * ctx->dim_l, ctx->resid_scale); }
         pr.end();
         if ((r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
         if (ctx->taps) hipMemcpyAsync(ctx->taps + (size_t)l * d.dim, ctx->x, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, s);
     }
     if (want_logits) {
         pr.begin(GL3_K_MATVEC_LOGITS, mv_bytes(ctx->wcls) + d.dim * 4, q8);
-        launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm,
-                      ctx->logits + (size_t)rank * ctx->vocab_l, nullptr, ctx->logit_scale);
+        { Gl3Range g("final rmsnorm + logits");
+          launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm,
+                        ctx->logits + (size_t)rank * ctx->vocab_l, nullptr, ctx->logit_scale); }
         pr.end();
         if ((r = all_gather(ctx, GB_LOGITS, ctx->vocab_l, pr)) != GL3_OK) return r;
     }
@@ -442,7 +447,14 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP(hipFuncSetAttribute((const void*)rmsnorm_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     TRYHIP(hipFuncSetAttribute((const void*)attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     TRYHIP(hipFuncSetAttribute((const void*)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    if ((size_t)d.ctx * 4 + (size_t)PV_ROWS * PV_COLS * 4 + 64 > 150 * 1024) return bail(GL3_E_UNSUPPORTED, "context length above 20k not supported by the decode attention kernel");
+    // softmax rows longer than the LDS window (16384 positions; GL3_ATTN_WINDOW, a multiple of 1024, shrinks it for tests) run in
+    // windows with the sequential sum carried across them: no cap on the context length (r2 rejected contexts above ~20 k)
+    {
+        const char* wv = getenv("GL3_ATTN_WINDOW");
+        int wmax = wv && *wv ? atoi(wv) : 16384;
+        if (wmax < PV_ROWS || wmax % PV_ROWS != 0 || wmax > 16384) return bail(GL3_E_ARG, "GL3_ATTN_WINDOW must be a multiple of 1024 between 1024 and 16384");
+        ctx->attn_win = d.ctx <= wmax ? ((d.ctx + 3) & ~3) : wmax;
+    }
     TRY(dmalloc(ctx, &ctx->dyn, 4));
     ctx->dyn_cur = ctx->dyn;
     TRY(dmalloc(ctx, &ctx->argmax, 2 + 2 * AMX_WGS));          // result, ticket, (value, index) pairs of argmax_kernel
@@ -687,7 +699,7 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
     }
     if (ctx->staging) { hipFree(ctx->staging); ctx->staging = nullptr; ctx->staging_bytes = 0; }
     ctx->finalized = true;
-    if (!(d.flags & GL3_FLAG_NO_GRAPH) && !env_flag("GL3_NO_GRAPH", false)) {
+    if (!(d.flags & GL3_FLAG_NO_GRAPH) && !env_flag("GL3_NO_GRAPH", false) && !gl3_roctx_on()) {
         const double t0 = now_ms();
         int32_t r = capture(ctx, true, false, &ctx->graph, &ctx->graph_exec);
         if (r == GL3_OK && ctx->fused_attn_ok) r = capture(ctx, true, true, &ctx->graph_s, &ctx->graph_exec_s);

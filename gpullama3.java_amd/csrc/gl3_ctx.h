@@ -6,6 +6,8 @@
 #include <rccl/rccl.h>
 
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -23,6 +25,37 @@ static inline bool env_flag(const char* name, bool dflt) {
     if (!v || !*v) return dflt;
     return atoi(v) != 0;
 }
+
+// roctx ranges (SURVEY.md §5 "tracing"): GL3_ROCTX=1 brackets the decode step, every layer and every kernel class of an EAGER step
+// (graphs are switched off: a replayed graph has no per-layer host calls) with roctxRangePush / Pop, resolved at run time from
+// rocprofiler-sdk's roctx library (or roctracer's) so that the library has no link-time dependency on a profiler.
+//     GL3_ROCTX=1 rocprofv3 --marker-trace --kernel-trace --output-format csv -- python bench.py --steps 1 --no-pp
+#include <dlfcn.h>
+struct Gl3Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+static inline Gl3Roctx& gl3_roctx() {
+    static Gl3Roctx r = [] {
+        Gl3Roctx x;
+        if (!env_flag("GL3_ROCTX", false)) return x;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            x.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            x.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (!x.push || !x.pop) x = Gl3Roctx{};
+        }
+        return x;
+    }();
+    return r;
+}
+static inline bool gl3_roctx_on() { return gl3_roctx().push != nullptr; }
+struct Gl3Range {
+    bool on;
+    explicit Gl3Range(const char* name) : on(gl3_roctx_on()) { if (on) gl3_roctx().push(name); }
+    Gl3Range(const char* what, int i) : on(gl3_roctx_on()) { if (on) { char b[48]; snprintf(b, sizeof b, "%s %d", what, i); gl3_roctx().push(b); } }
+    ~Gl3Range() { if (on) gl3_roctx().pop(); }
+    Gl3Range(const Gl3Range&) = delete;
+    Gl3Range& operator=(const Gl3Range&) = delete;
+};
 
 constexpr int GL3_FMT_Q8V = 108;
 
@@ -89,6 +122,7 @@ struct gl3_ctx {
     // derived (local = this tensor-parallel rank's share)
     int q_dim = 0, kv_dim = 0, heads_l = 0, kv_heads_l = 0, q_dim_l = 0, kv_dim_l = 0, hidden_l = 0, vocab_l = 0, dim_l = 0;
     int n_tsplit = 1;        // ceil(ctx / 64) score tiles
+    int attn_win = 0;        // floats of a softmax row kept in LDS by the long-context attention kernels (longer rows: windows)
     bool wo_replicated = false;   // tensor parallel: every rank holds all rows of Wo (3 gathers per layer instead of 4)
     int wo_rows = 0;              // rows of Wo held by this rank: dim (replicated) or dim / tp
     // Granite (InferenceCore.forwardGranite): embedding / residual / logit multipliers (1 otherwise) and the score multiplier

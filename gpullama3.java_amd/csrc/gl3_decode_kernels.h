@@ -86,8 +86,8 @@ __device__ __forceinline__ float seq_add4(float s, const float4& a) {
     return s;
 }
 template <bool SQ>
-__device__ __forceinline__ float seq_sum_lds(const float* v, int n) {
-    float s = 0.f;
+__device__ __forceinline__ float seq_sum_lds(const float* v, int n, float start = 0.f) {     // start: running sum before v[0] (chunked rows)
+    float s = start;
     int i = 0;
     if (n >= 16) {                                     // software pipeline: the next 8 elements are in flight
         float4 a0 = *reinterpret_cast<const float4*>(v), a1 = *reinterpret_cast<const float4*>(v + 4);
@@ -426,6 +426,7 @@ struct AttnArgs {
     size_t seq_stride;       // floats between the KV caches of consecutive sequences
     int qkv_stride, xb_stride;   // floats between consecutive tokens' rows of qkv / xb
     float att_mul;           // 0: score / sqrt(head_size); Granite: score * attentionScale (forwardGranite :870-872)
+    int win;                 // attn_softmax_pv_kernel: floats of the softmax row held in LDS (a multiple of PV_ROWS); longer rows run in windows
     int group;               // attn_head_kernel: query heads per workgroup (0 / 1: one; kvMul: the whole group of a kv head)
     // attn_head_kernel, static-batched decode on one rank: the output leaves the kernel as the wo projection's int8 operand in the
     // small-batch layout (gl3_bd_gemm.h: XQ2 / XS2, xq_slots token slots) instead of f32 xb; NULL = write xb
@@ -769,7 +770,7 @@ static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnA
     const int h = blockIdx.x / nj, j0 = (blockIdx.x % nj) * PV_COLS;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kvh = h / kvmul;
     const int n = a.dyn[1] + 1;
-    float* vbuf = e_s + ((a.ctx + 3) & ~3);
+    float* vbuf = e_s + a.win;                        // win = min(ctx rounded up to 4, window)
     const float* vbase = a.vcache + kvh * hs + j0;
     constexpr int SU = PV_ROWS * 4 / 256;         // thread = (row t>>2 + 64u, column quad t&3)
     float4 sreg[SU];
@@ -793,46 +794,73 @@ static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnA
     ATT_STAMP(0);
     stage_issue(0, min(n, PV_ROWS));
     ATT_STAMP(1);
-    {   // softmax of the head
-        const float* sc = a.att + (size_t)h * a.ctx;
-        float mx = -INFINITY;
-        for (int i = t; i < n; i += 256) { const float s = sc[i]; e_s[i] = s; mx = fmaxf(mx, s); }
+    const float* sc = a.att + (size_t)h * a.ctx;
+    const int W = a.win;                              // LDS window of the row
+    float mx = -INFINITY, sum = 0.f;
+    {   // softmax of the head: max, exp in double, strictly sequential f32 sum, divide (FloatTensor.softmaxInPlace :195-219)
+        if (n <= W) {
+            for (int i = t; i < n; i += 256) { const float s = sc[i]; e_s[i] = s; mx = fmaxf(mx, s); }
+        } else {
+            for (int i = t; i < n; i += 256) mx = fmaxf(mx, sc[i]);
+        }
         mx = wave_max(mx);
         if (lane == 0) red_s[wave] = mx;
         __syncthreads();
         mx = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));
         ATT_STAMP(2);
-        for (int i = t; i < n; i += 256) e_s[i] = (float)exp((double)(e_s[i] - mx));
-        __syncthreads();
-        ATT_STAMP(3);
-        if (wave == 0) { const float sum = seq_sum_lds<false>(e_s, n); if (lane == 0) red_s[4] = sum; }
-        __syncthreads();
-        ATT_STAMP(4);
-        const float sum = red_s[4];
-        for (int i = t; i < n; i += 256) e_s[i] = e_s[i] / sum;
+        if (n <= W) {
+            for (int i = t; i < n; i += 256) e_s[i] = (float)exp((double)(e_s[i] - mx));
+            __syncthreads();
+            ATT_STAMP(3);
+            if (wave == 0) { const float sm = seq_sum_lds<false>(e_s, n); if (lane == 0) red_s[4] = sm; }
+            __syncthreads();
+            ATT_STAMP(4);
+            sum = red_s[4];
+            for (int i = t; i < n; i += 256) e_s[i] = e_s[i] / sum;
+        } else {
+            // Row longer than the window (contexts beyond ~16 k positions): the sum runs over the windows in order, carrying the
+            // running value; the numerators are recomputed per window below (same exp of the same argument -> same bits).
+            for (int c0 = 0; c0 < n; c0 += W) {
+                const int len = min(W, n - c0);
+                __syncthreads();
+                for (int i = t; i < len; i += 256) e_s[i] = (float)exp((double)(sc[c0 + i] - mx));
+                __syncthreads();
+                if (wave == 0) { const float sm = seq_sum_lds<false>(e_s, len, c0 == 0 ? 0.f : red_s[4]); if (lane == 0) red_s[4] = sm; }
+            }
+            __syncthreads();
+            sum = red_s[4];
+        }
     }
     stage_commit(min(n, PV_ROWS));
     __syncthreads();
     ATT_STAMP(5);
     v4f acc = {0.f, 0.f, 0.f, 0.f};
-    for (int r0 = 0; r0 < n; r0 += PV_ROWS) {
-        const int nr = min(PV_ROWS, n - r0);
-        if (r0 > 0) { __syncthreads(); stage_issue(r0, nr); stage_commit(nr); __syncthreads(); }
-        if (wave == 0) {                               // lane l = column l&15, timestep 4g + (l>>4)
-            const int col = lane & 15, k = lane >> 4;
-            const float* ap = e_s + r0;
-            int g = 0;
-            for (; 4 * g + 16 <= nr; g += 4) {          // 4 MFMAs per iteration, operands fetched first
-                float p[4];
+    for (int c0 = 0; c0 < n; c0 += W) {                // one trip unless the row is longer than the window
+        const int clen = min(W, n - c0);
+        if (n > W) {
+            __syncthreads();
+            for (int i = t; i < clen; i += 256) e_s[i] = (float)exp((double)(sc[c0 + i] - mx)) / sum;
+            __syncthreads();
+        }
+        for (int r0 = c0; r0 < c0 + clen; r0 += PV_ROWS) {
+            const int nr = min(PV_ROWS, c0 + clen - r0);
+            if (r0 > 0) { __syncthreads(); stage_issue(r0, nr); stage_commit(nr); __syncthreads(); }
+            if (wave == 0) {                               // lane l = column l&15, timestep 4g + (l>>4)
+                const int col = lane & 15, k = lane >> 4;
+                const float* ap = e_s + (r0 - c0);
+                int g = 0;
+                for (; 4 * g + 16 <= nr; g += 4) {          // 4 MFMAs per iteration, operands fetched first
+                    float p[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int r = 4 * (g + u) + k; p[u] = ap[r] * vbuf[r * PV_COLS + col]; }
+                    for (int u = 0; u < 4; ++u) { const int r = 4 * (g + u) + k; p[u] = ap[r] * vbuf[r * PV_COLS + col]; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p[u], 1.0f, acc, 0, 0, 0);
-            }
-            for (; 4 * g < nr; ++g) {
-                const int r = 4 * g + k;
-                const float p = r < nr ? ap[r] * vbuf[r * PV_COLS + col] : 0.f;   // +0 pads the last group
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p, 1.0f, acc, 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p[u], 1.0f, acc, 0, 0, 0);
+                }
+                for (; 4 * g < nr; ++g) {
+                    const int r = 4 * g + k;
+                    const float p = r < nr ? ap[r] * vbuf[r * PV_COLS + col] : 0.f;   // +0 pads the last group
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p, 1.0f, acc, 0, 0, 0);
+                }
             }
         }
     }

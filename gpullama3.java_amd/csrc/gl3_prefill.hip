@@ -488,6 +488,7 @@ struct PfAttnArgs {
     int n_heads, n_kv_heads, hs, kv_dim, ctx;
     const int32_t* seq; const int32_t* pos; size_t seq_stride;
     float att_mul;                       // 0: score / sqrt(head_size); Granite: score * attentionScale
+    int win;                             // pf_attn_softmax_pv_kernel: floats of a softmax row held in LDS (longer rows: windows)
 };
 
 __global__ void pf_attn_scores_kernel(const PfAttnArgs a) {
@@ -522,39 +523,60 @@ __global__ void pf_attn_scores_kernel(const PfAttnArgs a) {
     }
 }
 
-// softmax + weighted V sum: grid = (n_heads * ceil(hs/64), ntok), block = 64
+// softmax + weighted V sum: grid = (n_heads * ceil(hs/64), ntok), block = 64.  The row sits in LDS when it fits the window
+// (a.win floats); longer rows (contexts beyond ~16 k positions) run in windows: the sequential sum carries its running value
+// across them and the numerators are recomputed per window for the weighted V sum (same exp of the same argument -> same bits).
 __global__ __launch_bounds__(64) void pf_attn_softmax_pv_kernel(const PfAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float e_s[];
     const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads;
     const int nj = (hs + 63) / 64;
     const int h = blockIdx.x / nj, j = (blockIdx.x % nj) * 64 + threadIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x, kvh = h / kvmul;
-    const int n = a.pos[b] + 1;
+    const int n = a.pos[b] + 1, W = a.win;
     const float* sc = a.att + ((size_t)b * a.n_heads + h) * a.ctx;
     float mx = -INFINITY;
-    for (int i = lane; i < n; i += 64) { const float s = sc[i]; e_s[i] = s; mx = fmaxf(mx, s); }
+    if (n <= W) { for (int i = lane; i < n; i += 64) { const float s = sc[i]; e_s[i] = s; mx = fmaxf(mx, s); } }
+    else { for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sc[i]); }
     mx = wave_max(mx);
     __syncthreads();
-    for (int i = lane; i < n; i += 64) e_s[i] = (float)exp((double)(e_s[i] - mx));
-    __syncthreads();
-    const float sum = seq_sum_lds<false>(e_s, n);
-    __syncthreads();
-    for (int i = lane; i < n; i += 64) e_s[i] = e_s[i] / sum;
-    __syncthreads();
-    if (j < hs) {
-        const float* v = a.vcache + (size_t)a.seq[b] * a.seq_stride + kvh * hs + j;
-        float acc = 0.f;
+    float sum = 0.f;
+    if (n <= W) {
+        for (int i = lane; i < n; i += 64) e_s[i] = (float)exp((double)(e_s[i] - mx));
+        __syncthreads();
+        sum = seq_sum_lds<false>(e_s, n);
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) e_s[i] = e_s[i] / sum;
+        __syncthreads();
+    } else {
+        for (int c0 = 0; c0 < n; c0 += W) {
+            const int len = min(W, n - c0);
+            __syncthreads();
+            for (int i = lane; i < len; i += 64) e_s[i] = (float)exp((double)(sc[c0 + i] - mx));
+            __syncthreads();
+            sum = seq_sum_lds<false>(e_s, len, sum);
+        }
+    }
+    const float* v = a.vcache + (size_t)a.seq[b] * a.seq_stride + kvh * hs + min(j, hs - 1);
+    float acc = 0.f;
+    for (int c0 = 0; c0 < n; c0 += W) {                 // one trip unless the row is longer than the window
+        const int clen = min(W, n - c0);
+        if (n > W) {
+            __syncthreads();
+            for (int i = lane; i < clen; i += 64) e_s[i] = (float)exp((double)(sc[c0 + i] - mx)) / sum;
+            __syncthreads();
+        }
+        const float* vw = v + (size_t)c0 * a.kv_dim;
         int tt = 0;
-        for (; tt + 8 <= n; tt += 8) {
+        for (; tt + 8 <= clen; tt += 8) {
             float vv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = v[(size_t)(tt + u) * a.kv_dim];
+            for (int u = 0; u < 8; ++u) vv[u] = vw[(size_t)(tt + u) * a.kv_dim];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = e_s[tt + u] * vv[u] + acc;
         }
-        for (; tt < n; ++tt) acc = e_s[tt] * v[(size_t)tt * a.kv_dim] + acc;
-        a.out[(size_t)b * a.out_stride + h * hs + j] = acc;
+        for (; tt < clen; ++tt) acc = e_s[tt] * vw[(size_t)tt * a.kv_dim] + acc;
     }
+    if (j < hs) a.out[(size_t)b * a.out_stride + h * hs + j] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -994,7 +1016,8 @@ static void pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
     } else {
         const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
         hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, KVH, n), dim3(64 * kvmul), sm1, s, aa);
-        hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(H * ((d.head_size + 63) / 64), n), dim3(64), (size_t)d.ctx * 4 + 16, s, aa);
+        aa.win = ctx->attn_win;
+        hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(H * ((d.head_size + 63) / 64), n), dim3(64), (size_t)ctx->attn_win * 4 + 16, s, aa);
     }
 }
 
@@ -1018,6 +1041,7 @@ static void launch_gemm_vl(gl3_ctx* ctx, const Q8Mat& w, int ntok, const float* 
 // The same layers for F16 / Q4_0 / Q8_0-with-f32-activation matrices on one rank: RMSNorm to f32 (exact sum of squares), GEMMs on
 // the f32 activations, gate and up as two GEMMs + an element-wise SwiGLU.
 static int32_t pf_layers_vl(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
+    Gl3Range chunk_range("gl3 batched step, tokens", n);
     gl3_prefill_state* p = ctx->pf;
     const gl3_model_desc& d = ctx->d;
     hipStream_t s = ctx->stream;
@@ -1028,6 +1052,7 @@ static int32_t pf_layers_vl(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
     const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
     for (int l = 0; l < d.n_layers; ++l) {
         gl3_layer& L = ctx->layers[l];
+        Gl3Range layer_range("layer", l);
         hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM_F32>), dim3(n), dim3(256), nq, s, p->X, d.dim, d.dim, L.attn_norm, d.rms_eps, (uint8_t*)nullptr, p->XN, 0, 0);
         launch_gemm_vl<EPI_STORE>(ctx, L.wqkv, n, p->XN, d.dim, p->QKV, qkv_dim);
         pf_attention(ctx, l, n, max_pos, one_seq, p->AO, false);
@@ -1046,6 +1071,7 @@ static int32_t pf_layers_vl(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
 // All layers for n tokens whose (token, sequence, position) are already on the device.  max_pos = largest position.
 // one_seq >= 0: all n tokens belong to that sequence at consecutive positions ending at max_pos (prefill).
 static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
+    Gl3Range chunk_range("gl3 batched step, tokens", n);
     gl3_prefill_state* p = ctx->pf;
     if (p->vl) return pf_layers_vl(ctx, n, max_pos, one_seq);
     const gl3_model_desc& d = ctx->d;
@@ -1067,6 +1093,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
     auto nq_smem = [&](int k) { return (size_t)(k + 32) * 4 + ss_scratch_bytes(k) + 64; };
     for (int l = 0; l < d.n_layers; ++l) {
         gl3_layer& L = ctx->layers[l];
+        Gl3Range layer_range("layer", l);
         hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.attn_norm, d.rms_eps,
                            p->XQ, p->XS, p->maxk, bd_tslots(n));
         launch_gemm<EPI_STORE>(ctx, L.wqkv, nullptr, n, p->QKV, qkv_dim);
@@ -1183,7 +1210,7 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
     // ~400 launches per step: replay them as one hipGraph per batch size.  Nothing position-dependent is baked in when every
     // position is below AF_MAXN (the one-launch attention reads sequence ids / positions from device memory).
     static const bool graphs_off = getenv("GL3_NO_GRAPH") && atoi(getenv("GL3_NO_GRAPH"));
-    const bool graphable = !graphs_off && !(d.flags & GL3_FLAG_NO_GRAPH) && ctx->fused_attn_ok && max_pos < AF_MAXN && ctx->transport != GL3_TP_RCCL;
+    const bool graphable = !graphs_off && !gl3_roctx_on() && !(d.flags & GL3_FLAG_NO_GRAPH) && ctx->fused_attn_ok && max_pos < AF_MAXN && ctx->transport != GL3_TP_RCCL;
     if (graphable) {
         if ((int)p->step_graphs.size() <= n) p->step_graphs.resize(n + 1, nullptr);
         if (!p->step_graphs[n]) {

@@ -379,11 +379,16 @@ def test_native_bench_host_over_the_c_abi(pkg, orc, planmod, tmp_path):
     assert ids == [orc.argmax(o.forward(toks[i], i)) for i in range(12)]          # greedy ids of the CPU oracle on the same file
 
 
-@pytest.mark.parametrize("cfg", ["tiny-llama", "tiny-qwen3"])
-def test_long_context_prefill_and_decode(pkg, orc, planmod, cfg):
+@pytest.mark.parametrize("cfg,window", [("tiny-llama", None), ("tiny-qwen3", None), ("tiny-llama", 1024), ("phi3-hs96", 1024)])
+def test_long_context_prefill_and_decode(pkg, orc, planmod, cfg, window, monkeypatch):
     """Context beyond one V slab (PV_ROWS = 1024) and beyond 16 score tiles: batched prefill in 512-token chunks that start
-    at non-zero positions, then decode steps at positions > 1024, all bit-identical to the oracle."""
+    at non-zero positions, then decode steps at positions > 1024, all bit-identical to the oracle.
+    window = 1024 (GL3_ATTN_WINDOW): the softmax rows of positions >= 1024 no longer fit the LDS window and run in windows with the
+    sequential sum carried across them — the path contexts beyond 16 k positions take (decode kernel; phi3-hs96 = head size 96 also
+    takes the per-token prefill kernels)."""
     plan_mod, hip = planmod
+    if window:
+        monkeypatch.setenv("GL3_ATTN_WINDOW", str(window))
     base = pkg.synth.CONFIGS[cfg]
     m = pkg.synth.make_numpy(pkg.synth.ModelConfig(**{**base.__dict__, "ctx": 1300}), seed=31)
     plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=512)
@@ -404,3 +409,22 @@ def test_long_context_prefill_and_decode(pkg, orc, planmod, cfg):
             ko, vo = o.kv(l, p)
             assert np.array_equal(k, ko) and np.array_equal(v, vo), (l, p)
     plan.freeTornadoExecutionPlan()
+
+
+@pytest.mark.gpu
+def test_context_beyond_20k_positions(pkg, orc, planmod):
+    """Round 2 rejected contexts above ~20 k positions (the decode attention kept a ctx-long softmax row in LDS); the reference has
+    no such cap (InferenceCore.java:98-137 is O(pos)).  A decode step at position 20 600 of a 21 000-position context, on a KV cache
+    that holds one prefilled chunk and zeros elsewhere (both sides zero-initialise it), is bit-identical to the oracle."""
+    plan_mod, hip = planmod
+    base = pkg.synth.CONFIGS["tiny-llama"]
+    m = pkg.synth.make_numpy(pkg.synth.ModelConfig(**{**base.__dict__, "ctx": 21000}), seed=5)
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=64)
+    o = orc.COracle(m)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 40)
+    plan.tornadoVMForwardBatchPrefill(toks[:32], 0)
+    o.prefill(toks[:32], 0)
+    for i, p in enumerate((20600, 20601, 16384, 16383)):
+        ref = o.forward(toks[32 + i], p)
+        got = plan.forward_decode(toks[32 + i], p)
+        assert np.array_equal(got, ref), (p, rel(got, ref))
