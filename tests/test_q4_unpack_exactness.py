@@ -27,8 +27,9 @@ def test_fma_with_negative_zero_addend_is_the_rounded_product():
                          np.array([0.0, -0.0, 1e-40, -1e-40, 3.4e38, -3.4e38, 1.17549435e-38], dtype=np.float32)])
     for n in range(16):
         h = np.float32(n - 8)
-        prod = xs * h                                            # f32 multiply, one rounding
-        fma = (xs.astype(np.float64) * np.float64(h) + np.float64(-0.0)).astype(np.float32)   # exact product (<= 28 bits) + (-0), one rounding
+        with np.errstate(over="ignore"):                         # +-3.4e38 * 8 overflows to inf on both sides
+            prod = xs * h                                        # f32 multiply, one rounding
+            fma = (xs.astype(np.float64) * np.float64(h) + np.float64(-0.0)).astype(np.float32)   # exact product (<= 28 bits) + (-0), one rounding
         assert np.array_equal(prod.view(np.uint32), fma.view(np.uint32)), n
 
 
