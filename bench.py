@@ -18,8 +18,9 @@ with logits + D2H).
 
 N > 1 runs ONE model tensor-parallel over N GPUs, one process per GPU: every matrix is split by OUTPUT rows (heads /
 hidden units / dim rows / vocab rows) so each dot product stays whole and in the reference's order on one rank
-(bit-identical results), and the activations are re-assembled by 4 all-gathers per layer + 1 for the logits (DESIGN.md
-section 7).  Total work is fixed, so "scaling": "strong".
+(bit-identical results), Wo is replicated, and the activations are re-assembled by 3 all-gathers per layer + 1 for the logits
+(DESIGN.md section 7).  Total work is fixed, so "scaling": "strong".  Without a launcher `--gpus N` starts its own N ranks and
+fails loudly if fewer than N devices are visible.
 
 Extra objects: `roofline` — the dominant decode kernel (fused gate/up Q8_0 matvec): `avg_us` = one HIP event pair on the
 plan's stream around back-to-back launches over all layers' weights (the figure the committed rocprofv3 kernel statistics

@@ -1,4 +1,6 @@
 """Host-side logic that needs no GPU: java.util.Random stream, GGUF round trip, quantisers."""
+import os
+
 import numpy as np
 
 
@@ -94,3 +96,24 @@ def test_recorded_bench_lines_follow_the_driver_contract():
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["parity_rel_err_fullsize"] == 0.0
     d = json.load(open(os.path.join(root, "profiles", "r01_bench_8b.json")))
     assert d["metric"] == "tg128 tok/s (llama-bench), Llama-3-8B Q8_0" and d["pp"]["batch"] == 512
+
+
+def test_bench_gpus_n_never_runs_on_fewer_devices():
+    """`bench.py --gpus N` must not silently benchmark fewer GPUs (round-2 review): without a launcher it starts its own N ranks
+    and refuses when fewer than N devices are visible; with a launcher whose WORLD_SIZE differs from N it refuses as well.  No GPU
+    here, so both refusals can be observed: non-zero exit, the reason on stderr, and no JSON line on stdout."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GL3_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0
+        assert "--gpus 2 requested but only" in r.stderr
+        assert "n_gpus" not in r.stdout
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0
+    assert "--gpus 2 but WORLD_SIZE=1" in r2.stderr
+    assert "n_gpus" not in r2.stdout
