@@ -114,15 +114,16 @@ typedef struct {
     int32_t n_layers;       /* block_count */
     int32_t n_heads;        /* attention.head_count */
     int32_t n_kv_heads;     /* attention.head_count_kv */
-    int32_t head_size;      /* dim / n_heads (llama) or attention.key_length (qwen3) */
+    int32_t head_size;      /* dim / n_heads (llama, phi3) or attention.key_length (qwen3); a multiple of 32 in 32 .. 256 */
     int32_t vocab;
-    int32_t ctx;            /* context length = KV-cache rows per layer */
+    int32_t ctx;            /* context length = KV-cache rows per layer (no upper bound besides memory: f32 K and V rows) */
     float   rms_eps;        /* attention.layer_norm_rms_epsilon */
     int32_t weight_type;    /* GL3_TYPE_* of the matrices */
     int32_t max_batch;      /* largest prefill chunk (llama.prefillBatchSize); <= 1: no batched prefill buffers */
     int32_t device;         /* HIP device ordinal */
     int32_t tp_rank;        /* tensor-parallel rank of this process (0 when tp_size == 1) */
-    int32_t tp_size;        /* tensor-parallel degree: heads / hidden units / vocab rows are split tp_size ways */
+    int32_t tp_size;        /* tensor-parallel degree: heads / hidden units / dim rows of W2 / vocab rows are split tp_size ways
+                             * (Wo is replicated: a rank computes the whole projection from the gathered attention output) */
     uint32_t flags;         /* GL3_FLAG_* */
     int32_t n_seqs;         /* independent sequences with their own KV cache (static batched decode); 0 or 1 = one */
     /* GL3_ARCH_GRANITE only (GraniteLoader.java:55-58: granite.embedding_scale, granite.attention.scale, granite.residual_scale,
