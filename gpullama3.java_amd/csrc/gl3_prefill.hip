@@ -22,6 +22,8 @@
 
 using namespace gl3;
 #include "gl3_bd_gemm.h"      // GemmArgs, bdw_gemm_kernel (expects the gl3 names in scope)
+// gl3_prefill_gemm2.hip (own translation unit, -fno-slp-vectorize): the > 64-token GEMM with the scale products on the matrix pipe (r4)
+void gl3_gemm2_launch(int epi, const GemmArgs& a, int rows, int ntok, int mode, hipStream_t s);
 
 struct gl3_prefill_state {
     int max_batch = 0;
@@ -940,6 +942,9 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     const int ntt = (ntok + GM_TOK - 1) / GM_TOK;
     a.ntt = ntt;
     auto grid = [&](int nrt) { a.nrt = nrt; return dim3(8 * ((ntt * nrt + 7) / 8)); };
+    // r4: scale products on the matrix pipe (gl3_prefill_gemm2.h).  GL3_PF_GEMM2=0: the r3 kernel; 1: -B s on the VALU (A/B switches)
+    static const int g2 = getenv("GL3_PF_GEMM2") ? atoi(getenv("GL3_PF_GEMM2")) : 2;
+    if (g2) { gl3_gemm2_launch(EPI, a, w.rows, ntok, g2, ctx->stream); return; }
     if constexpr (EPI == EPI_SWIGLU) {
         const dim3 g = grid((w.rows + 63) / 64);
         hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 4>), g, dim3(256), 2 * gm_stage_bytes(128), ctx->stream, a);

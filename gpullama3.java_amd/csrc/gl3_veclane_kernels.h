@@ -440,9 +440,12 @@ static __global__ __launch_bounds__(64 * MAXW) void matvec_vlq_kernel(const VlAr
     int4 wq[NM][RCM];
     int4 wsc4[NM][WT == WT_Q4_0 ? RCM : 1];
     uint2 wsc8[NM][WT == WT_Q8_0 ? RCM : 1];
-    float4 xr[RCM * CE / 256];
+    // float4 loads per lane that stage one round's activation slice (RCM chunks of CE floats).  Rounded UP: Q8_0 / SWIGLU / 16
+    // wavefronts has RCM * CE = 384, and a truncated 384 / 256 = 1 left the third chunk's slice unstaged (r3 advisor finding).
+    constexpr int XQ = (RCM * CE + 255) / 256;
+    static_assert(XQ * 256 >= RCM * CE, "the x staging registers must cover a round's chunks");
+    float4 xr[XQ];
     float sm[NM][RCM * CB];
-    constexpr int XQ = RCM * CE / 256;
 
 #define VQ_ISSUE(R_)                                                                                                     \
     do {                                                                                                                 \

@@ -9,9 +9,13 @@ Q4_0, Q8_0 = 2, 3
 
 
 def round_chunks(wt, maxw, nm):
-    if nm == 1:
-        return (8 if wt == Q4_0 else 12) // (2 if maxw == 16 else 1)
-    return ((1 if maxw == 16 else 3) if wt == Q4_0 else (2 if maxw == 16 else 4))
+    """vq_round_chunks<WT, MAXW>(nm): chunks per wavefront and round (integer divisions in the kernel's order)."""
+    return (8 if wt == Q4_0 else 12) // (2 if maxw == 16 else 1) // nm
+
+
+def x_quads(wt, maxw, nm):
+    """XQ of matvec_vlq_kernel: float4 loads per lane that stage a round's activation slice (rounded up)."""
+    return (round_chunks(wt, maxw, nm) * chunk_elems(wt) + 255) // 256
 
 
 def chunk_elems(wt):
@@ -37,6 +41,9 @@ def kernel_ranges(wt, k, nm, nw):
     nrounds = (nch + nw * rcm - 1) // (nw * rcm)
     rc = (nch + nw * nrounds - 1) // (nw * nrounds)
     assert 1 <= rc <= rcm, (wt, k, nm, nw, rc, rcm)
+    # the x staging registers (XQ float4 per lane, 64 lanes) must cover every chunk of a round (r3 advisor finding: Q8_0 /
+    # two matrices / 16 wavefronts has rcm * 128 = 384 floats, and a truncated XQ = 1 staged only 256 of them)
+    assert rc * chunk_elems(wt) <= x_quads(wt, maxw, nm) * 256, (wt, k, nm, nw, rc)
     order = []
     for r in range(nrounds):
         for w in range(nw):                      # chain order inside a round: wavefront 0, 1, ...
@@ -74,3 +81,12 @@ def test_wave_count_fills_the_chip_for_rank_slices():
     assert vq_waves(Q4_0, 4096, 1, 64) == 16          # wo slice of a tp = 8 rank
     assert vq_waves(Q4_0, 14336, 1, 64) == 16
     assert vq_waves(Q4_0, 256, 1, 8) == 4             # never more wavefronts than chunks (beyond the minimum of 4)
+
+
+def test_round_chunks_match_the_kernel_formula():
+    assert [round_chunks(Q4_0, 8, 1), round_chunks(Q4_0, 16, 1), round_chunks(Q4_0, 8, 2), round_chunks(Q4_0, 16, 2)] == [8, 4, 4, 2]
+    assert [round_chunks(Q8_0, 8, 1), round_chunks(Q8_0, 16, 1), round_chunks(Q8_0, 8, 2), round_chunks(Q8_0, 16, 2)] == [12, 6, 6, 3]
+    # the shape of the finding: dim 5120 / hidden 6912 at tp = 8 -> 108 groups, 16 wavefronts, 40 chunks, rc = 3
+    assert vq_waves(Q8_0, 5120, 2, 108) == 16
+    _, nch, _ = kernel_ranges(Q8_0, 5120, 2, 16)
+    assert nch == 40 and x_quads(Q8_0, 16, 2) == 2
