@@ -943,8 +943,13 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     a.ntt = ntt;
     auto grid = [&](int nrt) { a.nrt = nrt; return dim3(8 * ((ntt * nrt + 7) / 8)); };
     // r4: scale products on the matrix pipe (gl3_prefill_gemm2.h).  GL3_PF_GEMM2=0: the r3 kernel; 1: -B s on the VALU (A/B switches)
+    // Default: the gate/up GEMM (two matrices per workgroup, the dominant launch) on the r4 kernel — measured 246-250 us against 266-272
+    // for the r3 kernel at 512 tokens of the 8B layer; the other shapes stay on the r3 kernel (qkv 79 vs 80, wo 57 vs 45, down 222 vs 139:
+    // profiles/r04_gemm_experiments.md).  GL3_PF_GEMM2=0: r3 kernel everywhere; GL3_PF_GEMM2_ALL=1: r4 kernel for every shape;
+    // GL3_PF_GEMM2=1 / 4: A/B forms (-B s on the VALU / one tile per wavefront).
     static const int g2 = getenv("GL3_PF_GEMM2") ? atoi(getenv("GL3_PF_GEMM2")) : 2;
-    if (g2) { gl3_gemm2_launch(EPI, a, w.rows, ntok, g2, ctx->stream); return; }
+    static const bool g2_all = getenv("GL3_PF_GEMM2_ALL") && atoi(getenv("GL3_PF_GEMM2_ALL"));
+    if (g2 && (EPI == EPI_SWIGLU || g2_all)) { gl3_gemm2_launch(EPI, a, w.rows, ntok, g2, ctx->stream); return; }
     if constexpr (EPI == EPI_SWIGLU) {
         const dim3 g = grid((w.rows + 63) / 64);
         hipLaunchKernelGGL((pf_gemm_kernel<EPI, 1, 4>), g, dim3(256), 2 * gm_stage_bytes(128), ctx->stream, a);

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void pf_gemm2_kernel(const GemmArgs a
         // wavefronts of a CU issuing their pieces at once queue behind each other in the texture-address unit: ~700 cycles per
         // stage measured).  Past the last stage the fill repeats stage nkb - 1 into a slot nobody reads: no branches.
         const int kf = min(kb + 2, nkb - 1);
-#ifndef G2_SKIP_MEM
+#if !defined(G2_SKIP_MEM) && !defined(G2_ASYNC_EXPERIMENT)
         scale_load(kf);
 #endif
         G2_STAMP(tm_issue);
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void pf_gemm2_kernel(const GemmArgs a
         });
         G2_STAMP(tm_comp);
         static_assert(NDMA <= NTILE, "one LDS-DMA piece per step");
-#ifndef G2_SKIP_MEM
+#if !defined(G2_SKIP_MEM) && !defined(G2_ASYNC_EXPERIMENT)
         stage_store(fil);
         scale_store(kf, fil);
 #endif
@@ -355,7 +355,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void pf_gemm2_kernel(const GemmArgs a
         __builtin_amdgcn_s_waitcnt(0);                 // vmcnt(0) lgkmcnt(0): the LDS-DMA wait is charged to "store", not to the barrier
 #endif
         G2_STAMP(tm_store);
+#ifdef G2_ASYNC_EXPERIMENT
+        // timing experiment (wrong results: the scale operands are never refreshed): only LDS-DMA in the loop, and the barrier
+        // leaves the pieces issued during THIS stage in flight (they are needed one stage later)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NDMA) : "memory");
+#else
         __syncthreads();                               // slot fil complete for every wavefront; slot cur free
+#endif
         G2_STAMP(tm_bar);
         cur = nxt;
     }

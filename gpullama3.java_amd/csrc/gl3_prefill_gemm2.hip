@@ -7,6 +7,7 @@
 using namespace gl3;
 #include "gl3_bd_gemm.h"          // GemmArgs
 #include "gl3_prefill_gemm2.h"
+#include "gl3_prefill_gemm4.h"
 
 // LDS request of a variant; set once (dynamic LDS above 64 KB needs the attribute, below it is harmless)
 template <int EPI, int RF, int NW, int OCC, int MODE>
@@ -40,7 +41,33 @@ static void g2_dispatch(GemmArgs a, int rows, int ntok, int mode, hipStream_t s)
 #undef GL3_G2
 }
 
+// One tile per wavefront, four wavefronts per SIMD (gl3_prefill_gemm4.h): 128-row workgroup tiles (16 wavefronts, one workgroup per
+// CU) when they give every CU a workgroup, else 64-row tiles (8 wavefronts, two workgroups per CU).
+template <int EPI, int WR>
+static void g4_launch(GemmArgs a, int rows, int ntok, hipStream_t s) {
+    constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1, RPM = 32 * WR / NM;
+    constexpr int LDS = G2_RING * g2_stage_bytes(32 * WR);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)pf_gemm4_kernel<EPI, WR, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+    a.ntt = (ntok + 127) / 128;
+    a.nrt = (rows + RPM - 1) / RPM;
+    hipLaunchKernelGGL((pf_gemm4_kernel<EPI, WR, 4>), dim3(8 * ((a.ntt * a.nrt + 7) / 8)), dim3(256 * WR), LDS, s, a);
+}
+template <int EPI>
+static void g4_dispatch(const GemmArgs& a, int rows, int ntok, hipStream_t s) {
+    constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1;
+    const int ntt = (ntok + 127) / 128;
+    if ((size_t)ntt * ((rows + 128 / NM - 1) / (128 / NM)) >= 256) g4_launch<EPI, 4>(a, rows, ntok, s);
+    else g4_launch<EPI, 2>(a, rows, ntok, s);
+}
+
 void gl3_gemm2_launch(int epi, const GemmArgs& a, int rows, int ntok, int mode, hipStream_t s) {
+    if (mode >= 4) {
+        if (epi == EPI_SWIGLU) g4_dispatch<EPI_SWIGLU>(a, rows, ntok, s);
+        else if (epi == EPI_RESID) g4_dispatch<EPI_RESID>(a, rows, ntok, s);
+        else g4_dispatch<EPI_STORE>(a, rows, ntok, s);
+        return;
+    }
     if (epi == EPI_SWIGLU) g2_dispatch<EPI_SWIGLU>(a, rows, ntok, mode, s);
     else if (epi == EPI_RESID) g2_dispatch<EPI_RESID>(a, rows, ntok, mode, s);
     else g2_dispatch<EPI_STORE>(a, rows, ntok, mode, s);
