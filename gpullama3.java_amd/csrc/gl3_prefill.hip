@@ -771,6 +771,255 @@ __global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 4: scores + softmax + weighted V sum of ONE sequence's prefill chunk in one launch (the three kernels above stay for long
+// contexts and odd shapes).  Workgroup = (kv head, tile of FA_TB = 8 tokens), 2 * kvMul wavefronts; the score rows of the tile's
+// kvMul x 8 (query head, token) pairs live in LDS from the first q.k to the last a.v — no [token][head][ctx] round trip through
+// HBM / L2 (33 MB written, read, rewritten and read again per 8B layer at 512 tokens) and one launch instead of three.
+//   phase 1  scores: the K tiles of 64 timesteps alternate between the two wavefront groups; thread = (query head, timestep), K row
+//            in registers, the query rows as SGPR operands (pf_scores_tiled_kernel's inner loop: j ascending, product rounded, no FMA)
+//   phase 2  softmax rows (FloatTensor.softmaxInPlace): max, exp in double, the strictly sequential sum of ALL rows at once
+//            (lane = row: 32 chains side by side instead of one row per wavefront), divide
+//   phase 3  weighted V sum: V tiles of 64 timesteps through LDS, wavefront = (query head, 4 tokens), lane = 2 columns,
+//            acc = a_t * v + acc with t ascending (pf_pv_tiled_kernel's inner loop)
+// Tiles are dealt heaviest (latest positions) first, so the triangular work profile does not leave a tail.
+constexpr int FA_TB = 8;
+__host__ __device__ constexpr size_t fa_smem_bytes(int hs, int kvmul, int sstride) {
+    return ((size_t)kvmul * FA_TB * sstride + 2 * 64 * (hs + 4) + 64) * 4;
+}
+template <int HS>
+__global__ __launch_bounds__(512) void pf_attn_fused_kernel(const float* __restrict__ Q, int q_stride, const float* __restrict__ kc, const float* __restrict__ vc,
+                                                            float* __restrict__ out, int out_stride, int n_kv_heads, int kvmul, int kv_dim,
+                                                            int pos0, int ntok, float att_mul, int sstride) {
+    extern __shared__ __attribute__((aligned(16))) float fa_sm[];
+    constexpr int PITCH = HS + 4, H4 = HS / 4, NCOL = HS > 64 ? 2 : 1;
+    float* Ssc = fa_sm;                                             // [kvmul][FA_TB][sstride] score -> softmax rows
+    float* kt = fa_sm + (size_t)kvmul * FA_TB * sstride;            // [2][64][PITCH] K (phase 1) / V (phase 3) tiles
+    float* sums = kt + 2 * 64 * PITCH;                              // [kvmul * FA_TB]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nthr = blockDim.x, gthreads = 64 * kvmul;
+    const int grp = wave / kvmul, hq = wave % kvmul, gt = t - grp * gthreads;
+    const int ntile = (ntok + FA_TB - 1) / FA_TB;
+    const int kvh = blockIdx.x % n_kv_heads, tile = ntile - 1 - blockIdx.x / n_kv_heads;
+    const int b0 = tile * FA_TB, nb = min(FA_TB, ntok - b0), tmax = pos0 + b0 + nb - 1;
+    const int n_heads = n_kv_heads * kvmul, head = kvh * kvmul + hq;
+    const float sqrt_hs = (float)sqrt((double)HS);
+
+    // K / V tiles travel global -> registers -> LDS; the next tile's loads are in flight while the current one is consumed (clamped
+    // rows: every address is inside the cache, the surplus rows are never read).  8 float4 per thread cover a 64-row tile (host check).
+    // (written out at every site: a register array captured by a lambda, or filled in a macro loop, ends up in scratch with this compiler)
+    constexpr int NPK = 8;
+#ifdef FA_TIMING
+    unsigned long long fa_t0 = __builtin_readcyclecounter(), fa_t1, fa_t2, fa_t3;
+#endif
+    // ---- phase 1: scores
+    const int nkt = tmax / 64 + 1;
+    float4 pk0, pk1, pk2, pk3, pk4, pk5, pk6, pk7;           // named registers: an array here is not promoted out of scratch
+#define FA_REP8(X_) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7)
+    static_assert(NPK == 8, "FA_REP8");
+    {
+        const int ft0 = min(grp * 64, tmax), frows = max(1, min(64, tmax + 1 - grp * 64));
+#define FA_F(U_) { const int fi = min(gt + U_ * gthreads, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                        pk##U_ = *reinterpret_cast<const float4*>(kc + (size_t)(ft0 + fr) * kv_dim + kvh * HS + 4 * fc); }
+        FA_REP8(FA_F)
+#undef FA_F
+    }
+    for (int trip = 0; 2 * trip < nkt; ++trip) {
+        const int t0 = (2 * trip + grp) * 64;
+        const bool live = t0 <= tmax;
+        const int t1 = min(tmax + 1, t0 + 64);
+        float* ktg = kt + grp * 64 * PITCH;
+        if (live) {
+#define FA_P(U_) { const int fi = gt + U_ * gthreads; if (fi < 64 * H4) *reinterpret_cast<float4*>(ktg + (fi / H4) * PITCH + 4 * (fi % H4)) = pk##U_; }
+            FA_REP8(FA_P)
+#undef FA_P
+        }
+        __syncthreads();
+        {
+            const int tn = t0 + 128;                                 // this group's next tile (clamped: fetched even if it is not used)
+            {
+                const int ft0 = min(tn, tmax), frows = max(1, min(64, tmax + 1 - tn));
+#define FA_F(U_) { const int fi = min(gt + U_ * gthreads, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                                pk##U_ = *reinterpret_cast<const float4*>(kc + (size_t)(ft0 + fr) * kv_dim + kvh * HS + 4 * fc); }
+                FA_REP8(FA_F)
+#undef FA_F
+            }
+        }
+        if (live) {
+            float4 kr[H4];
+#pragma unroll
+            for (int c = 0; c < H4; ++c) kr[c] = *reinterpret_cast<const float4*>(ktg + min(lane, t1 - t0 - 1) * PITCH + 4 * c);
+            for (int tb = 0; tb < nb; tb += 2) {
+                // the two query rows are wavefront-uniform: scalar loads, SGPR operands in the multiplies (as pf_scores_tiled_kernel)
+                const float* q0 = Q + (size_t)(b0 + tb) * q_stride + (size_t)head * HS;
+                const float* q1 = Q + (size_t)(b0 + min(tb + 1, nb - 1)) * q_stride + (size_t)head * HS;
+                float s0 = 0.f, s1 = 0.f;
+                if constexpr (HS >= 64) {
+                    v16f_t a0, a1, c0, c1;
+                    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
+                    static_for<0, H4 / 4, 2>([&](auto ic) {
+                        constexpr int c4 = decltype(ic)::value;
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(s0), "+v"(s1));
+                        asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4" : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1), "n"((c4 + 1) * 64));
+                        score_step16(s0, s1, a0, a1, &kr[4 * c4]);
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c0), "+s"(c1), "+v"(s0), "+v"(s1));
+                        if constexpr (c4 + 2 < H4 / 4)
+                            asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1), "n"((c4 + 2) * 64));
+                        score_step16(s0, s1, c0, c1, &kr[4 * c4 + 4]);
+                    });
+                } else {
+                    v16f_t a0, a1, c0, c1;
+                    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
+                    asm volatile("s_load_dwordx16 %0, %2, 64\n\ts_load_dwordx16 %1, %3, 64" : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(c0), "+s"(c1), "+v"(s0), "+v"(s1));
+                    score_step16(s0, s1, a0, a1, &kr[0]);
+                    score_step16(s0, s1, c0, c1, &kr[4]);
+                }
+                const int ts = t0 + lane;
+                if (ts < t1) {
+                    if (ts <= pos0 + b0 + tb) Ssc[(size_t)(hq * FA_TB + tb) * sstride + ts] = att_mul != 0.f ? s0 * att_mul : s0 / sqrt_hs;
+                    if (tb + 1 < nb && ts <= pos0 + b0 + tb + 1) Ssc[(size_t)(hq * FA_TB + tb + 1) * sstride + ts] = att_mul != 0.f ? s1 * att_mul : s1 / sqrt_hs;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+#ifdef FA_TIMING
+    fa_t1 = __builtin_readcyclecounter();
+#endif
+    // the first V tile travels while the softmax runs
+    {
+        const int ft0 = 0, frows = min(64, tmax + 1);
+#define FA_F(U_) { const int fi = min(t + U_ * nthr, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                        pk##U_ = *reinterpret_cast<const float4*>(vc + (size_t)(ft0 + fr) * kv_dim + kvh * HS + 4 * fc); }
+        FA_REP8(FA_F)
+#undef FA_F
+    }
+    // ---- phase 2: softmax of the kvmul * nb rows
+    const int nrows = kvmul * nb, nwaves = nthr >> 6;
+    for (int row = wave; row < nrows; row += nwaves) {
+        const int tb = row % nb, n = pos0 + b0 + tb + 1;
+        float* e = Ssc + (size_t)((row / nb) * FA_TB + tb) * sstride;
+        float mx = -INFINITY;
+        for (int i = lane; i < n; i += 64) mx = fmaxf(mx, e[i]);
+        mx = wave_max(mx);
+        for (int i = lane; i < n; i += 64) e[i] = (float)exp((double)(e[i] - mx));      // lane-private slots
+    }
+    __syncthreads();
+    if (wave == 0 && lane < nrows) {                                 // lane = row: the strictly sequential sums, side by side
+        const int tb = lane % nb, n = pos0 + b0 + tb + 1;
+        const float* e = Ssc + (size_t)((lane / nb) * FA_TB + tb) * sstride;
+        sums[lane] = seq_sum_lds<false>(e, n);
+    }
+    __syncthreads();
+    for (int row = wave; row < nrows; row += nwaves) {
+        const int tb = row % nb, n = pos0 + b0 + tb + 1;
+        float* e = Ssc + (size_t)((row / nb) * FA_TB + tb) * sstride;
+        const float sum = sums[row];
+        for (int i = lane; i < n; i += 64) e[i] = e[i] / sum;
+    }
+
+#ifdef FA_TIMING
+    fa_t2 = __builtin_readcyclecounter();
+#endif
+    // ---- phase 3: weighted V sum; wavefront = (query head hq, tokens 4 * grp .. + 3)
+    int posu[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) posu[u] = 4 * grp + u < nb ? pos0 + b0 + 4 * grp + u : -1;       // -1: no timestep qualifies
+    const int wmax = 4 * grp < nb ? pos0 + b0 + min(4 * grp + 3, nb - 1) : -1;
+    const float* as = Ssc + (size_t)(hq * FA_TB + 4 * grp) * sstride;                             // rows of this wavefront's four tokens
+    float acc[4][NCOL];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) acc[u][c] = 0.f;
+    int vb = 0;
+    for (int t0 = 0; t0 <= tmax; t0 += 64, vb ^= 1) {
+        const int tt = min(64, tmax + 1 - t0);
+        float* vt = kt + vb * 64 * PITCH;
+        {
+#define FA_P(U_) { const int fi = t + U_ * nthr; if (fi < 64 * H4) *reinterpret_cast<float4*>(vt + (fi / H4) * PITCH + 4 * (fi % H4)) = pk##U_; }
+            FA_REP8(FA_P)
+#undef FA_P
+        }
+        __syncthreads();                                             // (also orders phase 2's writes before the first reads of `as`)
+        {
+            const int ft0 = min(t0 + 64, tmax), frows = max(1, min(64, tmax + 1 - (t0 + 64)));
+#define FA_F(U_) { const int fi = min(t + U_ * nthr, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                            pk##U_ = *reinterpret_cast<const float4*>(vc + (size_t)(ft0 + fr) * kv_dim + kvh * HS + 4 * fc); }
+            FA_REP8(FA_F)
+#undef FA_F
+        }
+        const int ttw = min(tt, wmax + 1 - t0);
+        const int rfull = (4 * grp + 3 < nb) ? max(0, min(tt, posu[0] + 1 - t0)) & ~3 : 0;       // timesteps all four tokens attend to
+        auto vload = [&](int r, float (&v)[NCOL]) {
+            if (NCOL == 2) {
+                const float2 v2 = *reinterpret_cast<const float2*>(vt + r * PITCH + 2 * lane);
+                v[0] = v2.x; v[NCOL - 1] = v2.y;
+            } else {
+                v[0] = lane < HS ? vt[r * PITCH + lane] : 0.f;
+            }
+        };
+        // four timesteps per group; the next group's softmax weights and V rows are read from LDS while the current group is
+        // accumulated (two named register sets: the un-pipelined loop spent ~2/3 of its time waiting for LDS, in-kernel stamps)
+#define FA_LD(A_, V_, R_)                                                                                                    \
+        do {                                                                                                                 \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) A_[u] = *reinterpret_cast<const float4*>(as + (size_t)u * sstride + t0 + (R_)); \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) vload((R_) + i, V_[i]);                                             \
+        } while (0)
+#define FA_ACC(A_, V_)                                                                                                       \
+        do {                                                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                              \
+                    const float at = i == 0 ? A_[u].x : i == 1 ? A_[u].y : i == 2 ? A_[u].z : A_[u].w;                        \
+                    _Pragma("unroll") for (int c = 0; c < NCOL; ++c) acc[u][c] = at * V_[i][c] + acc[u][c];                   \
+                }                                                                                                            \
+        } while (0)
+        float4 aA[4], aB[4];
+        float vA[4][NCOL], vB[4][NCOL];
+        if (rfull > 0) FA_LD(aA, vA, 0);
+        int r = 0;
+        for (; r + 8 <= rfull; r += 8) {
+            FA_LD(aB, vB, r + 4);
+            FA_ACC(aA, vA);
+            if (r + 8 < rfull) FA_LD(aA, vA, r + 8);
+            FA_ACC(aB, vB);
+        }
+        if (r < rfull) FA_ACC(aA, vA);                               // rfull is a multiple of 4: one group left
+#undef FA_LD
+#undef FA_ACC
+        for (int r = rfull; r < ttw; ++r) {                          // the diagonal: per-token conditions (uniform)
+            float v[NCOL];
+            vload(r, v);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (t0 + r <= posu[u]) {
+                    const float at = as[(size_t)u * sstride + t0 + r];
+#pragma unroll
+                    for (int c = 0; c < NCOL; ++c) acc[u][c] = at * v[c] + acc[u][c];
+                }
+            }
+        }
+    }
+#ifdef FA_TIMING
+    fa_t3 = __builtin_readcyclecounter();
+    if (lane == 0 && kvh == 0 && (tile % 9) == 0) printf("fa tile %d wave %d: scores %llu softmax %llu pv %llu\n", tile, wave, fa_t1 - fa_t0, fa_t2 - fa_t1, fa_t3 - fa_t2);
+#endif
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int tb = 4 * grp + u;
+        if (tb >= nb) continue;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            const int j = NCOL == 2 ? 2 * lane + c : lane;
+            if (j < HS) out[(size_t)(b0 + tb) * out_stride + head * HS + j] = acc[u][c];
+        }
+    }
+}
+
+#undef FA_REP8
+
 // Greedy id per sequence: first index of the maximum of each logits row (FloatTensor.argmax :138-151).
 // logits: rank-chunked [tp][rows][n / tp] (cc = n / tp, a multiple of 4; tp = 1: plain rows).
 // Two launches: (AMX_SPLIT segments x rows) workgroups scan their segment with float4 loads -> one (value, index) pair each; one
@@ -846,6 +1095,9 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
         GL3_HIP(hipFuncSetAttribute((const void*)gemm_vlq_kernel<WT_Q8_0, EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * vlq_stage_floats<WT_Q8_0>() * 4));
         GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         return GL3_OK;
     }
     p->maxk = d.hidden > ctx->q_dim ? d.hidden : ctx->q_dim;
@@ -885,6 +1137,9 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
 #undef GL3_GEMM_LDS
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return GL3_OK;
 }
 
@@ -1007,6 +1262,22 @@ static void pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
     }
     hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(H + KVH, n), dim3(64), 0, s, ra);
     const bool tiled = one_seq >= 0 && kvmul <= 4 && (hs == 32 || hs == 64 || hs == 128) && (size_t)(max_pos + 1) * 4 <= 60 * 1024;
+    // r4: one launch for scores + softmax + weighted V sum when a tile's score rows fit LDS (GL3_PF_FUSED_ATTN=0: the three kernels)
+    static const bool fused_off = getenv("GL3_PF_FUSED_ATTN") && atoi(getenv("GL3_PF_FUSED_ATTN")) == 0;
+    const int fa_sstride = ((max_pos + 1 + 63) & ~63) + 4;
+    if (tiled && !fused_off && 64 * (hs / 4) <= 8 * 64 * kvmul && fa_smem_bytes(hs, kvmul, fa_sstride) <= 150 * 1024) {      // 8 float4 per thread stage a tile
+        const int pos0 = max_pos + 1 - n, ntile = (n + FA_TB - 1) / FA_TB;
+        const size_t sms = fa_smem_bytes(hs, kvmul, fa_sstride);
+        const float* kc1 = aa.kcache + (size_t)one_seq * ctx->kv_seq_stride;
+        const float* vc1 = aa.vcache + (size_t)one_seq * ctx->kv_seq_stride;
+#define GL3_FA(HS_) hipLaunchKernelGGL((pf_attn_fused_kernel<HS_>), dim3(KVH * ntile), dim3(128 * kvmul), sms, s, aa.Q, aa.q_stride, kc1, vc1, aa.out, aa.out_stride, \
+                                       KVH, kvmul, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride)
+        if (hs == 128) GL3_FA(128);
+        else if (hs == 64) GL3_FA(64);
+        else GL3_FA(32);
+#undef GL3_FA
+        return;
+    }
     if (tiled) {
         const int pos0 = max_pos + 1 - n, ntt = (n + PA_TB - 1) / PA_TB;
         const size_t sms = (size_t)64 * (hs + 4) * 4;
