@@ -44,6 +44,46 @@ HBM_PEAK_GBS = 8000.0        # MI355X spec sheet (MI355X_MICROARCH.md: 8.0 TB/s;
 INT8_MFMA_PEAK_TOPS = 5000.0 # dense int8 MFMA (same rate class as FP8, ~5 P(FL)OP/s spec; micro-benchmark ceiling 3944 TOP/s)
 
 
+def probe_peaks(device):
+    """Measured-achievable peaks of this device (gl3_probe_peaks: 1 GiB streaming read / copy, int8 MFMA loop), SURVEY.md 8d."""
+    import ctypes as C
+    from importlib import import_module
+    import __graft_entry__ as ge
+    ge.load_package()
+    hip = import_module(ge.PKG_NAME + ".hip")
+    rd, cp, tops = C.c_double(), C.c_double(), C.c_double()
+    rc = hip.lib().gl3_probe_peaks(device, C.byref(rd), C.byref(cp), C.byref(tops))
+    if rc != 0:
+        return None
+    return dict(hbm_read_gbs=round(rd.value, 1), hbm_copy_gbs=round(cp.value, 1), int8_mfma_tops=round(tops.value, 1),
+                method="gl3_probe_peaks in this run: best of 3 — streaming float4 read of 1 GiB, device-to-device copy of 1 GiB (read + written bytes), "
+                       "4 independent v_mfma_i32_32x32x32_i8 accumulators per wavefront on every SIMD")
+
+
+def host_cpu_info():
+    """CPU model and the affinity mask the CPU baseline ran under."""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+        runs, start, prev = [], aff[0], aff[0]
+        for c in aff[1:] + [None]:
+            if c is None or c != prev + 1:
+                runs.append("%d-%d" % (start, prev) if prev != start else "%d" % start)
+                start = c
+            prev = c
+        mask = ",".join(runs)
+    except (AttributeError, OSError, IndexError):
+        aff, mask = [], None
+    return dict(cpu_model=model, affinity=mask, affinity_cpus=len(aff), logical_cpus=os.cpu_count())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +267,13 @@ def main():
                            "avg_us_instrumented_steps: start/stop events passed into each dispatch (hipExtLaunchKernel), mean over %d "
                            "launches in %d eager decode steps at positions 64.." % (cfg.n_layers, n_prof * cfg.n_layers, n_prof))
 
+    # measured-achievable peaks of THIS device beside the spec-sheet denominators; frac stays on the spec peak
+    peaks = probe_peaks(local_rank) if rank == 0 else None
+    if peaks:
+        roofline["peak_measured"] = peaks["hbm_read_gbs"]
+        roofline["frac_of_peak_measured"] = round(dom["gbs"] / peaks["hbm_read_gbs"], 4)
+        roofline["peak_measured_detail"] = peaks
+
     # ---- batched prefill: the dominant GEMM (gate/up, int8 MFMA) and the other three, at the pp chunk size
     roofline_pp = None
     if pp is not None and "tok_s" in pp and args.wtype == "q8_0" and args.batch > 1:
@@ -236,13 +283,28 @@ def main():
             pk[name.replace("matvec_", "gemm_")] = dict(avg_us=round(r["avg_us"], 2), int8_ops_per_launch=r["int8_ops_per_launch"], tops=round(r["tops"], 1),
                                                         frac_of_int8_mfma_peak=round(r["tops"] / INT8_MFMA_PEAK_TOPS, 4))
         g = pk["gemm_gateup"]
-        roofline_pp = dict(bound="mfma", kernel="pf_gemm_kernel<EPI_SWIGLU> (gate/up Q8_0 x int8-activation GEMM + SwiGLU, 2 x %dx%d x %d tokens)" %
-                           (cfg.hidden // world, cfg.dim, min(args.batch, args.n_prompt)),
+        ntok_pp = min(args.batch, args.n_prompt)
+        # matrix-pipe time of the r4 kernel: three 32-cycle MFMAs per (32 x 32 tile, block) — the int8 dot and the two exact bf16-split
+        # outer products s = wScale aScale, -B s (gl3_prefill_gemm2.h) — on 4 SIMDs x CUs; the honest MFMA-bound floor of this arithmetic
+        tiles_blocks = 2 * (cfg.hidden // world // 32) * ((ntok_pp + 31) // 32) * (cfg.dim // 32)
+        roofline_pp = dict(bound="mfma", kernel="pf_gemm2_kernel<EPI_SWIGLU> (gate/up Q8_0 x int8-activation GEMM + SwiGLU, 2 x %dx%d x %d tokens)" %
+                           (cfg.hidden // world, cfg.dim, ntok_pp),
                            achieved=g["tops"], peak=INT8_MFMA_PEAK_TOPS, unit="TOP/s", frac=g["frac_of_int8_mfma_peak"], traffic=None,
-                           avg_us=g["avg_us"], int8_ops_per_launch=g["int8_ops_per_launch"], dtype="i8 x i8 -> i32 MFMA, f32 per-block scale-accumulate on the VALU",
-                           note="VALU-bound by construction: the reference's per-32-block f32 scale-and-accumulate needs >= 4 VALU lane-ops per "
-                                "output per block beside each 32-cycle MFMA; MfmaUtil from rocprofv3 --pmc is in profiles/ (separate pass)",
+                           avg_us=g["avg_us"], int8_ops_per_launch=g["int8_ops_per_launch"],
+                           dtype="i8 x i8 -> i32 MFMA + two bf16 MFMAs for the exact scale products; 2 f32 VALU ops per output and block (fma, add)",
+                           mfma_instructions_per_launch=3 * tiles_blocks,
+                           note="the int8-peak fraction counts only the int8 dot; the reference's per-32-block f32 arithmetic "
+                                "(result += isum * (wScale * aScale), one rounding per operation) cannot reach 50 % of the int8 peak bit-exactly: r3 needed 4 VALU "
+                                "lane-ops per output and block (VALU-bound), r4 moves two of them onto the matrix pipe as exact outer products, which "
+                                "makes the pipe 3 x 32 cycles per tile-block = 1/3 int8 work at best; measured breakdown in profiles/r04_gemm_experiments.md",
                            gemms=pk, method="one HIP event pair around 3 sweeps x %d layers per GEMM class" % cfg.n_layers)
+        if peaks:
+            roofline_pp["peak_measured"] = peaks["int8_mfma_tops"]
+            roofline_pp["frac_of_peak_measured"] = round(g["tops"] / peaks["int8_mfma_tops"], 4)
+            # time the matrix pipe needs for this launch's 3 MFMAs per tile-block at the measured int8 MFMA issue rate
+            mfma_floor_us = 3 * tiles_blocks * 65536 / (peaks["int8_mfma_tops"] * 1e12) * 1e6
+            roofline_pp["matrix_pipe_floor_us"] = round(mfma_floor_us, 1)
+            roofline_pp["frac_of_matrix_pipe_floor"] = round(mfma_floor_us / g["avg_us"], 4)
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read in-process, so `traffic` stays null in this line.  The figure of
     # the round's SEPARATE rocprofv3 --pmc FETCH_SIZE pass over this same command (profiles/rNN_pmc_fetch_summary.csv, x2 gfx950
@@ -279,7 +341,10 @@ def main():
             if el > args.cpu_seconds or n_done >= args.n_gen:
                 break
         cpu = dict(value=round(n_done / el, 4), unit="tok/s", cores=oracle_c.lib().orc_num_threads(), kind="port",
-                   sample="tg%d at depth 0 (first %d decode steps of the same model/token stream, %.1f s)" % (n_done, n_done, el))
+                   sample="tg%d at depth 0 (first %d decode steps of the same model/token stream, %.1f s)" % (n_done, n_done, el),
+                   note="C restatement of forwardJava, rows / heads over an OpenMP pool; it quantises the activation once per matmul where the "
+                        "Java path re-quantises per row, so it is FASTER than the JVM path it stands for (kind 'port', not 'reference')",
+                   **host_cpu_info())
         # parity spot check on the full-size model, printed to stderr (the asserts live in tests/)
         ref = o.forward(toks[n_done], n_done)
         plan.reset_kv()

@@ -916,6 +916,106 @@ int32_t gl3_unpin_host_buffer(gl3_ctx* ctx, void* ptr) {
     GL3_FAIL(GL3_E_ARG, "buffer was not pinned through this plan");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// gl3_probe_peaks: what this device actually sustains ("re-verify on the box, report both spec and measured")
+typedef int probe_v4i __attribute__((ext_vector_type(4)));
+typedef int probe_v16i __attribute__((ext_vector_type(16)));
+typedef float probe_v4f __attribute__((ext_vector_type(4)));
+static __global__ __launch_bounds__(256) void probe_read_kernel(const float4* __restrict__ src4, size_t n4, float* __restrict__ sink) {
+    const probe_v4f* src = reinterpret_cast<const probe_v4f*>(src4);
+    // every workgroup streams its own contiguous slice, eight independent non-temporal 16-byte loads per thread in flight
+    const size_t per = n4 / gridDim.x, base = (size_t)blockIdx.x * per;
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    size_t i = threadIdx.x;
+    for (; i + 7 * 256 < per; i += 8 * 256) {
+        probe_v4f v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + base + i + u * 256);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; i < per; i += 256) { const probe_v4f v = src[base + i]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    if (a.x + a.y + a.z + a.w == 12345.678f) sink[0] = a.x;        // keeps the loads alive
+}
+static __global__ __launch_bounds__(256) void probe_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+static __global__ __launch_bounds__(256) void probe_mfma_kernel(int iters, int* __restrict__ sink) {
+    probe_v16i c0, c1, c2, c3;
+    for (int r = 0; r < 16; ++r) { c0[r] = 0; c1[r] = 1; c2[r] = 2; c3[r] = 3; }
+    const probe_v4i a = {0x01020304, 0x05060708, (int)threadIdx.x, 0x01010101};
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, c3, 0, 0, 0);
+    }
+    int s = 0;
+    for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+    if (s == 0x7fffffff) sink[0] = s;
+}
+
+int32_t gl3_probe_peaks(int32_t device, double* hbm_read_gbs, double* hbm_copy_gbs, double* int8_mfma_tops) {
+    if (hipSetDevice(device) != hipSuccess) return GL3_E_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GL3_E_HIP;
+    const int cus = prop.multiProcessorCount;
+    const size_t bytes = (size_t)1 << 30, n4 = bytes / 16;
+    float4 *src = nullptr, *dst = nullptr;
+    float* sink = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int32_t rc = GL3_E_HIP;
+    do {
+        if (hipMalloc((void**)&src, 3 * bytes) != hipSuccess) { rc = GL3_E_OOM; break; }      // three regions, read in rotation: nothing of a
+                                                                                               // repetition's 1 GiB is still in the 256 MB Infinity Cache
+        if (hipMalloc((void**)&dst, bytes) != hipSuccess) { rc = GL3_E_OOM; break; }
+        if (hipMalloc((void**)&sink, 256) != hipSuccess) break;
+        if (hipStreamCreate(&s) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+        if (hipMemsetAsync(src, 1, 3 * bytes, s) != hipSuccess || hipMemsetAsync(dst, 0, bytes, s) != hipSuccess) break;
+        int region = 0;
+        auto timed = [&](auto&& launch) -> double {                 // best of 3 after one warm-up, ms
+            double best = 1e30;
+            for (int rep = 0; rep < 4; ++rep) {
+                region = (region + 1) % 3;
+                hipEventRecord(e0, s);
+                launch();
+                hipEventRecord(e1, s);
+                hipEventSynchronize(e1);
+                float ms = 0;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < best) best = ms;
+            }
+            return best;
+        };
+        const dim3 grid(cus * 8), block(256);
+        if (hbm_read_gbs) {                                         // best over a few grid sizes (2 ... 16 workgroups per CU)
+            double best = 0;
+            for (int wpc = 2; wpc <= 16; wpc *= 2) {
+                const double gbs = bytes / (timed([&] { hipLaunchKernelGGL(probe_read_kernel, dim3(cus * wpc), block, 0, s, src + (size_t)region * n4, n4, sink); }) * 1e6);
+                if (gbs > best) best = gbs;
+            }
+            *hbm_read_gbs = best;
+        }
+        if (hbm_copy_gbs) *hbm_copy_gbs = 2.0 * bytes / (timed([&] { hipLaunchKernelGGL(probe_copy_kernel, grid, block, 0, s, src + (size_t)region * n4, dst, n4); }) * 1e6);
+        if (int8_mfma_tops) {
+            const int iters = 4096;
+            const double ms = timed([&] { hipLaunchKernelGGL(probe_mfma_kernel, dim3(cus), block, 0, s, iters, (int*)sink); });
+            // 4 wavefronts per workgroup x 4 MFMAs per trip x 2 * 32 * 32 * 32 int8 operations
+            *int8_mfma_tops = (double)cus * 4.0 * iters * 4.0 * 65536.0 / (ms * 1e9);
+        }
+        rc = hipGetLastError() == hipSuccess ? GL3_OK : GL3_E_HIP;
+    } while (0);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (s) hipStreamDestroy(s);
+    if (src) hipFree(src);
+    if (dst) hipFree(dst);
+    if (sink) hipFree(sink);
+    return rc;
+}
+
 int32_t gl3_profile_prefill_kernel(gl3_ctx* ctx, int32_t klass, int32_t n_tokens, int32_t iters, double* out_us, uint64_t* int8_ops_per_launch) {
     if (!ctx || !out_us || iters <= 0) return GL3_E_ARG;
     if (!ctx->finalized) GL3_FAIL(GL3_E_STATE, "profile before gl3_finalize");

@@ -71,6 +71,7 @@ _SIGS = {  # symbol -> (restype, argtypes): exactly the declarations of include/
     "gl3_profile_decode": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(KernelTimes)]),
     "gl3_profile_kernel": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "gl3_profile_prefill_kernel": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "gl3_probe_peaks": (C.c_int32, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gl3_get_init_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gl3_destroy": (None, [C.c_void_p]),
     "gl3_last_error": (C.c_char_p, [C.c_void_p]),

@@ -255,6 +255,12 @@ GL3_API int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, d
 GL3_API int32_t gl3_profile_prefill_kernel(gl3_ctx* ctx, int32_t klass, int32_t n_tokens, int32_t iters, double* out_us,
                                            uint64_t* int8_ops_per_launch);
 
+/* Measured-achievable peaks of THIS device, for the roofline denominators beside the spec-sheet figures: a streaming
+ * read of 1 GiB (float4 non-temporal loads, every CU busy; three regions read in rotation so that nothing is still in the Infinity Cache), a device-to-device copy of the same size (bytes counted = read + written) and
+ * a loop of independent v_mfma_i32_32x32x32_i8 on every SIMD (4 accumulators per wavefront).  Best of 3 timed repetitions each,
+ * HIP events on a private stream; any out pointer may be NULL.  Needs no plan. */
+GL3_API int32_t gl3_probe_peaks(int32_t device, double* hbm_read_gbs, double* hbm_copy_gbs, double* int8_mfma_tops);
+
 /* RunMetrics slots (TornadoVMMasterPlanSingleToken.java:40-54): plan creation and weight copy-in, ms. */
 GL3_API int32_t gl3_get_init_ms(gl3_ctx* ctx, double* plan_ms, double* copy_in_ms);
 

@@ -581,6 +581,17 @@ ORC_API float orc_dot_v256(const void* wrow, int type, const float* x, int n) {
 }
 /* 1 = -Dllama.quantizeActivation=false: Q8_0 matrices multiply the f32 activation (vector_bits 256: vectorDot, 0: scalarDot) */
 ORC_API int orc_set_f32_activation(orc_ctx* o, int on) { o->f32_activation = on ? 1 : 0; return 0; }
+/* thread pool size of the following forwards (tiny test models run faster on a few threads than on every logical CPU); returns the old value */
+ORC_API int orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    const int old = omp_get_max_threads();
+    if (n > 0) omp_set_num_threads(n);
+    return old;
+#else
+    (void)n;
+    return 1;
+#endif
+}
 ORC_API int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

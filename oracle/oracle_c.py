@@ -35,6 +35,7 @@ def build(force: bool = False):
 
 
 _lib = None
+_MAX_THREADS = [0]      # the OpenMP pool size the process started with (filled by lib())
 
 
 def lib():
@@ -44,6 +45,7 @@ def lib():
             build()
         L = C.CDLL(_SO)
         L.orc_create.restype = C.c_void_p
+        _MAX_THREADS[0] = L.orc_num_threads()
         L.orc_create.argtypes = [C.POINTER(OrcConfig)]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_set_tensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -112,14 +114,24 @@ class COracle:
         self._cr, self._ci = model.rope
         L.orc_set_rope(self._h, _p(self._cr), _p(self._ci))
 
+    def _pool(self):
+        """OpenMP threads for this model's forwards: every logical CPU for the full-size shapes, 8 for the small test models — a
+        256-thread region per matmul of a 256 x 512 matrix spends its time in the barrier (measured on the GPU box: 48 s against
+        < 1 s for a 24-step loop of tiny-llama).  Results do not depend on the count: rows and heads are independent."""
+        c = self.cfg
+        small = c.dim * max(c.hidden, c.vocab) < (1 << 24)
+        lib().orc_set_num_threads(8 if small else _MAX_THREADS[0])
+
     def forward(self, token: int, pos: int, layer_x: bool = False):
         c = self.cfg
+        self._pool()
         logits = np.empty(c.vocab, np.float32)
         lx = np.empty((c.n_layers, c.dim), np.float32) if layer_x else None
         lib().orc_forward(self._h, token, pos, _p(logits), _p(lx) if layer_x else None)
         return (logits, lx) if layer_x else logits
 
     def prefill(self, tokens, start_pos: int):
+        self._pool()
         t = np.ascontiguousarray(tokens, np.int32)
         lib().orc_prefill(self._h, _p(t), len(t), start_pos)
 
