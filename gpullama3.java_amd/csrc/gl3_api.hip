@@ -365,6 +365,13 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
         return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0 matrices need inner dimensions that are multiples of 64");
     if (d.weight_type != GL3_TYPE_Q8_0 && rl_smem_bytes(d.hidden > d.dim ? d.hidden : d.dim, EPI_STORE) > 150 * 1024)
         return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0: activation vector does not fit in LDS");
+    {   // vector-order matvecs (the default for F16 / Q4_0, and Q8_0 with the f32 activation) stage the whole activation in LDS under the
+        // 64 KB dynamic default: K <= 16384.  Reported here, not as a launch failure at the first decode step (r3 review).
+        const bool vector_order = q8v || (d.weight_type != GL3_TYPE_Q8_0 && !(d.flags & GL3_FLAG_SCALAR_DOT));
+        const int qd_ = d.n_heads * d.head_size, kmax = d.hidden > d.dim ? (d.hidden > qd_ ? d.hidden : qd_) : (d.dim > qd_ ? d.dim : qd_);
+        if (vector_order && vl_smem_bytes(kmax) > 64 * 1024)
+            return bail(GL3_E_UNSUPPORTED, "vector-order matvec: an inner dimension above 16384 does not fit its LDS staging (Q8_0 with the int8 activation has no such limit)");
+    }
     if (d.weight_type == GL3_TYPE_Q4_0 && !(d.flags & GL3_FLAG_SCALAR_DOT) && (d.dim % 256 || d.hidden % 256 || (d.n_heads * d.head_size) % 256))
         return bail(GL3_E_UNSUPPORTED, "Q4_0 in Vector-API order needs inner dimensions that are multiples of 256 (or GL3_FLAG_SCALAR_DOT)");
     if (d.weight_type != GL3_TYPE_Q8_0 && d.tp_size > 1 && (d.vocab / d.tp_size) % 64)
@@ -389,7 +396,9 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     // from the gathered xb, so the residual stream is complete on every rank without a gather behind it: 3 gathers per layer
     // (xb, hb, x) instead of 4.  Streaming all of Wo (17.9 MB for the 8B model: ~6 us) costs less than a gather hop over xGMI, and
     // the dot products stay whole and in order, so the results stay bit-identical.  GL3_TP_SPLIT_WO=1 restores the row split.
-    ctx->wo_replicated = tp > 1 && !env_flag("GL3_TP_SPLIT_WO", false);
+    // (the batched prefill runs the replicated Wo per rank chunk of dim / tp rows and reads 32-row strip pairs: a chunk must start on an
+    // even strip, i.e. dim % (32 tp) == 0 — otherwise the row split with its padded per-rank allocation is used)
+    ctx->wo_replicated = tp > 1 && !env_flag("GL3_TP_SPLIT_WO", false) && (d.max_batch <= 1 || d.dim % (32 * tp) == 0);
     ctx->wo_rows = ctx->wo_replicated ? d.dim : ctx->dim_l;
     ctx->use_rccl = tp > 1 || (d.flags & GL3_FLAG_FORCE_RCCL);
 

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_DIR, "libgl3_oracle.so")
+_SO = os.environ.get("GL3_ORACLE_LIB") or os.path.join(_DIR, "libgl3_oracle.so")      # GL3_ORACLE_LIB: the sanitizer build (scripts/sanitize.sh)
 
 T_IDS = {"token_embd.weight": 0, "output_norm.weight": 1, "output.weight": 2, "attn_norm.weight": 3,
          "attn_q.weight": 4, "attn_k.weight": 5, "attn_v.weight": 6, "attn_output.weight": 7,

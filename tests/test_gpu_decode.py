@@ -212,6 +212,17 @@ def test_error_behaviour(pkg, planmod):
         plan.forward_decode_batch([1, 2], [0, 1], [0, 0])
     assert e.value.code == -2
     plan.freeTornadoExecutionPlan()
+    # an inner dimension the vector-order matvecs cannot stage in LDS is refused at gl3_create (before any allocation), not at the first launch
+    import ctypes as C
+    d = hip.ModelDesc(struct_size=C.sizeof(hip.ModelDesc), arch=0, dim=4096, hidden=16640, n_layers=1, n_heads=32, n_kv_heads=8, head_size=128, vocab=1024, ctx=64,
+                      rms_eps=1e-5, weight_type=1, max_batch=1, device=0, tp_rank=0, tp_size=1, flags=0, n_seqs=1, embedding_scale=1.0, attention_scale=0.0,
+                      residual_scale=1.0, logit_scale=1.0)
+    h = C.c_void_p()
+    assert hip.lib().gl3_create(C.byref(d), C.byref(h)) == -2 and not h.value
+    assert b"16384" in hip.lib().gl3_last_error(None)
+    d.weight_type = 8                                         # Q8_0 with the int8 activation has no such limit
+    assert hip.lib().gl3_create(C.byref(d), C.byref(h)) == 0
+    hip.lib().gl3_destroy(h)
 
 
 @pytest.mark.parametrize("cfg,batch,chunks", [("tiny-llama", 8, [8, 8, 5]), ("mid-llama", 64, [40, 64, 3]), ("mid-qwen3", 32, [30, 7]), ("mid-qwen2", 64, [50, 9]), ("mid-granite", 64, [33, 20]), ("mid-phi3", 64, [41, 6]),
