@@ -407,9 +407,17 @@ def select_transport(want, world, rank, local_rank, dist, pkg, plan_mod, hip, to
         if rc != 0 or reach.value != world:
             ok, why = 0, "hipDeviceCanAccessPeer: %d of %d peers reachable (rc %d)" % (reach.value, world, rc)
 
+    exchanged = [False]
+
     def exchange(handle):
+        # exactly ONE handle all-gather per rank: a rank whose plan fails BEFORE it gets here (gl3_create error, out of memory)
+        # joins it afterwards with None, so the collectives of all ranks stay paired (r3 advisor finding: the failed rank used to
+        # run ahead into the flags gather while its peers sat in this one)
+        exchanged[0] = True
         out = [None] * world
         dist.all_gather_object(out, handle)
+        if any(h is None for h in out):
+            raise RuntimeError("a peer failed before the IPC handle exchange")
         return out
 
     flags = [None] * world
@@ -423,6 +431,11 @@ def select_transport(want, world, rank, local_rank, dist, pkg, plan_mod, hip, to
             probe = plan_mod.HipMasterPlan(synth.make_numpy(cfg, seed=5), device=local_rank, tp_rank=rank, tp_size=world, p2p_exchange=exchange)
         except Exception as e:                          # noqa: BLE001
             ok, why = 0, "probe plan over IPC: %s" % e
+        if not exchanged[0]:
+            try:
+                exchange(None)
+            except RuntimeError:
+                pass
         dist.all_gather_object(flags, ok)
         if all(flags):
             try:
