@@ -473,11 +473,11 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP(hipHostMalloc((void**)&ctx->h_logits, (size_t)d.vocab * 4));
     TRYHIP(hipHostMalloc((void**)&ctx->h_argmax, sizeof(int)));
     // batched prefill / static-batched decode: int8 MFMA GEMMs for Q8_0 (any tensor-parallel degree); f32-MFMA / VALU GEMMs in the
-    // Vector-API order for F16, Q4_0 and Q8_0 with the f32 activation on one rank (gl3_prefill_vl.h).  The scalar dot order
-    // (GL3_FLAG_SCALAR_DOT) and tensor-parallel ranks of those types prefill token by token.
+    // Vector-API order for F16, Q4_0 and Q8_0 with the f32 activation (gl3_prefill_vl.h).  The scalar dot order
+    // (GL3_FLAG_SCALAR_DOT) prefills token by token.
     {
         const bool int8_path = d.weight_type == GL3_TYPE_Q8_0 && !(d.flags & GL3_FLAG_F32_ACTIVATION);
-        const bool vl_path = !int8_path && !(d.flags & GL3_FLAG_SCALAR_DOT) && tp == 1 && !(d.flags & GL3_FLAG_FORCE_RCCL);
+        const bool vl_path = !int8_path && !(d.flags & GL3_FLAG_SCALAR_DOT);      // r4: tensor-parallel ranks too (rank-chunked activations)
         if (d.max_batch > 1 && (int8_path || vl_path)) TRY(gl3_prefill_alloc(ctx));
     }
     if (getenv("GL3_DEBUG_ALLOC")) {
@@ -1072,6 +1072,11 @@ int32_t gl3_get_buffer(gl3_ctx* ctx, int32_t which, float* out, uint64_t n) {
     case 1: src = ctx->xb; cap = ctx->q_dim; break;
     case 2: src = ctx->hb; cap = ctx->d.hidden; break;
     case 3: src = ctx->logits; cap = ctx->d.vocab; break;
+    case 4: case 5: case 6:                    // batched step: rank-chunked X / AO / HB of the last chunk (GB_PF_X / _AO / _HB), max_batch rows
+        if (!ctx->pf) GL3_FAIL(GL3_E_STATE, "no batched-prefill buffers (max_batch <= 1)");
+        src = gl3_prefill_buf(ctx, which);
+        cap = (uint64_t)ctx->d.max_batch * (which == 4 ? ctx->d.dim : which == 5 ? ctx->q_dim : ctx->d.hidden);
+        break;
     default: GL3_FAIL(GL3_E_ARG, "unknown buffer id");
     }
     if (n > cap) GL3_FAIL(GL3_E_ARG, "buffer shorter than requested");

@@ -82,12 +82,12 @@ __global__ __launch_bounds__(256) void pf_embed_kernel(const uint8_t* __restrict
 // independent, and one workgroup per token left 32 tokens on 32 CUs).
 //   PQ_PLAIN:  quantise an f32 row;  PQ_NORM: RMSNorm, then quantise
 //   PQ_NORM_F32: RMSNorm only, f32 out (XS = [ntok][k] floats; the f32-activation weight types, gl3_prefill_vl.h)
-enum { PQ_PLAIN = 0, PQ_NORM = 1, PQ_NORM_F32 = 2 };
+enum { PQ_PLAIN = 0, PQ_NORM = 1, PQ_NORM_F32 = 2, PQ_PLAIN_F32 = 3 };     // PQ_PLAIN_F32: rank-chunked f32 row -> plain f32 row (XS)
 template <int MODE>
 __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restrict__ in, int k, int in_stride,
                                                              const float* __restrict__ norm_w, float eps,
                                                              uint8_t* __restrict__ XQ, float* __restrict__ XS, int maxk, int tslots) {
-    constexpr bool NORM = MODE != PQ_PLAIN;
+    constexpr bool NORM = MODE == PQ_NORM || MODE == PQ_NORM_F32;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* xf = reinterpret_cast<float*>(smem);                 // [k + 32]
     uint8_t* scratch = smem + (size_t)(k + 32) * 4;             // ss_scratch_bytes(k)
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restr
         } else {
             v = xquad(qd);
         }
-        if (MODE == PQ_NORM_F32) { *reinterpret_cast<float4*>(XS + (size_t)b * k + 4 * qd) = v; continue; }
+        if (MODE == PQ_NORM_F32 || MODE == PQ_PLAIN_F32) { *reinterpret_cast<float4*>(XS + (size_t)b * k + 4 * qd) = v; continue; }
         if (tslots == 0) quantize_quad(v, qd, xq, xs);
         else {                                           // the wave-owned small-batch GEMM's operand layout (gl3_bd_gemm.h)
             float qs;
@@ -784,6 +784,11 @@ __global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, in
 //            acc = a_t * v + acc with t ascending (pf_pv_tiled_kernel's inner loop)
 // Tiles are dealt heaviest (latest positions) first, so the triangular work profile does not leave a tail.
 constexpr int FA_TB = 8;
+#ifdef FA_SCALAR_GLC
+#define FA_GLC " glc"
+#else
+#define FA_GLC ""
+#endif
 __host__ __device__ constexpr size_t fa_smem_bytes(int hs, int kvmul, int sstride) {
     return ((size_t)kvmul * FA_TB * sstride + 2 * 64 * (hs + 4) + 64) * 4;
 }
@@ -814,6 +819,10 @@ __global__ __launch_bounds__(512) void pf_attn_fused_kernel(const float* __restr
 #endif
     // ---- phase 1: scores
     const int nkt = tmax / 64 + 1;
+#ifdef FA_DCACHE_INV
+    __builtin_amdgcn_s_dcache_inv();
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
     float4 pk0, pk1, pk2, pk3, pk4, pk5, pk6, pk7;           // named registers: an array here is not promoted out of scratch
 #define FA_REP8(X_) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7)
     static_assert(NPK == 8, "FA_REP8");
@@ -856,21 +865,21 @@ __global__ __launch_bounds__(512) void pf_attn_fused_kernel(const float* __restr
                 float s0 = 0.f, s1 = 0.f;
                 if constexpr (HS >= 64) {
                     v16f_t a0, a1, c0, c1;
-                    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
+                    asm volatile("s_load_dwordx16 %0, %2, 0x0" FA_GLC "\n\ts_load_dwordx16 %1, %3, 0x0" FA_GLC : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
                     static_for<0, H4 / 4, 2>([&](auto ic) {
                         constexpr int c4 = decltype(ic)::value;
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(s0), "+v"(s1));
-                        asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4" : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1), "n"((c4 + 1) * 64));
+                        asm volatile("s_load_dwordx16 %0, %2, %4" FA_GLC "\n\ts_load_dwordx16 %1, %3, %4" FA_GLC : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1), "n"((c4 + 1) * 64));
                         score_step16(s0, s1, a0, a1, &kr[4 * c4]);
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c0), "+s"(c1), "+v"(s0), "+v"(s1));
                         if constexpr (c4 + 2 < H4 / 4)
-                            asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1), "n"((c4 + 2) * 64));
+                            asm volatile("s_load_dwordx16 %0, %2, %4" FA_GLC "\n\ts_load_dwordx16 %1, %3, %4" FA_GLC : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1), "n"((c4 + 2) * 64));
                         score_step16(s0, s1, c0, c1, &kr[4 * c4 + 4]);
                     });
                 } else {
                     v16f_t a0, a1, c0, c1;
-                    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
-                    asm volatile("s_load_dwordx16 %0, %2, 64\n\ts_load_dwordx16 %1, %3, 64" : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1));
+                    asm volatile("s_load_dwordx16 %0, %2, 0x0" FA_GLC "\n\ts_load_dwordx16 %1, %3, 0x0" FA_GLC : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
+                    asm volatile("s_load_dwordx16 %0, %2, 64" FA_GLC "\n\ts_load_dwordx16 %1, %3, 64" FA_GLC : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1));
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(c0), "+s"(c1), "+v"(s0), "+v"(s1));
                     score_step16(s0, s1, a0, a1, &kr[0]);
                     score_step16(s0, s1, c0, c1, &kr[4]);
@@ -1071,13 +1080,22 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     p->max_batch = d.max_batch;
     const size_t M = d.max_batch;
     p->vl = ctx->emb.vl;
-    if (p->vl) {       // f32-activation weight types on one rank (gl3_create admits nothing else here): plain f32 buffers
+    if (p->vl) {       // f32-activation weight types: f32 buffers; the gathered ones (X, AO, HB, LOGITS) in the arena under tensor parallelism
         GL3_HIP(hipMalloc((void**)&p->tokens, M * sizeof(int32_t)));
-        GL3_HIP(hipMalloc((void**)&p->X, M * d.dim * 4));
-        GL3_HIP(hipMalloc((void**)&p->XN, M * d.dim * 4));
-        GL3_HIP(hipMalloc((void**)&p->AO, M * ctx->q_dim * 4));
-        GL3_HIP(hipMalloc((void**)&p->HB, M * d.hidden * 4));
-        GL3_HIP(hipMalloc((void**)&p->HB2, M * d.hidden * 4));
+        if (ctx->arena.base && ctx->arena.off[GB_PF_X]) {
+            uint8_t* b = ctx->arena.base;
+            p->X = (float*)(b + ctx->arena.off[GB_PF_X]); p->AO = (float*)(b + ctx->arena.off[GB_PF_AO]); p->HB = (float*)(b + ctx->arena.off[GB_PF_HB]);
+            p->LOGITS = (float*)(b + ctx->arena.off[GB_PF_LOGITS]); p->logits_rows = ctx->arena.pf_logits_rows;
+            p->in_arena = true;
+        } else {
+            GL3_HIP(hipMalloc((void**)&p->X, M * d.dim * 4));
+            GL3_HIP(hipMalloc((void**)&p->AO, M * ctx->q_dim * 4));
+            GL3_HIP(hipMalloc((void**)&p->HB, M * d.hidden * 4));
+        }
+        // XN: normalised / un-chunked f32 operand of the next GEMM (K up to max(dim, q_dim, hidden)); HB2: this rank's up projection
+        const size_t kmax = (size_t)(d.hidden > ctx->q_dim ? (d.hidden > d.dim ? d.hidden : d.dim) : (ctx->q_dim > d.dim ? ctx->q_dim : d.dim));
+        GL3_HIP(hipMalloc((void**)&p->XN, M * kmax * 4));
+        GL3_HIP(hipMalloc((void**)&p->HB2, M * ctx->hidden_l * 4));
         GL3_HIP(hipMalloc((void**)&p->QKV, M * (ctx->q_dim + 2 * ctx->kv_dim) * 4));
         GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
         GL3_HIP(hipMalloc((void**)&p->seqpos, 2 * M * sizeof(int32_t)));
@@ -1272,10 +1290,14 @@ static void pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
         const float* vc1 = aa.vcache + (size_t)one_seq * ctx->kv_seq_stride;
 #define GL3_FA(HS_) hipLaunchKernelGGL((pf_attn_fused_kernel<HS_>), dim3(KVH * ntile), dim3(128 * kvmul), sms, s, aa.Q, aa.q_stride, kc1, vc1, aa.out, aa.out_stride, \
                                        KVH, kvmul, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride)
+        static const int fa_dbg = getenv("GL3_FA_DBG") ? atoi(getenv("GL3_FA_DBG")) : 0;      // 1: device sync around the launch; 2: poison the output first
+        if (fa_dbg & 2) hipMemsetAsync(aa.out, 0xFF, (size_t)n * aa.out_stride * 4, s);
+        if (fa_dbg & 1) hipDeviceSynchronize();
         if (hs == 128) GL3_FA(128);
         else if (hs == 64) GL3_FA(64);
         else GL3_FA(32);
 #undef GL3_FA
+        if (fa_dbg & 1) hipDeviceSynchronize();
         return;
     }
     if (tiled) {
@@ -1319,31 +1341,60 @@ static void launch_gemm_vl(gl3_ctx* ctx, const Q8Mat& w, int ntok, const float* 
     }
 }
 
-// The same layers for F16 / Q4_0 / Q8_0-with-f32-activation matrices on one rank: RMSNorm to f32 (exact sum of squares), GEMMs on
-// the f32 activations, gate and up as two GEMMs + an element-wise SwiGLU.
+// The same layers for F16 / Q4_0 / Q8_0-with-f32-activation matrices: RMSNorm to f32 (exact sum of squares), GEMMs on the f32
+// activations, gate and up as two GEMMs + an element-wise SwiGLU.  Tensor parallel (r4): the row-split matrices write this rank's
+// chunk of the rank-chunked X / AO / HB (as the int8 path does), the gathers are in place, and the next GEMM's operand is the
+// gathered activation un-chunked (or normalised) into XN.
 static int32_t pf_layers_vl(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
     Gl3Range chunk_range("gl3 batched step, tokens", n);
     gl3_prefill_state* p = ctx->pf;
     const gl3_model_desc& d = ctx->d;
     hipStream_t s = ctx->stream;
-    const int qkv_dim = ctx->q_dim + 2 * ctx->kv_dim;
-    if (ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((pf_embed_vl_kernel<WT_F16>), dim3(n), dim3(256), 0, s, ctx->emb.w, d.dim, p->tokens, p->X, ctx->emb_scale);
-    else if (ctx->emb.fmt == GL3_TYPE_Q4_0) hipLaunchKernelGGL((pf_embed_vl_kernel<WT_Q4_0>), dim3(n), dim3(256), 0, s, ctx->emb.w, d.dim, p->tokens, p->X, ctx->emb_scale);
-    else hipLaunchKernelGGL((pf_embed_vl_kernel<WT_Q8_0>), dim3(n), dim3(256), 0, s, ctx->emb.w, d.dim, p->tokens, p->X, ctx->emb_scale);
+    const int rank = d.tp_rank, tp = d.tp_size, qd = ctx->q_dim_l, kvd = ctx->kv_dim_l, hid = ctx->hidden_l, dml = ctx->dim_l;
+    const int qkv_dim = qd + 2 * kvd;
+    float* Xr = p->X + (size_t)rank * n * dml;
+    float* AOr = p->AO + (size_t)rank * n * qd;
+    float* HBr = p->HB + (size_t)rank * n * hid;
+    int32_t r;
+    // every rank holds the whole embedding table: the full X, written in the rank-chunked layout
+    if (ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((pf_embed_vl_kernel<WT_F16>), dim3(n), dim3(256), 0, s, ctx->emb.w, d.dim, p->tokens, p->X, ctx->emb_scale, dml);
+    else if (ctx->emb.fmt == GL3_TYPE_Q4_0) hipLaunchKernelGGL((pf_embed_vl_kernel<WT_Q4_0>), dim3(n), dim3(256), 0, s, ctx->emb.w, d.dim, p->tokens, p->X, ctx->emb_scale, dml);
+    else hipLaunchKernelGGL((pf_embed_vl_kernel<WT_Q8_0>), dim3(n), dim3(256), 0, s, ctx->emb.w, d.dim, p->tokens, p->X, ctx->emb_scale, dml);
     const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
+    auto unchunk = [&](const float* src, int k, int cc) {          // rank-chunked [tp][n][cc] -> plain XN[n][k] (tp = 1: a copy the GEMM could skip, kept for one code path)
+        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN_F32>), dim3(n, (k / 4 + 255) / 256), dim3(256), 0, s, src, k, cc, (const float*)nullptr, 0.f, (uint8_t*)nullptr, p->XN, 0, 0);
+    };
     for (int l = 0; l < d.n_layers; ++l) {
         gl3_layer& L = ctx->layers[l];
         Gl3Range layer_range("layer", l);
-        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM_F32>), dim3(n), dim3(256), nq, s, p->X, d.dim, d.dim, L.attn_norm, d.rms_eps, (uint8_t*)nullptr, p->XN, 0, 0);
+        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM_F32>), dim3(n), dim3(256), nq, s, p->X, d.dim, dml, L.attn_norm, d.rms_eps, (uint8_t*)nullptr, p->XN, 0, 0);
         launch_gemm_vl<EPI_STORE>(ctx, L.wqkv, n, p->XN, d.dim, p->QKV, qkv_dim);
-        pf_attention(ctx, l, n, max_pos, one_seq, p->AO, false);
-        launch_gemm_vl<EPI_RESID>(ctx, L.wo, n, p->AO, ctx->q_dim, p->X, d.dim, ctx->resid_scale);
-        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM_F32>), dim3(n), dim3(256), nq, s, p->X, d.dim, d.dim, L.ffn_norm, d.rms_eps, (uint8_t*)nullptr, p->XN, 0, 0);
-        launch_gemm_vl<EPI_STORE>(ctx, L.w1, n, p->XN, d.dim, p->HB, d.hidden);
-        launch_gemm_vl<EPI_STORE>(ctx, L.w3, n, p->XN, d.dim, p->HB2, d.hidden);
-        const size_t ne = (size_t)n * d.hidden;
-        hipLaunchKernelGGL(pf_swiglu_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, p->HB, p->HB2, ne);
-        launch_gemm_vl<EPI_RESID>(ctx, L.w2, n, p->HB, d.hidden, p->X, d.dim, ctx->resid_scale);
+        pf_attention(ctx, l, n, max_pos, one_seq, AOr, false);
+        if ((r = gl3_all_gather(ctx, GB_PF_AO, (size_t)n * qd)) != GL3_OK) return r;
+        const float* ao = p->AO;
+        if (tp > 1) { unchunk(p->AO, ctx->q_dim, qd); ao = p->XN; }
+        if (ctx->wo_replicated) {
+            // every rank holds all of Wo: one GEMM per rank chunk of the rank-chunked X (rows [c dml, (c + 1) dml) -> chunk c), no gather
+            for (int c = 0; c < tp; ++c) {
+                Q8Mat sub = L.wo;
+                sub.rows = dml;
+                sub.w = L.wo.w + (size_t)(c * dml / 8) * L.wo.vl_group_bytes();
+                launch_gemm_vl<EPI_RESID>(ctx, sub, n, ao, ctx->q_dim, p->X + (size_t)c * n * dml, dml, ctx->resid_scale);
+            }
+        } else {
+            launch_gemm_vl<EPI_RESID>(ctx, L.wo, n, ao, ctx->q_dim, Xr, dml, ctx->resid_scale);
+            if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
+        }
+        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM_F32>), dim3(n), dim3(256), nq, s, p->X, d.dim, dml, L.ffn_norm, d.rms_eps, (uint8_t*)nullptr, p->XN, 0, 0);
+        launch_gemm_vl<EPI_STORE>(ctx, L.w1, n, p->XN, d.dim, HBr, hid);
+        launch_gemm_vl<EPI_STORE>(ctx, L.w3, n, p->XN, d.dim, p->HB2, hid);
+        const size_t ne = (size_t)n * hid;
+        hipLaunchKernelGGL(pf_swiglu_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, HBr, p->HB2, ne);
+        if ((r = gl3_all_gather(ctx, GB_PF_HB, (size_t)n * hid)) != GL3_OK) return r;
+        const float* hb = p->HB;
+        if (tp > 1) { unchunk(p->HB, d.hidden, hid); hb = p->XN; }
+        launch_gemm_vl<EPI_RESID>(ctx, L.w2, n, hb, d.hidden, Xr, dml, ctx->resid_scale);
+        if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
     }
     GL3_HIP(hipGetLastError());
     return GL3_OK;
@@ -1476,8 +1527,8 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
         if (rr != GL3_OK) return rr;
         const size_t nq = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
         if (p->vl) {
-            hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM_F32>), dim3(n), dim3(256), nq, s, p->X, d.dim, d.dim, ctx->out_norm, d.rms_eps, (uint8_t*)nullptr, p->XN, 0, 0);
-            launch_gemm_vl<EPI_STORE>(ctx, ctx->wcls, n, p->XN, d.dim, p->LOGITS, d.vocab, ctx->logit_scale);
+            hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM_F32>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, (uint8_t*)nullptr, p->XN, 0, 0);
+            launch_gemm_vl<EPI_STORE>(ctx, ctx->wcls, n, p->XN, d.dim, p->LOGITS + (size_t)d.tp_rank * n * vl, vl, ctx->logit_scale);
         } else {
         hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk, bd_tslots(n));
         // vocab rows are split across ranks: this rank's logits are the chunk [n][vocab / tp] of the rank-chunked buffer

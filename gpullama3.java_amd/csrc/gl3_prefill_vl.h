@@ -291,27 +291,30 @@ static __global__ __launch_bounds__(256) void pf_swiglu_kernel(float* __restrict
 // token_embedding_table.copyTo per token of the batch (batchForwardJavaPrefill :96), VL layouts
 template <int WT>
 static __global__ __launch_bounds__(256) void pf_embed_vl_kernel(const uint8_t* __restrict__ emb, int dim, const int32_t* __restrict__ tokens,
-                                                                 float* __restrict__ X, float emb_scale) {
+                                                                 float* __restrict__ X, float emb_scale, int cc) {
+    // X is rank-chunked [dim / cc][ntok][cc] (cc = dim: the plain [ntok][dim]); element i of token b at ((i / cc) ntok + b) cc + i % cc
     const int token = tokens[blockIdx.x], g = token >> 3, rr = token & 7;
     const uint8_t* gb = emb + (size_t)g * vl_group_bytes(WT, dim);
-    float* x = X + (size_t)blockIdx.x * dim;
+    const int bt = blockIdx.x, nt = gridDim.x;
+#define x(I_) X[((size_t)((I_) / cc) * nt + bt) * cc + (I_) % cc]
     for (int i = threadIdx.x; i < dim; i += 256) {
         if (WT == WT_F16) {
             const int c = i >> 6, e = i & 63, l = e & 7, kk = e >> 3;
-            x[i] = h2f(reinterpret_cast<const uint16_t*>(gb + (size_t)c * 1024 + (rr * 8 + l) * 16)[kk]) * emb_scale;
+            x(i) = h2f(reinterpret_cast<const uint16_t*>(gb + (size_t)c * 1024 + (rr * 8 + l) * 16)[kk]) * emb_scale;
         } else if (WT == WT_Q8_0) {
             const int b = i >> 5, j = i & 31, c = b >> 2, kk = b & 3, l = j & 7;
             const uint8_t* cb = gb + (size_t)c * 1088;
             const int q = (int8_t)cb[(rr * 8 + l) * 16 + 4 * kk + (j >> 3)];
-            x[i] = ((float)q * h2f(reinterpret_cast<const uint16_t*>(cb + 1024 + rr * 8)[kk])) * emb_scale;
+            x(i) = ((float)q * h2f(reinterpret_cast<const uint16_t*>(cb + 1024 + rr * 8)[kk])) * emb_scale;
         } else {
             const int b = i >> 5, j = i & 31, c = b >> 3, kk = b & 7, l = j & 7;
             const uint8_t* cb = gb + (size_t)c * 1152;
             const uint8_t byte = cb[(rr * 8 + l) * 16 + ((j & 8) ? 8 : 0) + kk];
             const int q = j < 16 ? (byte & 0x0F) : (byte >> 4);
-            x[i] = ((float)(q - 8) * h2f(reinterpret_cast<const uint16_t*>(cb + 1024 + rr * 16)[kk])) * emb_scale;
+            x(i) = ((float)(q - 8) * h2f(reinterpret_cast<const uint16_t*>(cb + 1024 + rr * 16)[kk])) * emb_scale;
         }
     }
+#undef x
 }
 
 }  // namespace gl3

