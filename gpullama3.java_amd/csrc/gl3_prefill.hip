@@ -784,11 +784,6 @@ __global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, in
 //            acc = a_t * v + acc with t ascending (pf_pv_tiled_kernel's inner loop)
 // Tiles are dealt heaviest (latest positions) first, so the triangular work profile does not leave a tail.
 constexpr int FA_TB = 8;
-#ifdef FA_SCALAR_GLC
-#define FA_GLC " glc"
-#else
-#define FA_GLC ""
-#endif
 __host__ __device__ constexpr size_t fa_smem_bytes(int hs, int kvmul, int sstride) {
     return ((size_t)kvmul * FA_TB * sstride + 2 * 64 * (hs + 4) + 64) * 4;
 }
@@ -819,10 +814,6 @@ __global__ __launch_bounds__(512) void pf_attn_fused_kernel(const float* __restr
 #endif
     // ---- phase 1: scores
     const int nkt = tmax / 64 + 1;
-#ifdef FA_DCACHE_INV
-    __builtin_amdgcn_s_dcache_inv();
-    __builtin_amdgcn_s_waitcnt(0);
-#endif
     float4 pk0, pk1, pk2, pk3, pk4, pk5, pk6, pk7;           // named registers: an array here is not promoted out of scratch
 #define FA_REP8(X_) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7)
     static_assert(NPK == 8, "FA_REP8");
@@ -865,21 +856,21 @@ __global__ __launch_bounds__(512) void pf_attn_fused_kernel(const float* __restr
                 float s0 = 0.f, s1 = 0.f;
                 if constexpr (HS >= 64) {
                     v16f_t a0, a1, c0, c1;
-                    asm volatile("s_load_dwordx16 %0, %2, 0x0" FA_GLC "\n\ts_load_dwordx16 %1, %3, 0x0" FA_GLC : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
+                    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
                     static_for<0, H4 / 4, 2>([&](auto ic) {
                         constexpr int c4 = decltype(ic)::value;
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+v"(s0), "+v"(s1));
-                        asm volatile("s_load_dwordx16 %0, %2, %4" FA_GLC "\n\ts_load_dwordx16 %1, %3, %4" FA_GLC : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1), "n"((c4 + 1) * 64));
+                        asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4" : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1), "n"((c4 + 1) * 64));
                         score_step16(s0, s1, a0, a1, &kr[4 * c4]);
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c0), "+s"(c1), "+v"(s0), "+v"(s1));
                         if constexpr (c4 + 2 < H4 / 4)
-                            asm volatile("s_load_dwordx16 %0, %2, %4" FA_GLC "\n\ts_load_dwordx16 %1, %3, %4" FA_GLC : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1), "n"((c4 + 2) * 64));
+                            asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1), "n"((c4 + 2) * 64));
                         score_step16(s0, s1, c0, c1, &kr[4 * c4 + 4]);
                     });
                 } else {
                     v16f_t a0, a1, c0, c1;
-                    asm volatile("s_load_dwordx16 %0, %2, 0x0" FA_GLC "\n\ts_load_dwordx16 %1, %3, 0x0" FA_GLC : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
-                    asm volatile("s_load_dwordx16 %0, %2, 64" FA_GLC "\n\ts_load_dwordx16 %1, %3, 64" FA_GLC : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1));
+                    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(a0), "=&s"(a1) : "s"(q0), "s"(q1));
+                    asm volatile("s_load_dwordx16 %0, %2, 64\n\ts_load_dwordx16 %1, %3, 64" : "=&s"(c0), "=&s"(c1) : "s"(q0), "s"(q1));
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1), "+s"(c0), "+s"(c1), "+v"(s0), "+v"(s1));
                     score_step16(s0, s1, a0, a1, &kr[0]);
                     score_step16(s0, s1, c0, c1, &kr[4]);
@@ -1290,14 +1281,10 @@ static void pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
         const float* vc1 = aa.vcache + (size_t)one_seq * ctx->kv_seq_stride;
 #define GL3_FA(HS_) hipLaunchKernelGGL((pf_attn_fused_kernel<HS_>), dim3(KVH * ntile), dim3(128 * kvmul), sms, s, aa.Q, aa.q_stride, kc1, vc1, aa.out, aa.out_stride, \
                                        KVH, kvmul, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride)
-        static const int fa_dbg = getenv("GL3_FA_DBG") ? atoi(getenv("GL3_FA_DBG")) : 0;      // 1: device sync around the launch; 2: poison the output first
-        if (fa_dbg & 2) hipMemsetAsync(aa.out, 0xFF, (size_t)n * aa.out_stride * 4, s);
-        if (fa_dbg & 1) hipDeviceSynchronize();
         if (hs == 128) GL3_FA(128);
         else if (hs == 64) GL3_FA(64);
         else GL3_FA(32);
 #undef GL3_FA
-        if (fa_dbg & 1) hipDeviceSynchronize();
         return;
     }
     if (tiled) {
