@@ -486,7 +486,9 @@ def bench_decode_batch(args, cfg, synth, plan_mod, pkg, torch, np, dev):
     per step (B x 4 bytes D2H), logits stay on the device as with -Dllama.deviceSample."""
     B = args.decode_batch
     cfg = synth.ModelConfig(**{**cfg.__dict__, "ctx": args.n_gen + 8})
-    model = synth.StreamModel(cfg, synth.GGML_Q8_0, synth.iter_torch(cfg, seed=args.seed, device=dev))
+    # with a CPU baseline leg the host keeps the tensors (synth.make_torch) for the oracle; otherwise they stream through
+    model = synth.make_torch(cfg, wtype=synth.GGML_Q8_0, seed=args.seed, device=dev) if not args.no_cpu_baseline else \
+        synth.StreamModel(cfg, synth.GGML_Q8_0, synth.iter_torch(cfg, seed=args.seed, device=dev))
     t0 = time.time()
     plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(model, prefill_batch_size=B, n_seqs=B)
     setup_s = time.time() - t0
@@ -510,6 +512,25 @@ def bench_decode_batch(args, cfg, synth, plan_mod, pkg, torch, np, dev):
     mat_elems = L * (cfg.q_dim * cfg.dim + 2 * kvd * cfg.dim + cfg.dim * cfg.q_dim + 3 * cfg.hidden * cfg.dim) + cfg.vocab * cfg.dim
     step_bytes = mat_elems * 34 // 32 + (2 * L + 1) * cfg.dim * 4
     gbs = step_bytes * steps_s / 1e9
+    # CPU baseline beside it (kind "port"): B independent sequences on the C oracle are B single-sequence decodes — the reference's CPU path
+    # has no batched decode — so a bounded sample of ONE sequence's steps gives the per-sequence rate; the host runs them back to back.
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle_c
+        if getattr(model, "tensors", None):
+            o = oracle_c.COracle(model)
+            n_done, tc = 0, time.perf_counter()
+            while True:
+                o.forward(int(toks[n_done, 0]), n_done)
+                n_done += 1
+                el = time.perf_counter() - tc
+                if el > args.cpu_seconds or n_done >= args.n_gen:
+                    break
+            cpu = dict(value=round(n_done / el, 4), unit="tok/s", cores=oracle_c.lib().orc_num_threads(), kind="port",
+                       sample="%d single-sequence decode steps of sequence 0 (%.1f s): the CPU path has no batched decode, B sequences run one after the other "
+                              "at this rate" % (n_done, el), **host_cpu_info())
+    peaks = probe_peaks(0)
+    roof_extra = dict(peak_measured=peaks["hbm_read_gbs"], frac_of_peak_measured=round(gbs / peaks["hbm_read_gbs"], 4), peak_measured_detail=peaks) if peaks else {}
     print(json.dumps({
         "metric": "static-batched decode B=%d tok/s, %s Q8_0" % (B, args.model), "value": round(steps_s * B, 2), "unit": "tok/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(total / args.steps * 1e3, 3),
@@ -519,7 +540,8 @@ def bench_decode_batch(args, cfg, synth, plan_mod, pkg, torch, np, dev):
         "batched_steps_per_s": round(steps_s, 2), "ms_per_batched_step": round(1e3 / steps_s, 4),
         "roofline": {"bound": "hbm", "kernel": "whole batched step (weights read once per step)", "achieved": round(gbs, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                     "bytes_per_step": int(step_bytes)},
+                     "bytes_per_step": int(step_bytes), **roof_extra},
+        "cpu_baseline": cpu,
         "init": dict(plan.init_ms(), setup_s=round(setup_s, 2))}))
     plan.freeTornadoExecutionPlan()
 
