@@ -10,8 +10,8 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for st in $STAGES; do case $st in
 tests)
-  for f in tp decode fullsize kquant sampling seqsum run_host reference_golden; do
-    ( timeout 600 python -m pytest tests/test_gpu_$f.py tests/test_$f.py -m gpu -x -q --timeout 240 2>&1 | grep -E "passed|failed|skipped|^FAILED|rror" | tail -4 ) > $O/pytest_$f.log 2>&1
+  for f in gpu_tp gpu_decode gpu_fullsize gpu_kquant gpu_sampling gpu_seqsum gpu_run_host reference_golden; do
+    ( timeout 600 python -m pytest tests/test_$f.py -m gpu -x -q --timeout 240 2>&1 | grep -E "passed|failed|skipped|^FAILED|rror" | tail -4 ) > $O/pytest_$f.log 2>&1
     echo "== $f: $(tail -1 $O/pytest_$f.log)"
   done ;;
 bench)

@@ -75,7 +75,7 @@ def counter_table(sub, out_name, want):
             w.writerow(row)
 
 
-counter_table("pmc_pp_q8", tag + "_pmc_prefill_q8_mfma_valu.csv", ["pf_gemm", "pf_scores", "pf_pv", "pf_softmax"])
+counter_table("pmc_pp_q8", tag + "_pmc_prefill_q8_mfma_valu.csv", ["pf_gemm", "pf_scores", "pf_pv", "pf_softmax", "pf_attn"])
 counter_table("pmc_pp_f16", tag + "_pmc_prefill_f16_mfma_valu.csv", ["gemm_f16", "gemm_vlq"])
 counter_table("pmc_pp_q8_fetch", tag + "_pmc_prefill_q8_fetch.csv", ["pf_gemm"])
 
