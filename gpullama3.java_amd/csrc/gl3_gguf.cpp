@@ -331,11 +331,14 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
     if (it == g->meta.end()) return fail(g, GL3_E_ARG, "general.architecture missing");
     const std::string a = it->second.str;
     if (a == "llama") d->arch = GL3_ARCH_LLAMA;
+    // Devstral 2 (DevstralModelLoader.java:45-70, metadata prefix "mistral3"): the Llama graph with an independent head
+    // dimension (attention.key_length; forwardJavaDevstral InferenceCore.java:178-261) and a YaRN RoPE table
+    else if (a == "mistral3") d->arch = GL3_ARCH_LLAMA;
     else if (a == "qwen3") d->arch = GL3_ARCH_QWEN3;
     else if (a == "qwen2") d->arch = GL3_ARCH_QWEN2;
     else if (a == "granite") d->arch = GL3_ARCH_GRANITE;
     else if (a == "phi3") d->arch = GL3_ARCH_PHI3;
-    else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, qwen3, qwen2, granite, phi3)");
+    else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, mistral3, qwen3, qwen2, granite, phi3)");
     auto need = [&](const char* k, double* v) { return meta_num(g, a + "." + k, v); };
     // defaults as the reference loaders: rms epsilon 1e-5, rope theta 10000 (LlamaModelLoader.java:62-63)
     double dim, hid, nl, nh, nkv, eps = 1e-5, theta = 10000.0, ctx, kl;
@@ -401,6 +404,55 @@ void gl3_rope_table(int32_t ctx, int32_t head_size, float theta, float* cr, floa
         }
 }
 
+// RoPE.precomputeFreqsCisYaRN (J/inference/operation/RoPE.java:39-83, Devstral 2): per pair i0 = i/2 the frequency is a ramp
+// between the extrapolated (plain) and the interpolated (/ factor) one, and cos / sin carry the attention scale mscale.
+// Every intermediate is rounded to f32 where the reference's is a Java float.
+void gl3_rope_table_yarn(int32_t ctx, int32_t head_size, float theta, float factor, float beta_fast, float beta_slow,
+                         float log_multiplier, int32_t original_ctx, float* cr, float* ci) {
+    const int half = head_size / 2;
+    const float freq_scale = 1.0f / factor;
+    auto corr_dim = [&](float n_rot) {           // yarnCorrDim :76-78
+        const float ratio = (float)original_ctx / (n_rot * 2.0f * (float)M_PI);
+        return (float)head_size * (float)log((double)ratio) / (2.0f * (float)log((double)theta));
+    };
+    const float low = corr_dim(beta_fast), high = corr_dim(beta_slow);
+    const float mscale = log_multiplier > 0 ? 1.0f + 0.1f * log_multiplier * (float)log((double)(1.0f / freq_scale)) : 1.0f;
+    for (int pos = 0; pos < ctx; ++pos)
+        for (int i = 0; i < half; ++i) {
+            const float extrap = (float)(1.0 / pow((double)theta, (double)(2 * i) / (double)head_size));
+            const float interp = freq_scale * extrap;
+            const float span = high - low;
+            const float y = ((float)i - low) / (0.001f > span ? 0.001f : span);                  // yarnRamp :80-83
+            const float ramp = 1.0f - fminf(1.0f, fmaxf(0.0f, y));
+            const float freq = interp * (1.0f - ramp) + extrap * ramp;
+            const float val = (float)pos * freq;
+            cr[(size_t)pos * half + i] = (float)cos((double)val) * mscale;
+            ci[(size_t)pos * half + i] = (float)sin((double)val) * mscale;
+        }
+}
+
+// <arch>.rope.scaling.* of a YaRN file (DevstralModelLoader.java:80-86).  Returns 1 and fills the five parameters when
+// rope.scaling.type == "yarn" and the required keys are present, 0 when the file asks for the plain table.
+int32_t gl3_gguf_yarn_params(gl3_gguf* g, float* factor, float* beta_fast, float* beta_slow, float* log_multiplier, int32_t* original_ctx) {
+    if (!g) return 0;
+    auto it = g->meta.find("general.architecture");
+    if (it == g->meta.end()) return 0;
+    const std::string a = it->second.str;
+    auto ty = g->meta.find(a + ".rope.scaling.type");
+    if (ty == g->meta.end() || ty->second.type != GT_STRING || ty->second.str != "yarn") return 0;
+    double f, bf, bs, lm = 0.0, oc;
+    if (!meta_num(g, a + ".rope.scaling.factor", &f) || !meta_num(g, a + ".rope.scaling.yarn_beta_fast", &bf) ||
+        !meta_num(g, a + ".rope.scaling.yarn_beta_slow", &bs) || !meta_num(g, a + ".rope.scaling.original_context_length", &oc))
+        return 0;
+    meta_num(g, a + ".rope.scaling.yarn_log_multiplier", &lm);
+    if (factor) *factor = (float)f;
+    if (beta_fast) *beta_fast = (float)bf;
+    if (beta_slow) *beta_slow = (float)bs;
+    if (log_multiplier) *log_multiplier = (float)lm;
+    if (original_ctx) *original_ctx = (int32_t)oc;
+    return 1;
+}
+
 // Opens the file, builds the plan and uploads every tensor straight from the mapping (tensor names as
 // LlamaModelLoader.java:83-98).  opts (nullable) supplies ctx / max_batch / device / tp_* / flags / n_seqs; shape fields
 // are overwritten from the metadata.  Tensor-parallel plans are returned un-finalized when tp_size > 1 (the caller must
@@ -463,7 +515,10 @@ int32_t gl3_load_gguf(const char* path, const gl3_model_desc* opts, gl3_ctx** ou
     if (r == GL3_OK) {
         const size_t n = (size_t)d.ctx * (d.head_size / 2);
         std::vector<float> cr(n), ci(n);
-        gl3_rope_table(d.ctx, d.head_size, theta, cr.data(), ci.data());
+        float yf, ybf, ybs, ylm;
+        int32_t yoc;
+        if (gl3_gguf_yarn_params(g, &yf, &ybf, &ybs, &ylm, &yoc)) gl3_rope_table_yarn(d.ctx, d.head_size, theta, yf, ybf, ybs, ylm, yoc, cr.data(), ci.data());
+        else gl3_rope_table(d.ctx, d.head_size, theta, cr.data(), ci.data());
         r = gl3_upload_rope(ctx, cr.data(), ci.data(), n);
     }
     if (r == GL3_OK && d.tp_size <= 1 && !(d.flags & GL3_FLAG_FORCE_RCCL)) r = gl3_finalize(ctx);

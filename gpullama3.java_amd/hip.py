@@ -85,6 +85,10 @@ _SIGS = {  # symbol -> (restype, argtypes): exactly the declarations of include/
     "gl3_gguf_meta_string": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p)]),
     "gl3_gguf_model_desc": (C.c_int32, [C.c_void_p, C.POINTER(ModelDesc), C.POINTER(C.c_float)]),
     "gl3_rope_table": (None, [C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "gl3_rope_table_yarn": (None, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                   C.c_void_p, C.c_void_p]),
+    "gl3_gguf_yarn_params": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                         C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "gl3_kquant_to_q8_0": (C.c_int32, [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p]),
     "gl3_load_gguf": (C.c_int32, [C.c_char_p, C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
 }

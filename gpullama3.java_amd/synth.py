@@ -43,6 +43,10 @@ class ModelConfig:
     attention_scale: float = 0.0
     residual_scale: float = 1.0
     logit_scale: float = 1.0
+    # Devstral 2 only (DevstralModelLoader.java:80-86): (factor, beta_fast, beta_slow, log_multiplier, original_context_length) of
+    # the YaRN RoPE table, and the metadata prefix / general.architecture of the file ("mistral3")
+    yarn: tuple | None = None
+    gguf_arch: str | None = None
 
     @property
     def q_dim(self):
@@ -78,6 +82,12 @@ CONFIGS = {
     "mid-phi3": ModelConfig("mid-phi3-random", ARCH_PHI3, 1536, 4096, 2, 12, 4, 128, 2048, 160, 1e-5, 10000.0, False),
     # Phi-3-mini / Phi-3.5-mini head layout: head_size = dim / heads = 96 (not a power of two), multi-head attention
     "phi3-hs96": ModelConfig("phi3-hs96-random", ARCH_PHI3, 768, 2048, 2, 8, 8, 96, 1024, 160, 1e-5, 10000.0, False),
+    # Devstral 2 shape (forwardJavaDevstral): the Llama graph with head_size != dim / heads (q_dim 512 / 4096 on dim 256 / 2560) and
+    # a YaRN table whose ramp (pairs 17 .. 33 of 64 at head_size 128) and mscale are both active
+    "tiny-devstral": ModelConfig("tiny-devstral-random", ARCH_LLAMA, 256, 512, 2, 8, 2, 64, 512, 64, 1e-5, 1000000.0, False,
+                                  yarn=(8.0, 32.0, 1.0, 1.0, 4096), gguf_arch="mistral3"),
+    "mid-devstral": ModelConfig("mid-devstral-random", ARCH_LLAMA, 2560, 4096, 2, 32, 8, 128, 4096, 160, 1e-5, 1000000.0, False,
+                                 yarn=(48.0, 32.0, 1.0, 1.0, 8192), gguf_arch="mistral3"),
     "mha-llama": ModelConfig("mha-llama-random", ARCH_LLAMA, 1024, 2048, 2, 8, 8, 128, 1024, 160, 1e-5, 10000.0, False),
     # full-size SHAPES of the BASELINE models with few layers / a small vocabulary, so that the CPU oracle finishes in seconds:
     # one Llama-3-8B layer (K = 14336: 112 tile groups, activation quads == 14 * 256 exactly), the 128256-row vocabulary
@@ -150,6 +160,38 @@ def rope_table(ctx: int, head_size: int, theta: float):
             np.ascontiguousarray(np.sin(v64).astype(np.float32).reshape(-1)))
 
 
+def rope_table_yarn(ctx: int, head_size: int, theta: float, factor: float, beta_fast: float, beta_slow: float,
+                    log_multiplier: float, original_ctx: int):
+    """Host-side YaRN table as DevstralModelLoader.precomputeRopeFrequencies builds it (RoPE.precomputeFreqsCisYaRN,
+    J/inference/operation/RoPE.java:39-83); NumPy statement with every Java float kept in f32."""
+    f = np.float32
+    lnb = f(np.log(np.float64(f(theta))))
+
+    def corr_dim(n_rot):
+        ratio = f(f(original_ctx) / f(f(f(n_rot) * f(2.0)) * f(np.pi)))
+        return f(f(f(head_size) * f(np.log(np.float64(ratio)))) / f(f(2.0) * lnb))
+
+    low, high = corr_dim(beta_fast), corr_dim(beta_slow)
+    fscale = f(f(1.0) / f(factor))
+    mscale = f(f(1.0) + f(f(f(0.1) * f(log_multiplier)) * f(np.log(np.float64(f(f(1.0) / fscale)))))) if log_multiplier > 0 else f(1.0)
+    i = np.arange(0, head_size, 2, dtype=np.float64)
+    extrap = (1.0 / np.power(np.float64(theta), i / np.float64(head_size))).astype(f)
+    interp = (fscale * extrap).astype(f)
+    y = ((np.arange(head_size // 2, dtype=f) - low).astype(f) / max(f(0.001), f(high - low))).astype(f)
+    ramp = (f(1.0) - np.minimum(f(1.0), np.maximum(f(0.0), y))).astype(f)
+    freq = ((interp * (f(1.0) - ramp)).astype(f) + (extrap * ramp).astype(f)).astype(f)
+    v64 = (np.arange(ctx, dtype=f)[:, None] * freq[None, :]).astype(f).astype(np.float64)
+    return (np.ascontiguousarray((np.cos(v64).astype(f) * mscale).astype(f).reshape(-1)),
+            np.ascontiguousarray((np.sin(v64).astype(f) * mscale).astype(f).reshape(-1)))
+
+
+def model_rope(cfg: "ModelConfig"):
+    """The table the reference's loader for this model builds: YaRN for a Devstral file, the plain one otherwise."""
+    if cfg.yarn:
+        return rope_table_yarn(cfg.ctx, cfg.head_size, cfg.rope_theta, *cfg.yarn)
+    return rope_table(cfg.ctx, cfg.head_size, cfg.rope_theta)
+
+
 # ------------------------------------------------------------------ tensor list
 def tensor_specs(cfg: ModelConfig, wtype: int):
     """(name, rows, cols, ggml_type, kind) in file order; kind: 'mat' | 'norm'."""
@@ -194,7 +236,7 @@ class SynthModel:
 
     def __init__(self, cfg: ModelConfig, wtype: int, tensors: dict):
         self.cfg, self.wtype, self.tensors = cfg, wtype, tensors
-        self.rope = rope_table(cfg.ctx, cfg.head_size, cfg.rope_theta)
+        self.rope = model_rope(cfg)
 
     def tensor_items(self):
         return self.tensors.items()
@@ -233,7 +275,7 @@ class SynthModel:
     # ---- GGUF round trip (metadata keys as the reference loaders read them)
     def metadata(self):
         c = self.cfg
-        a = _ARCH_NAME[c.arch]
+        a = c.gguf_arch or _ARCH_NAME[c.arch]
         ftype = {GGML_F32: 0, GGML_F16: 1, GGML_Q4_0: 2, GGML_Q8_0: 7}[self.wtype]
         md = {
             "general.architecture": a, "general.name": c.name, "general.file_type": ftype,
@@ -245,7 +287,12 @@ class SynthModel:
         if c.arch == ARCH_GRANITE:
             md.update({"granite.embedding_scale": float(c.embedding_scale), "granite.attention.scale": float(c.attention_scale),
                        "granite.residual_scale": float(c.residual_scale), "granite.logit_scale": float(c.logit_scale)})
-        if c.arch == ARCH_QWEN3:
+        if c.yarn:
+            md.update({f"{a}.rope.scaling.type": "yarn", f"{a}.rope.scaling.factor": float(c.yarn[0]),
+                       f"{a}.rope.scaling.yarn_beta_fast": float(c.yarn[1]), f"{a}.rope.scaling.yarn_beta_slow": float(c.yarn[2]),
+                       f"{a}.rope.scaling.yarn_log_multiplier": float(c.yarn[3]),
+                       f"{a}.rope.scaling.original_context_length": int(c.yarn[4])})
+        if c.arch == ARCH_QWEN3 or c.head_size * c.n_heads != c.dim:
             md[f"{a}.attention.key_length"] = c.head_size
             md[f"{a}.attention.value_length"] = c.head_size
         return md
@@ -262,7 +309,11 @@ class SynthModel:
         g = gguf.GGUFFile(path)
         md = g.metadata
         a = md["general.architecture"]
-        arch = {v: k for k, v in _ARCH_NAME.items()}[a]
+        arch = ARCH_LLAMA if a == "mistral3" else {v: k for k, v in _ARCH_NAME.items()}[a]
+        yarn = None
+        if md.get(f"{a}.rope.scaling.type") == "yarn":
+            yarn = (md[f"{a}.rope.scaling.factor"], md[f"{a}.rope.scaling.yarn_beta_fast"], md[f"{a}.rope.scaling.yarn_beta_slow"],
+                    md.get(f"{a}.rope.scaling.yarn_log_multiplier", 0.0), md[f"{a}.rope.scaling.original_context_length"])
         dim, nh = md[f"{a}.embedding_length"], md[f"{a}.attention.head_count"]
         hs = md.get(f"{a}.attention.key_length", dim // nh)
         cfg = ModelConfig(md["general.name"], arch, dim, md[f"{a}.feed_forward_length"], md[f"{a}.block_count"], nh,
@@ -271,7 +322,8 @@ class SynthModel:
                           ctx or md[f"{a}.context_length"], md[f"{a}.attention.layer_norm_rms_epsilon"],
                           md[f"{a}.rope.freq_base"], "output.weight" not in g.tensors,
                           embedding_scale=md.get("granite.embedding_scale", 1.0), attention_scale=md.get("granite.attention.scale", 0.0),
-                          residual_scale=md.get("granite.residual_scale", 1.0), logit_scale=md.get("granite.logit_scale", 1.0))
+                          residual_scale=md.get("granite.residual_scale", 1.0), logit_scale=md.get("granite.logit_scale", 1.0),
+                          yarn=yarn, gguf_arch=a if a == "mistral3" else None)
         tensors = {}
         for name, (dims, ty, raw) in g.tensors.items():
             rows = dims[1] if len(dims) > 1 else 1
@@ -361,7 +413,7 @@ class StreamModel:
 
     def __init__(self, cfg: ModelConfig, wtype: int, it):
         self.cfg, self.wtype, self._it = cfg, wtype, it
-        self.rope = rope_table(cfg.ctx, cfg.head_size, cfg.rope_theta)
+        self.rope = model_rope(cfg)
 
     def tensor_items(self):
         for name, raw, ty, rows, cols in self._it:

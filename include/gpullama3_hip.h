@@ -57,7 +57,8 @@ typedef enum {
 } gl3_status;
 
 /* model families with all three plan modes in the reference (ForwardPlanFactory.java:123-141) */
-/* LLAMA: InferenceCore.forwardJava (also Mistral GGUFs, architecture "llama"); QWEN3: forwardJavaQwen3 (per-head q/k RMSNorm,
+/* LLAMA: InferenceCore.forwardJava (also Mistral GGUFs, architecture "llama") and forwardJavaDevstral :178-261 (Devstral 2,
+ * architecture "mistral3": the same graph with head_size = attention.key_length != dim / n_heads and a YaRN RoPE table); QWEN3: forwardJavaQwen3 (per-head q/k RMSNorm,
  * NeoX RoPE); QWEN2: forwardJavaQwen2 :434-563 (q/k/v bias, NeoX RoPE; Qwen2.5, DeepSeek-R1-Distill-Qwen). */
 enum { GL3_ARCH_LLAMA = 0, GL3_ARCH_QWEN3 = 1, GL3_ARCH_QWEN2 = 2,
        GL3_ARCH_GRANITE = 3, /* InferenceCore.forwardGranite :814-924: the Llama graph + embedding / attention / residual / logit scalars */
@@ -287,6 +288,15 @@ GL3_API int32_t gl3_gguf_meta_string(const gl3_gguf* g, const char* key, const c
 GL3_API int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* desc, float* rope_theta);
 /* RoPE.precomputeFreqsCis with ropeScaling = false: cr / ci are f32[ctx * head_size/2]. */
 GL3_API void gl3_rope_table(int32_t ctx, int32_t head_size, float theta, float* cr, float* ci);
+/* RoPE.precomputeFreqsCisYaRN (J/inference/operation/RoPE.java:39-83; Devstral 2, DevstralModelLoader.java:76-110): ramp between the
+ * plain and the / factor frequency per pair, cos / sin scaled by mscale = 1 + 0.1 * log_multiplier * ln(factor) (1 when
+ * log_multiplier <= 0).  gl3_load_gguf builds this table when <arch>.rope.scaling.type == "yarn". */
+GL3_API void gl3_rope_table_yarn(int32_t ctx, int32_t head_size, float theta, float factor, float beta_fast, float beta_slow,
+                                 float log_multiplier, int32_t original_ctx, float* cr, float* ci);
+/* <arch>.rope.scaling.{factor, yarn_beta_fast, yarn_beta_slow, yarn_log_multiplier (default 0), original_context_length}
+ * (DevstralModelLoader.java:80-86): returns 1 and fills them for a "yarn" file, 0 for a file with the plain table. */
+GL3_API int32_t gl3_gguf_yarn_params(gl3_gguf* g, float* factor, float* beta_fast, float* beta_slow, float* log_multiplier,
+                                     int32_t* original_ctx);
 /* ModelLoader.dequantizeToQ8_0TornadoTensor (J/model/loader/ModelLoader.java:173-224): the load-time conversion the reference's GPU
  * path applies to Q4_K / Q5_K / Q6_K tensors — element-wise getFloat of the CPU tensor classes (Q4_KFloatTensor.java:86-114,
  * Q5_KFloatTensor.java:86-120, Q6_KFloatTensor.java) re-quantised to Q8_0 blocks.  n_elements % 256 == 0; dst: n / 32 * 34 bytes.

@@ -364,8 +364,9 @@ static void forward(orc_ctx* o, int token, int pos, int want_logits, float* laye
             for (int i = 0; i < kvd; i++) o->v[i] = o->v[i] + t_get(&o->layer[ORC_T_BV][l], i);
         }
         if (c->arch == 0 || c->arch == 3) {
-            /* adjacent-pair RoPE, q for i<dim and k for i<kvDim — InferenceCore.java:75-87 */
-            for (int i = 0; i < dim; i += 2) {
+            /* adjacent-pair RoPE, q for i<dim and k for i<kvDim — InferenceCore.java:75-87; a Llama / Granite file has
+             * qDim == dim (headSize = dim / heads), Devstral 2 runs the same loop over qDim — forwardJavaDevstral :198-212 */
+            for (int i = 0; i < qd; i += 2) {
                 int head_dim = i % hs;
                 float fcr = o->rope_cr[(size_t)pos * (hs / 2) + head_dim / 2];
                 float fci = o->rope_ci[(size_t)pos * (hs / 2) + head_dim / 2];
@@ -500,6 +501,36 @@ ORC_API void orc_rope_table(int ctx, int head_size, double theta, float* cr, flo
             float val = pos * freq;
             cr[n] = (float)cos((double)val);
             ci[n] = (float)sin((double)val);
+            n++;
+        }
+}
+
+/* RoPE.precomputeFreqsCisYaRN  J/inference/operation/RoPE.java:39-74 with yarnCorrDim :76-78 and yarnRamp :80-83 (Devstral 2) */
+static float yarn_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) {
+    return n_dims * (float)log((double)(n_ctx_orig / (n_rot * 2.0f * (float)M_PI))) / (2.0f * (float)log((double)base));
+}
+static float yarn_ramp(float low, float high, int i0) {
+    float span = high - low;
+    float y = (i0 - low) / (0.001f > span ? 0.001f : span);
+    float c = 0.0f > y ? 0.0f : y;
+    return 1.0f - (1.0f < c ? 1.0f : c);
+}
+ORC_API void orc_rope_table_yarn(int ctx, int head_size, double theta, float factor, float beta_fast, float beta_slow,
+                                 float log_multiplier, int original_ctx, float* cr, float* ci) {
+    float freq_scale = 1.0f / factor;
+    float d0 = yarn_corr_dim(head_size, original_ctx, beta_fast, (float)theta);
+    float d1 = yarn_corr_dim(head_size, original_ctx, beta_slow, (float)theta);
+    float mscale = log_multiplier > 0 ? 1.0f + 0.1f * log_multiplier * (float)log((double)(1.0f / freq_scale)) : 1.0f;
+    size_t n = 0;
+    for (int pos = 0; pos < ctx; ++pos)
+        for (int i = 0; i < head_size; i += 2) {
+            float extrap = (float)(1.0 / pow(theta, i / (double)head_size));
+            float interp = freq_scale * extrap;
+            float mix = yarn_ramp(d0, d1, i / 2);
+            float freq = interp * (1.0f - mix) + extrap * mix;
+            float val = pos * freq;
+            cr[n] = (float)cos((double)val) * mscale;
+            ci[n] = (float)sin((double)val) * mscale;
             n++;
         }
 }

@@ -56,6 +56,9 @@ def lib():
         L.orc_get_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_argmax.argtypes = [C.c_void_p, C.c_int]
         L.orc_rope_table.argtypes = [C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_rope_table_yarn.argtypes = [C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                          C.c_void_p, C.c_void_p]
+        L.orc_rope_table_yarn.restype = None
         L.orc_f16_to_f32.restype = C.c_float
         L.orc_f16_to_f32.argtypes = [C.c_uint16]
         L.orc_f32_to_f16.restype = C.c_uint16

@@ -176,6 +176,35 @@ def rope_table(ctx: int, head_size: int, theta: float):
     return np.cos(val.astype(np.float64)).astype(F32).reshape(-1), np.sin(val.astype(np.float64)).astype(F32).reshape(-1)
 
 
+def rope_table_yarn(ctx: int, head_size: int, theta: float, factor: float, beta_fast: float, beta_slow: float,
+                    log_multiplier: float, original_ctx: int):
+    """RoPE.precomputeFreqsCisYaRN — J/inference/operation/RoPE.java:39-83 (Devstral 2).  Every Java float stays an F32 here."""
+    f = F32
+    theta32 = f(theta)
+
+    def corr_dim(n_rot):
+        ratio = f(f(original_ctx) / f(f(f(n_rot) * f(2.0)) * f(np.pi)))
+        return f(f(f(head_size) * f(np.log(np.float64(ratio)))) / f(f(2.0) * f(np.log(np.float64(theta32)))))
+
+    low, high = corr_dim(beta_fast), corr_dim(beta_slow)
+    freq_scale = f(f(1.0) / f(factor))
+    if log_multiplier > 0:
+        mscale = f(f(1.0) + f(f(f(0.1) * f(log_multiplier)) * f(np.log(np.float64(f(f(1.0) / freq_scale))))))
+    else:
+        mscale = f(1.0)
+    i = np.arange(0, head_size, 2, dtype=np.float64)
+    extrap = (1.0 / np.power(np.float64(theta), i / np.float64(head_size))).astype(F32)
+    interp = (freq_scale * extrap).astype(F32)
+    span = max(f(0.001), f(high - low))
+    y = ((np.arange(head_size // 2, dtype=F32) - low).astype(F32) / span).astype(F32)
+    ramp = (f(1.0) - np.minimum(f(1.0), np.maximum(f(0.0), y))).astype(F32)
+    freq = ((interp * (f(1.0) - ramp)).astype(F32) + (extrap * ramp).astype(F32)).astype(F32)
+    val = (np.arange(ctx, dtype=F32)[:, None] * freq[None, :]).astype(F32)
+    cr = (np.cos(val.astype(np.float64)).astype(F32) * mscale).astype(F32)
+    ci = (np.sin(val.astype(np.float64)).astype(F32) * mscale).astype(F32)
+    return cr.reshape(-1), ci.reshape(-1)
+
+
 class NpOracle:
     """Holds config, raw GGUF-layout tensors and the State arrays (LlamaState.java:28-81)."""
 

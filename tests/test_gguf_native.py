@@ -64,6 +64,84 @@ def test_native_rope_table_is_bit_identical_to_the_numpy_restatement(pkg, hip, c
     assert np.array_equal(a, cr) and np.array_equal(b, ci)
 
 
+YARN_CASES = [(64, 64, 1000000.0, 8.0, 32.0, 1.0, 1.0, 4096), (160, 128, 1000000.0, 48.0, 32.0, 1.0, 1.0, 8192),
+              (33, 128, 1e9, 48.0, 32.0, 1.0, 0.0, 8192),          # log_multiplier 0: mscale = 1
+              (20, 32, 10000.0, 4.0, 32.0, 1.0, 0.5, 2048), (9, 96, 500000.0, 2.5, 16.0, 2.0, 1.0, 1024)]
+
+
+@pytest.mark.parametrize("ctx,hs,theta,factor,bf,bs,lm,oc", YARN_CASES)
+def test_yarn_rope_table_four_statements_agree_bit_for_bit(pkg, hip, orc, ctx, hs, theta, factor, bf, bs, lm, oc):
+    """RoPE.precomputeFreqsCisYaRN (RoPE.java:39-83): the library's table (what gl3_load_gguf uploads for a Devstral file), the C
+    oracle's, and the two NumPy statements (host mirror, oracle_np) are the same bits."""
+    from oracle import oracle_np
+    cr, ci = pkg.synth.rope_table_yarn(ctx, hs, theta, factor, bf, bs, lm, oc)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    a, b = np.empty_like(cr), np.empty_like(ci)
+    hip.lib().gl3_rope_table_yarn(ctx, hs, C.c_float(theta), C.c_float(factor), C.c_float(bf), C.c_float(bs), C.c_float(lm), oc, p(a), p(b))
+    assert np.array_equal(a, cr) and np.array_equal(b, ci)
+    a2, b2 = np.empty_like(cr), np.empty_like(ci)
+    orc.lib().orc_rope_table_yarn(ctx, hs, theta, factor, bf, bs, lm, oc, p(a2), p(b2))
+    assert np.array_equal(a2, cr) and np.array_equal(b2, ci)
+    n_cr, n_ci = oracle_np.rope_table_yarn(ctx, hs, theta, factor, bf, bs, lm, oc)
+    assert np.array_equal(n_cr, cr) and np.array_equal(n_ci, ci)
+
+
+def test_yarn_rope_table_known_structure(pkg):
+    """Hand-checkable structure of the YaRN table (RoPE.java:46-69): below the fast-rotation correlation dimension the pair keeps the
+    plain frequency, above the slow one it is divided by the factor, and every entry carries mscale = 1 + 0.1 * m * ln(factor)."""
+    ctx, hs, theta, factor, bf, bs, lm, oc = 48, 128, 1000000.0, 48.0, 32.0, 1.0, 1.0, 8192
+    cr, ci = (t.reshape(ctx, hs // 2) for t in pkg.synth.rope_table_yarn(ctx, hs, theta, factor, bf, bs, lm, oc))
+    pr, pi = (t.reshape(ctx, hs // 2) for t in pkg.synth.rope_table(ctx, hs, theta))
+    mscale = np.float32(1.0) + np.float32(0.1) * np.float32(np.log(np.float64(np.float32(48.0))))
+    assert abs(float(mscale) - 1.3871201) < 1e-6
+    # corr dims: 128 * ln(8192 / (32 * 2 pi)) / (2 ln 1e6) = 17.17..., 128 * ln(8192 / (2 pi)) / (2 ln 1e6) = 33.22...
+    low, high = 17.17, 33.23
+    fast = np.arange(hs // 2) <= int(low)              # ramp == 1: extrapolated (plain) frequency
+    assert np.array_equal(cr[:, fast], (pr[:, fast] * mscale).astype(np.float32))
+    assert np.array_equal(ci[:, fast], (pi[:, fast] * mscale).astype(np.float32))
+    slow = np.arange(hs // 2) >= int(high) + 1         # ramp == 0: frequency / factor
+    i = np.arange(0, hs, 2, dtype=np.float64)
+    f = ((1.0 / np.power(theta, i / hs)).astype(np.float32) * (np.float32(1.0) / np.float32(factor))).astype(np.float32)
+    val = (np.arange(ctx, dtype=np.float32)[:, None] * f[None, :]).astype(np.float32).astype(np.float64)
+    assert np.array_equal(cr[:, slow], (np.cos(val).astype(np.float32) * mscale).astype(np.float32)[:, slow])
+    mid = ~fast & ~slow
+    assert mid.sum() == 16 and not np.array_equal(cr[1:, mid], (pr[1:, mid] * mscale).astype(np.float32))
+    assert np.array_equal(cr[0], np.full(hs // 2, mscale, np.float32)) and not ci[0].any()     # position 0: cos = mscale, sin = 0
+
+
+def test_devstral_gguf_metadata_round_trip(pkg, hip, tmp_path):
+    """A "mistral3" file (DevstralModelLoader.java:45-110): Llama graph, head_size from attention.key_length, YaRN parameters."""
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-devstral"], seed=3)
+    path = str(tmp_path / "d.gguf")
+    m.write_gguf(path)
+    L = hip.lib()
+    g = C.c_void_p()
+    hip.check_gguf(L.gl3_gguf_open(path.encode(), C.byref(g)))
+    try:
+        d = hip.ModelDesc()
+        theta = C.c_float()
+        hip.check_gguf(L.gl3_gguf_model_desc(g, C.byref(d), C.byref(theta)), g)
+        c = m.cfg
+        assert (d.arch, d.dim, d.n_heads, d.n_kv_heads, d.head_size) == (0, c.dim, c.n_heads, c.n_kv_heads, c.head_size)
+        assert d.head_size * d.n_heads == 2 * d.dim
+        f, bf, bs, lm, oc = C.c_float(), C.c_float(), C.c_float(), C.c_float(), C.c_int32()
+        assert L.gl3_gguf_yarn_params(g, C.byref(f), C.byref(bf), C.byref(bs), C.byref(lm), C.byref(oc)) == 1
+        assert (f.value, bf.value, bs.value, lm.value, oc.value) == c.yarn
+    finally:
+        L.gl3_gguf_close(g)
+    back = pkg.synth.SynthModel.from_gguf(path)
+    assert back.cfg.yarn == c.yarn and back.cfg.head_size == c.head_size and back.cfg.arch == 0
+    assert np.array_equal(back.rope[0], m.rope[0]) and np.array_equal(back.rope[1], m.rope[1])
+    # a plain file has no YaRN block
+    m2 = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], seed=3)
+    m2.write_gguf(path)
+    hip.check_gguf(L.gl3_gguf_open(path.encode(), C.byref(g)))
+    try:
+        assert L.gl3_gguf_yarn_params(g, None, None, None, None, None) == 0
+    finally:
+        L.gl3_gguf_close(g)
+
+
 def test_reader_rejects_bad_files(hip, tmp_path):
     L = hip.lib()
     g = C.c_void_p()

@@ -31,6 +31,7 @@ def planmod():
 @pytest.mark.parametrize("fx,cfg,seed,wtype,scalar", [("tiny_llama_q8_0", "tiny-llama", 7, 8, False), ("tiny_qwen3_q8_0", "tiny-qwen3", 5, 8, False),
                                                       ("tiny_llama_f16", "tiny-llama", 7, 1, True), ("tiny_llama_tied_q4_0", "tiny-llama-tied", 11, 2, True),
                                                       ("tiny_qwen2_q8_0", "tiny-qwen2", 13, 8, False), ("tiny_granite_q8_0", "tiny-granite", 19, 8, False), ("tiny_phi3_q8_0", "tiny-phi3", 23, 8, False),
+                                                      ("tiny_devstral_q8_0", "tiny-devstral", 29, 8, False),
                                                       ("tiny_llama_f16_v256", "tiny-llama", 7, 1, False), ("tiny_llama_tied_q4_0_v256", "tiny-llama-tied", 11, 2, False),
                                                       ("tiny_llama_q8_0_f32act_v256", "tiny-llama", 7, 8, "f32act")])
 def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed, wtype, scalar):
@@ -56,7 +57,7 @@ def test_decode_matches_golden_fixture(pkg, planmod, fx, cfg, seed, wtype, scala
 
 
 @pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "tiny-llama-tied", "tiny-qwen2", "mid-qwen2", "mha-llama", "tiny-granite", "mid-granite", "tiny-phi3", "mid-phi3",
-                                 "phi3-hs96"])      # head_size 96 = Phi-3-mini's dim / heads (not a power of two)
+                                 "phi3-hs96", "mid-devstral"])      # head_size 96 = Phi-3-mini's dim / heads (not a power of two)
 def test_decode_matches_c_oracle_live(pkg, orc, planmod, cfg):
     """Shapes with full 64-block chunks, ragged chunk tails (K = 2560), head sizes 32/64/128, tied wcls, and multi-head
     attention (kvMul = 1 with head_size 128: the KV write must cover head_size > 64 * kvMul)."""
@@ -225,7 +226,7 @@ def test_error_behaviour(pkg, planmod):
     hip.lib().gl3_destroy(h)
 
 
-@pytest.mark.parametrize("cfg,batch,chunks", [("tiny-llama", 8, [8, 8, 5]), ("mid-llama", 64, [40, 64, 3]), ("mid-qwen3", 32, [30, 7]), ("mid-qwen2", 64, [50, 9]), ("mid-granite", 64, [33, 20]), ("mid-phi3", 64, [41, 6]),
+@pytest.mark.parametrize("cfg,batch,chunks", [("tiny-llama", 8, [8, 8, 5]), ("mid-llama", 64, [40, 64, 3]), ("mid-qwen3", 32, [30, 7]), ("mid-qwen2", 64, [50, 9]), ("mid-granite", 64, [33, 20]), ("mid-phi3", 64, [41, 6]), ("mid-devstral", 64, [45, 18]),
                                              ("tiny-llama-tied", 512, [37]), ("phi3-hs96", 64, [50, 14])])
 def test_batched_prefill_is_bit_identical_to_the_cpu_path(pkg, orc, planmod, cfg, batch, chunks):
     """tornadoVMForwardBatchPrefill (MFMA int8 GEMM path) vs batchForwardJavaPrefill: same KV cache, same x of the
@@ -349,7 +350,8 @@ def test_static_batched_decode_matches_independent_cpu_runs(pkg, orc, planmod, c
     plan.freeTornadoExecutionPlan()
 
 
-@pytest.mark.parametrize("cfg,wtype", [("tiny-llama", 8), ("tiny-qwen3", 8), ("tiny-llama-tied", 1), ("tiny-qwen2", 8), ("tiny-granite", 8), ("tiny-phi3", 8)])
+@pytest.mark.parametrize("cfg,wtype", [("tiny-llama", 8), ("tiny-qwen3", 8), ("tiny-llama-tied", 1), ("tiny-qwen2", 8), ("tiny-granite", 8), ("tiny-phi3", 8),
+                                       ("tiny-devstral", 8)])          # "mistral3" file: key_length head size + YaRN table built by the library
 def test_native_gguf_loader_builds_the_same_plan(pkg, orc, planmod, tmp_path, cfg, wtype):
     """gl3_load_gguf (mmap + native config / tensor-name map / RoPE table) vs the per-tensor upload path driven from Python."""
     plan_mod, hip = planmod

@@ -11,6 +11,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = [("tiny_llama_q8_0", "tiny-llama", 8, 7, 0), ("tiny_llama_f16", "tiny-llama", 1, 7, 0),
          ("tiny_llama_tied_q4_0", "tiny-llama-tied", 2, 11, 0), ("tiny_qwen3_q8_0", "tiny-qwen3", 8, 5, 0),
          ("tiny_qwen2_q8_0", "tiny-qwen2", 8, 13, 0), ("tiny_granite_q8_0", "tiny-granite", 8, 19, 0), ("tiny_phi3_q8_0", "tiny-phi3", 8, 23, 0),
+         ("tiny_devstral_q8_0", "tiny-devstral", 8, 29, 0),
          # Vector-API dot order (256-bit species) for F16 / Q4_0 matrices: FP16FloatTensor.vectorDot / Q4_0FloatTensor.vectorDot
          ("tiny_llama_f16_v256", "tiny-llama", 1, 7, 256), ("tiny_llama_tied_q4_0_v256", "tiny-llama-tied", 2, 11, 256),
          # Q8_0 + 256 = -Dllama.quantizeActivation=false: Q8_0FloatTensor.vectorDot on the f32 activation (SURVEY 8 a4')
@@ -38,7 +39,8 @@ def test_c_oracle_matches_golden_bitwise(pkg, orc, fx, cfg, wt, seed, vbits):
 
 def test_numpy_and_c_agree_on_fresh_seed(pkg, orc):
     # qwen2: q/k/v bias + NeoX RoPE; mha-llama: n_heads == n_kv_heads (kvMul = 1), head_size 128
-    for cfg, wt in [("tiny-llama-tied", 8), ("tiny-qwen3", 1), ("tiny-qwen2", 8), ("tiny-qwen2", 2), ("mha-llama", 8), ("tiny-granite", 8), ("tiny-granite", 1), ("tiny-phi3", 8), ("tiny-phi3", 2)]:
+    for cfg, wt in [("tiny-llama-tied", 8), ("tiny-qwen3", 1), ("tiny-qwen2", 8), ("tiny-qwen2", 2), ("mha-llama", 8), ("tiny-granite", 8), ("tiny-granite", 1), ("tiny-phi3", 8), ("tiny-phi3", 2),
+                    ("tiny-devstral", 8), ("tiny-devstral", 1)]:       # devstral: q_dim 512 on dim 256, YaRN table
         m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wt, seed=1234)
         co = orc.COracle(m)
         no = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope)
