@@ -21,6 +21,7 @@
 #include "gl3_decode_kernels.h"
 #include "gl3_rowlane_kernels.h"
 #include "gl3_veclane_kernels.h"
+#include "gl3_moe_kernels.h"
 
 using namespace gl3;
 
@@ -157,6 +158,25 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
     else launch_matvec_t<PRO_RMS, EPI_SWIGLU>(ctx, a, wgs, smem, nt);
 }
 
+// Routed experts of a Qwen2-MoE layer: one launch, blockIdx.y = slot of the top-k selection (matvec_q8t_kernel<.., SEL>).
+// stack holds n_experts sub-matrices of `rows` rows each; x / out advance by x_slot / out_slot floats per slot.
+static void launch_matvec_sel(gl3_ctx* ctx, int pro, int epi, const Q8Mat& stack, const Q8Mat* stack2, int rows, const float* x,
+                              const float* norm_w, float* out, int x_slot, int out_slot) {
+    const gl3_model_desc& d = ctx->d;
+    static const int max_wgs = getenv("GL3_WGS") ? atoi(getenv("GL3_WGS")) : 512;
+    Q8Mat sub = stack;
+    sub.rows = rows; sub.nstrips = rows / 16;
+    MatvecArgs a{};
+    a.w = stack.w; a.w2 = stack2 ? stack2->w : nullptr; a.rows = rows; a.k = stack.k; a.ng = stack.ng; a.nstrips = sub.nstrips;
+    a.x = x; a.norm_w = norm_w; a.eps = d.rms_eps; a.out = out; a.resid_in = nullptr; a.out_scale = 1.0f;
+    a.sel = ctx->moe_sel; a.sel_stride = (size_t)sub.nstrips * stack.ng * TILE_BYTES; a.x_slot_stride = x_slot; a.out_slot_stride = out_slot;
+    const int wgs = sub.nstrips < max_wgs ? sub.nstrips : max_wgs;
+    const size_t smem = matvec_smem(pro, epi, sub);
+    const dim3 grid(wgs, d.n_experts_used);
+    if (pro == PRO_RMS) hipLaunchKernelGGL((matvec_q8t_kernel<PRO_RMS, EPI_SWIGLU, true, 4, true>), grid, dim3(mv_threads(4)), smem, ctx->stream, a);
+    else hipLaunchKernelGGL((matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 4, true>), grid, dim3(mv_threads(4)), smem, ctx->stream, a);
+}
+
 // ------------------------------------------------------------------------------------------------ decode step
 struct Prof {
     gl3_ctx* ctx; gl3_kernel_times* kt; size_t n = 0; std::vector<int> klass;
@@ -190,6 +210,38 @@ struct Prof {
 };
 
 static uint64_t mv_bytes(const Q8Mat& w) { return w.algo_bytes() + (uint64_t)w.k * 4 + (uint64_t)w.rows * 4; }
+
+// The MoE feed-forward block of one decode step — InferenceCore.forwardJavaQwen2MoE :363-415 (kernels: gl3_moe_kernels.h).
+// x is read by every projection (each normalises it in its own prologue) and only rewritten by the final combine launch, so the
+// order of the launches in between is free; the accumulation order into x is the reference's (selection order, then shared).
+static void enqueue_moe_ffn(gl3_ctx* ctx, gl3_layer& L, Prof& pr) {
+    const gl3_model_desc& d = ctx->d;
+    hipStream_t s = ctx->stream;
+    const int E = d.n_experts, topk = d.n_experts_used, mh = d.moe_hidden;
+    const uint64_t row34 = (uint64_t)(d.dim / 32) * 34;
+    pr.begin(GL3_K_OTHER, (uint64_t)(E + 1) * d.dim * 4 + d.dim * 8);
+    {   Gl3Range g("moe: rmsnorm + router + top-k");
+        const size_t sm = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
+        hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3(1), dim3(256), sm, s, ctx->x, d.dim, L.ffn_norm, d.rms_eps, ctx->xn);
+        hipLaunchKernelGGL(moe_router_kernel, dim3(E + 1), dim3(256), (size_t)d.dim * 4, s, L.gate_inp, L.gate_inp_shexp, ctx->xn, d.dim, E, topk,
+                           ctx->moe_logits, ctx->moe_w);
+        hipLaunchKernelGGL(moe_select_kernel, dim3(1), dim3(64), (size_t)(E + 4) * 4, s, ctx->moe_logits, E, topk, ctx->moe_sel, ctx->moe_w); }
+    pr.end();
+    pr.begin(GL3_K_MATVEC_GATEUP, (uint64_t)2 * topk * mh * row34 + mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4);
+    {   Gl3Range g("moe: expert + shared gate/up + swiglu");
+        launch_matvec_sel(ctx, PRO_RMS, EPI_SWIGLU, L.gate_exps, &L.up_exps, mh, ctx->x, L.ffn_norm, ctx->moe_hb, 0, mh);
+        launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb, nullptr); }
+    pr.end();
+    pr.begin(GL3_K_MATVEC_DOWN, (uint64_t)topk * d.dim * (mh / 32) * 34 + mv_bytes(L.w2));
+    {   Gl3Range g("moe: expert + shared down");
+        launch_matvec_sel(ctx, PRO_QUANT, EPI_RESID, L.down_exps, nullptr, d.dim, ctx->moe_hb, nullptr, ctx->moe_y, mh, d.dim);
+        launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->moe_y + (size_t)topk * d.dim, nullptr); }
+    pr.end();
+    pr.begin(GL3_K_OTHER, (uint64_t)(topk + 3) * d.dim * 4);
+    {   Gl3Range g("moe: weighted accumulation into x");
+        hipLaunchKernelGGL(moe_combine_kernel, dim3((d.dim + 255) / 256), dim3(256), 0, s, ctx->x, ctx->moe_y, ctx->moe_w, d.dim, topk + 1); }
+    pr.end();
+}
 
 static int32_t all_gather(gl3_ctx* ctx, int which, int count_per_rank, Prof& pr) {
     if (!ctx->use_rccl) return GL3_OK;
@@ -262,6 +314,11 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         pr.end();
         if (!ctx->wo_replicated && (r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
 
+        if (d.arch == GL3_ARCH_QWEN2MOE) {
+            enqueue_moe_ffn(ctx, L, pr);
+            if (ctx->taps) hipMemcpyAsync(ctx->taps + (size_t)l * d.dim, ctx->x, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, s);
+            continue;
+        }
         pr.begin(GL3_K_MATVEC_GATEUP, mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4, q8);
         { Gl3Range g("rmsnorm + gate/up + swiglu"); launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr); }
         pr.end();
@@ -342,10 +399,22 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     const gl3_model_desc& d = ctx->d;
     auto bail = [&](int32_t code, const std::string& msg) { g_create_err = msg.empty() ? ctx->err : msg; gl3_destroy(ctx); return code; };
     const double t0 = now_ms();
-    if (d.arch != GL3_ARCH_LLAMA && d.arch != GL3_ARCH_QWEN3 && d.arch != GL3_ARCH_QWEN2 && d.arch != GL3_ARCH_GRANITE && d.arch != GL3_ARCH_PHI3)
+    if (d.arch != GL3_ARCH_LLAMA && d.arch != GL3_ARCH_QWEN3 && d.arch != GL3_ARCH_QWEN2 && d.arch != GL3_ARCH_GRANITE && d.arch != GL3_ARCH_PHI3 &&
+        d.arch != GL3_ARCH_QWEN2MOE)
         return bail(GL3_E_UNSUPPORTED, "unsupported architecture");
+    const bool moe = d.arch == GL3_ARCH_QWEN2MOE;
+    if (moe) {      // the reference's GPU plan for this family is Q8_0, single token (Qwen2MoEQ8_0PlanComponents); so is this one
+        if (d.weight_type != GL3_TYPE_Q8_0 || (d.flags & GL3_FLAG_F32_ACTIVATION))
+            return bail(GL3_E_UNSUPPORTED, "qwen2moe: Q8_0 matrices with the int8 activation only");
+        if (d.tp_size > 1 || (d.flags & GL3_FLAG_FORCE_RCCL)) return bail(GL3_E_UNSUPPORTED, "qwen2moe: tensor parallelism is not built");
+        if (d.max_batch > 1 || d.n_seqs > 1) return bail(GL3_E_UNSUPPORTED, "qwen2moe: batched prefill / static-batched decode are not built (max_batch <= 1, n_seqs <= 1)");
+        if (d.n_experts < 1 || d.n_experts > 4096 || d.n_experts_used < 1 || d.n_experts_used > d.n_experts || d.n_experts_used > 64)
+            return bail(GL3_E_ARG, "qwen2moe: need 1 <= n_experts_used <= min(n_experts, 64), n_experts <= 4096");
+        if (d.moe_hidden < 32 || d.moe_hidden % 32) return bail(GL3_E_ARG, "qwen2moe: moe_hidden must be a positive multiple of 32");
+    } else if (d.n_experts || d.n_experts_used || d.moe_hidden)
+        return bail(GL3_E_ARG, "n_experts / n_experts_used / moe_hidden belong to GL3_ARCH_QWEN2MOE");
     // Granite: the Llama graph (adjacent-pair RoPE) + four scalars; Phi-3: NeoX pairs like Qwen2, without biases
-    ctx->rope_arch = d.arch == GL3_ARCH_GRANITE ? 0 : d.arch == GL3_ARCH_PHI3 ? 2 : d.arch;
+    ctx->rope_arch = d.arch == GL3_ARCH_GRANITE ? 0 : (d.arch == GL3_ARCH_PHI3 || moe) ? 2 : d.arch;
     if (d.arch == GL3_ARCH_GRANITE) {
         if (!(d.attention_scale > 0.f)) return bail(GL3_E_ARG, "granite: attention_scale must be > 0");
         ctx->emb_scale = d.embedding_scale; ctx->resid_scale = d.residual_scale; ctx->logit_scale = d.logit_scale; ctx->att_mul = d.attention_scale;
@@ -417,7 +486,25 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
         TRY(dmalloc(ctx, &L.attn_norm, d.dim));
         TRY(dmalloc(ctx, &L.ffn_norm, d.dim));
         if (d.arch == GL3_ARCH_QWEN3) { TRY(dmalloc(ctx, &L.qnorm, d.head_size)); TRY(dmalloc(ctx, &L.knorm, d.head_size)); }
-        if (d.arch == GL3_ARCH_QWEN2) { TRY(dmalloc(ctx, &L.bq, ctx->q_dim_l)); TRY(dmalloc(ctx, &L.bk, ctx->kv_dim_l)); TRY(dmalloc(ctx, &L.bv, ctx->kv_dim_l)); }
+        if (d.arch == GL3_ARCH_QWEN2 || moe) { TRY(dmalloc(ctx, &L.bq, ctx->q_dim_l)); TRY(dmalloc(ctx, &L.bk, ctx->kv_dim_l)); TRY(dmalloc(ctx, &L.bv, ctx->kv_dim_l)); }
+        if (moe) {
+            TRY(alloc_mat(ctx, L.gate_exps, d.n_experts * d.moe_hidden, d.dim));
+            TRY(alloc_mat(ctx, L.up_exps, d.n_experts * d.moe_hidden, d.dim));
+            TRY(alloc_mat(ctx, L.down_exps, d.n_experts * d.dim, d.moe_hidden));
+            TRY(dmalloc(ctx, &L.gate_inp, (size_t)d.n_experts * d.dim));
+            TRY(dmalloc(ctx, &L.gate_inp_shexp, d.dim));
+        }
+    }
+    if (moe) {
+        TRY(dmalloc(ctx, &ctx->moe_logits, d.n_experts));
+        TRY(dmalloc(ctx, &ctx->moe_w, d.n_experts_used + 1));
+        TRY(dmalloc(ctx, &ctx->moe_sel, d.n_experts_used));
+        TRY(dmalloc(ctx, &ctx->moe_hb, (size_t)d.n_experts_used * d.moe_hidden));
+        TRY(dmalloc(ctx, &ctx->moe_y, (size_t)(d.n_experts_used + 1) * d.dim));
+        TRYHIP(hipMemset(ctx->moe_sel, 0, sizeof(int) * d.n_experts_used));
+        TRYHIP(hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO_RMS, EPI_SWIGLU, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        TRYHIP(hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        TRYHIP(hipFuncSetAttribute((const void*)moe_router_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
     TRY(dmalloc(ctx, &ctx->out_norm, d.dim));
     ctx->kv_seq_stride = (size_t)d.n_layers * d.ctx * ctx->kv_dim_l;
@@ -515,7 +602,9 @@ void gl3_destroy(gl3_ctx* ctx) {
     for (auto& L : ctx->layers) {
         f(L.wqkv.w); f(L.wo.w); f(L.w1.w); f(L.w3.w); f(L.w2.w);
         f(L.attn_norm); f(L.ffn_norm); f(L.qnorm); f(L.knorm); f(L.bq); f(L.bk); f(L.bv);
+        f(L.gate_exps.w); f(L.up_exps.w); f(L.down_exps.w); f(L.gate_inp); f(L.gate_inp_shexp);
     }
+    f(ctx->moe_logits); f(ctx->moe_w); f(ctx->moe_sel); f(ctx->moe_hb); f(ctx->moe_y);
     f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->xn); f(ctx->qkv);
     if (!ctx->arena.base) { f(ctx->x); f(ctx->xb); f(ctx->hb); f(ctx->logits); }
     gl3_tp_arena_free(ctx);
@@ -608,7 +697,9 @@ int32_t gl3_upload_tensor(gl3_ctx* ctx, int32_t id, int32_t layer, const void* h
     const int rank = d.tp_rank;
     if ((id == GL3_T_WQKV || id == GL3_T_W13) && d.arch != GL3_ARCH_PHI3) GL3_FAIL(GL3_E_ARG, "fused attn_qkv / gate|up tensors belong to GL3_ARCH_PHI3");
     const bool is_mat = !(id == GL3_T_OUTPUT_NORM || id == GL3_T_ATTN_NORM || id == GL3_T_FFN_NORM || id == GL3_T_ATTN_Q_NORM ||
-                          id == GL3_T_ATTN_K_NORM || id == GL3_T_BQ || id == GL3_T_BK || id == GL3_T_BV);
+                          id == GL3_T_ATTN_K_NORM || id == GL3_T_BQ || id == GL3_T_BK || id == GL3_T_BV || id == GL3_T_FFN_GATE_INP ||
+                          id == GL3_T_FFN_GATE_INP_SHEXP);
+    if (id >= GL3_T_FFN_GATE_INP && d.arch != GL3_ARCH_QWEN2MOE) GL3_FAIL(GL3_E_ARG, "router / expert tensors belong to GL3_ARCH_QWEN2MOE");
     if (is_mat && type != d.weight_type) GL3_FAIL(GL3_E_UNSUPPORTED, "matrix ggml type differs from gl3_model_desc.weight_type");
     if (id > GL3_T_OUTPUT && (layer < 0 || layer >= d.n_layers)) GL3_FAIL(GL3_E_ARG, "layer out of range");
     gl3_layer* L = id > GL3_T_OUTPUT ? &ctx->layers[layer] : nullptr;
@@ -647,6 +738,12 @@ int32_t gl3_upload_tensor(gl3_ctx* ctx, int32_t id, int32_t layer, const void* h
         if (r == GL3_OK) r = upload_q8(ctx, L->w3, 0, ctx->hidden_l, host, bytes, 2 * d.hidden, d.dim, (long)d.hidden + (long)rank * ctx->hidden_l);
         if (r == GL3_OK) L->have |= (1u << GL3_T_W1) | (1u << GL3_T_W3);
         break;
+    // qwen2moe: the stacked experts are plain row ranges of one matrix (expert e = rows [e * rows_per_expert, (e + 1) * ...))
+    case GL3_T_FFN_GATE_EXPS: r = upload_q8(ctx, L->gate_exps, 0, d.n_experts * d.moe_hidden, host, bytes, d.n_experts * d.moe_hidden, d.dim, 0); break;
+    case GL3_T_FFN_UP_EXPS: r = upload_q8(ctx, L->up_exps, 0, d.n_experts * d.moe_hidden, host, bytes, d.n_experts * d.moe_hidden, d.dim, 0); break;
+    case GL3_T_FFN_DOWN_EXPS: r = upload_q8(ctx, L->down_exps, 0, d.n_experts * d.dim, host, bytes, d.n_experts * d.dim, d.moe_hidden, 0); break;
+    case GL3_T_FFN_GATE_INP: r = upload_f32(ctx, L->gate_inp, d.n_experts * d.dim, host, bytes, type); break;
+    case GL3_T_FFN_GATE_INP_SHEXP: r = upload_f32(ctx, L->gate_inp_shexp, d.dim, host, bytes, type); break;
     default: GL3_FAIL(GL3_E_ARG, "unknown tensor id");
     }
     if (r != GL3_OK) return r;
@@ -690,7 +787,9 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
     uint32_t need_l = (1u << GL3_T_ATTN_NORM) | (1u << GL3_T_WQ) | (1u << GL3_T_WK) | (1u << GL3_T_WV) | (1u << GL3_T_WO) |
                       (1u << GL3_T_FFN_NORM) | (1u << GL3_T_W1) | (1u << GL3_T_W2) | (1u << GL3_T_W3);
     if (d.arch == GL3_ARCH_QWEN3) need_l |= (1u << GL3_T_ATTN_Q_NORM) | (1u << GL3_T_ATTN_K_NORM);
-    if (d.arch == GL3_ARCH_QWEN2) need_l |= (1u << GL3_T_BQ) | (1u << GL3_T_BK) | (1u << GL3_T_BV);
+    if (d.arch == GL3_ARCH_QWEN2 || d.arch == GL3_ARCH_QWEN2MOE) need_l |= (1u << GL3_T_BQ) | (1u << GL3_T_BK) | (1u << GL3_T_BV);
+    if (d.arch == GL3_ARCH_QWEN2MOE)
+        need_l |= (1u << GL3_T_FFN_GATE_INP) | (1u << GL3_T_FFN_GATE_EXPS) | (1u << GL3_T_FFN_UP_EXPS) | (1u << GL3_T_FFN_DOWN_EXPS) | (1u << GL3_T_FFN_GATE_INP_SHEXP);
     for (int l = 0; l < d.n_layers; ++l)
         if ((ctx->layers[l].have & need_l) != need_l) GL3_FAIL(GL3_E_STATE, "layer " + std::to_string(l) + ": tensors missing");
     if (!ctx->rope_cr) GL3_FAIL(GL3_E_STATE, "rope tables not uploaded");
@@ -1077,6 +1176,20 @@ int32_t gl3_get_buffer(gl3_ctx* ctx, int32_t which, float* out, uint64_t n) {
         src = gl3_prefill_buf(ctx, which);
         cap = (uint64_t)ctx->d.max_batch * (which == 4 ? ctx->d.dim : which == 5 ? ctx->q_dim : ctx->d.hidden);
         break;
+    case 7:                                     // qwen2moe: routing weights of the last layer [n_experts_used] + the shared-expert gate
+        if (!ctx->moe_w) GL3_FAIL(GL3_E_STATE, "not a qwen2moe plan");
+        src = ctx->moe_w; cap = ctx->d.n_experts_used + 1;
+        break;
+    case 8: {                                   // qwen2moe: selected expert ids of the last layer, as floats
+        if (!ctx->moe_sel) GL3_FAIL(GL3_E_STATE, "not a qwen2moe plan");
+        if (n > (uint64_t)ctx->d.n_experts_used) GL3_FAIL(GL3_E_ARG, "buffer shorter than requested");
+        GL3_HIP(hipSetDevice(ctx->d.device));
+        GL3_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<int> ids(n);
+        GL3_HIP(hipMemcpy(ids.data(), ctx->moe_sel, n * sizeof(int), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i) out[i] = (float)ids[i];
+        return GL3_OK;
+    }
     default: GL3_FAIL(GL3_E_ARG, "unknown buffer id");
     }
     if (n > cap) GL3_FAIL(GL3_E_ARG, "buffer shorter than requested");

@@ -82,6 +82,10 @@ struct gl3_layer {
     Q8Mat wqkv, wo, w1, w3, w2;
     float *attn_norm = nullptr, *ffn_norm = nullptr, *qnorm = nullptr, *knorm = nullptr;
     float *bq = nullptr, *bk = nullptr, *bv = nullptr;      // qwen2: this rank's rows of the q / k / v bias
+    // qwen2moe: stacked routed experts ([n_experts * moe_hidden x dim] x 2, [n_experts * dim x moe_hidden]), the F32 router rows
+    // [n_experts x dim] and the F32 shared-expert gate row [dim]; the shared expert itself is w1 / w3 / w2
+    Q8Mat gate_exps, up_exps, down_exps;
+    float *gate_inp = nullptr, *gate_inp_shexp = nullptr;
     uint32_t have = 0;       // bit per tensor id
 };
 
@@ -145,6 +149,11 @@ struct gl3_ctx {
     float *x = nullptr, *qkv = nullptr, *xb = nullptr, *hb = nullptr, *logits = nullptr, *att = nullptr;
     float* xn = nullptr;                          // RMS-normalised activation (F16 / Q4_0 path only)
     float* taps = nullptr;                        // [L][dim] when GL3_FLAG_LAYER_TAPS
+    // qwen2moe scratch (Qwen2MoEState.java:15-32): router logits [n_experts], routing weights [topk + 1] (last = shared-expert
+    // gate), selected expert ids [topk], the selected experts' SwiGLU outputs [topk][moe_hidden], the down-projected outputs
+    // [topk + 1][dim] (last = shared expert)
+    float *moe_logits = nullptr, *moe_w = nullptr, *moe_hb = nullptr, *moe_y = nullptr;
+    int* moe_sel = nullptr;
     int *dyn = nullptr, *argmax = nullptr;        // dyn[0] = token, dyn[1] = position
     int* h_dyn = nullptr;                         // pinned
     const int* dyn_cur = nullptr;                 // (token, position) pair the next launches read: dyn, or an entry of dyn_seq

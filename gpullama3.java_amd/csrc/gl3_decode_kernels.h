@@ -67,6 +67,12 @@ struct MatvecArgs {
     const float* resid_in;   // may be NULL (tensor-parallel ranks > 0)
     float out_scale;         // EPI_STORE / EPI_RESID: the row result is multiplied by this first (1 except Granite: residualScale after wo /
                              // down, logitScale on the logits — InferenceCore.forwardGranite :893-894, :911-912, :921; x * 1.0f is exact)
+    // SEL instantiations only (Qwen2-MoE routed experts, InferenceCore.matmulExpert :430-432): blockIdx.y = slot j of the top-k
+    // selection; the launch works on expert sel[j] of a stacked tensor: w / w2 += sel[j] * sel_stride bytes,
+    // x += j * x_slot_stride floats (the slot's own hbE for the down projection), out += j * out_slot_stride floats
+    const int* sel;
+    size_t sel_stride;
+    int x_slot_stride, out_slot_stride;
 };
 
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
@@ -176,8 +182,17 @@ __device__ __forceinline__ uint16_t ld2(const uint8_t* p) {
 //       the epilogue while the producers already stream the next strip.
 // Register pressure is the maximum of the roles, not their sum (wave-uniform branches).
 //   LDS: xq[ng*128] | xs[ng*4] f32 | xf[k + 32] f32 (PRO_RMS) | pbuf[2][NM][ng*64] f32 | red[4] | sync[4]
-template <int PRO, int EPI, bool NT, int NPW = 4>
-__global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_kernel(const MatvecArgs a) {
+template <int PRO, int EPI, bool NT, int NPW = 4, bool SEL = false>
+__global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_kernel(const MatvecArgs a_in) {
+    MatvecArgs a = a_in;
+    if (SEL) {                                          // wave-uniform: one scalar load of the expert id
+        const int slot = blockIdx.y;
+        const size_t woff = (size_t)a.sel[slot] * a.sel_stride;
+        a.w += woff;
+        if (a.w2) a.w2 += woff;
+        a.x += (size_t)slot * a.x_slot_stride;
+        a.out += (size_t)slot * a.out_slot_stride;
+    }
     constexpr int MV_PRODUCERS = NPW;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NM = (EPI == EPI_SWIGLU) ? 2 : 1;

@@ -338,7 +338,8 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
     else if (a == "qwen2") d->arch = GL3_ARCH_QWEN2;
     else if (a == "granite") d->arch = GL3_ARCH_GRANITE;
     else if (a == "phi3") d->arch = GL3_ARCH_PHI3;
-    else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, mistral3, qwen3, qwen2, granite, phi3)");
+    else if (a == "qwen2moe") d->arch = GL3_ARCH_QWEN2MOE;          // ModelLoader.detectModelType :50-52: the architecture key decides
+    else return fail(g, GL3_E_UNSUPPORTED, "architecture '" + a + "' is not implemented (llama, mistral3, qwen3, qwen2, qwen2moe, granite, phi3)");
     auto need = [&](const char* k, double* v) { return meta_num(g, a + "." + k, v); };
     // defaults as the reference loaders: rms epsilon 1e-5, rope theta 10000 (LlamaModelLoader.java:62-63)
     double dim, hid, nl, nh, nkv, eps = 1e-5, theta = 10000.0, ctx, kl;
@@ -384,6 +385,15 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
         double es = 12.0, rs = 0.22, as = 0.0078125, ls = 16.0;
         need("embedding_scale", &es); need("residual_scale", &rs); need("attention.scale", &as); need("logit_scale", &ls);
         d->embedding_scale = (float)es; d->residual_scale = (float)rs; d->attention_scale = (float)as; d->logit_scale = (float)ls;
+    }
+    d->n_experts = d->n_experts_used = d->moe_hidden = 0;
+    if (d->arch == GL3_ARCH_QWEN2MOE) {         // Qwen2MoEModelLoader.java:56-84
+        double ne, nu;
+        if (!need("expert_count", &ne) || !need("expert_used_count", &nu)) return fail(g, GL3_E_ARG, "qwen2moe: expert_count / expert_used_count missing");
+        auto de = g->by_name.find("blk.0.ffn_down_exps.weight");
+        if (de == g->by_name.end() || g->tensors[de->second].n_dims != 3) return fail(g, GL3_E_ARG, "qwen2moe: blk.0.ffn_down_exps.weight missing or not 3-D");
+        d->n_experts = (int32_t)ne; d->n_experts_used = (int32_t)nu;
+        d->moe_hidden = (int32_t)g->tensors[de->second].ne[0];                  // dimensions()[0] of the down stack = experts' hidden size
     }
     // K-quant files run as Q8_0 after the load-time conversion (ModelLoader.loadTornadoTensor :163-164)
     d->weight_type = (emb.type == GL3_TYPE_Q4_K || emb.type == GL3_TYPE_Q5_K || emb.type == GL3_TYPE_Q6_K) ? GL3_TYPE_Q8_0 : emb.type;
@@ -495,6 +505,20 @@ int32_t gl3_load_gguf(const char* path, const gl3_model_desc* opts, gl3_ctx** ou
         {"ffn_gate.weight", GL3_T_W1, -1}, {"ffn_down.weight", GL3_T_W2, -1}, {"ffn_up.weight", GL3_T_W3, -1},
         {"attn_q_norm.weight", GL3_T_ATTN_Q_NORM, GL3_ARCH_QWEN3}, {"attn_k_norm.weight", GL3_T_ATTN_K_NORM, GL3_ARCH_QWEN3},
         {"attn_q.bias", GL3_T_BQ, GL3_ARCH_QWEN2}, {"attn_k.bias", GL3_T_BK, GL3_ARCH_QWEN2}, {"attn_v.bias", GL3_T_BV, GL3_ARCH_QWEN2}};
+    // Qwen2-MoE (Qwen2MoEModelLoader.java:86-110): qwen2 attention tensors, no dense FFN; the shared expert takes the W1 / W3 / W2 slots
+    static const struct { const char* name; int id; } moe_layer[] = {
+        {"attn_norm.weight", GL3_T_ATTN_NORM}, {"attn_q.weight", GL3_T_WQ}, {"attn_k.weight", GL3_T_WK}, {"attn_v.weight", GL3_T_WV},
+        {"attn_q.bias", GL3_T_BQ}, {"attn_k.bias", GL3_T_BK}, {"attn_v.bias", GL3_T_BV}, {"attn_output.weight", GL3_T_WO},
+        {"ffn_norm.weight", GL3_T_FFN_NORM}, {"ffn_gate_inp.weight", GL3_T_FFN_GATE_INP}, {"ffn_gate_exps.weight", GL3_T_FFN_GATE_EXPS},
+        {"ffn_up_exps.weight", GL3_T_FFN_UP_EXPS}, {"ffn_down_exps.weight", GL3_T_FFN_DOWN_EXPS}, {"ffn_gate_shexp.weight", GL3_T_W1},
+        {"ffn_up_shexp.weight", GL3_T_W3}, {"ffn_down_shexp.weight", GL3_T_W2}, {"ffn_gate_inp_shexp.weight", GL3_T_FFN_GATE_INP_SHEXP}};
+    if (d.arch == GL3_ARCH_QWEN2MOE) {
+        for (int l = 0; l < d.n_layers && r == GL3_OK; ++l)
+            for (const auto& t : moe_layer) {
+                r = up("blk." + std::to_string(l) + "." + t.name, t.id, l, true);
+                if (r != GL3_OK) break;
+            }
+    }
     // Phi-3 (Phi3ModelLoader.java:111-116): attn_qkv and ffn_up (= gate | up) are fused tensors
     static const struct { const char* name; int id; } phi3_layer[] = {
         {"attn_norm.weight", GL3_T_ATTN_NORM}, {"attn_qkv.weight", GL3_T_WQKV}, {"attn_output.weight", GL3_T_WO},
@@ -506,7 +530,7 @@ int32_t gl3_load_gguf(const char* path, const gl3_model_desc* opts, gl3_ctx** ou
                 if (r != GL3_OK) break;
             }
     }
-    for (int l = 0; l < d.n_layers && r == GL3_OK && d.arch != GL3_ARCH_PHI3; ++l)
+    for (int l = 0; l < d.n_layers && r == GL3_OK && d.arch != GL3_ARCH_PHI3 && d.arch != GL3_ARCH_QWEN2MOE; ++l)
         for (const auto& t : per_layer) {
             if (t.arch_only >= 0 && t.arch_only != d.arch) continue;
             r = up("blk." + std::to_string(l) + "." + t.name, t.id, l, true);

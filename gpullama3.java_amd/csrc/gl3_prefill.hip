@@ -802,7 +802,7 @@ __global__ __launch_bounds__(512) void pf_attn_fused_kernel(const float* __restr
     const int ntile = (ntok + FA_TB - 1) / FA_TB;
     const int kvh = blockIdx.x % n_kv_heads, tile = ntile - 1 - blockIdx.x / n_kv_heads;
     const int b0 = tile * FA_TB, nb = min(FA_TB, ntok - b0), tmax = pos0 + b0 + nb - 1;
-    const int n_heads = n_kv_heads * kvmul, head = kvh * kvmul + hq;
+    const int head = kvh * kvmul + hq;
     const float sqrt_hs = (float)sqrt((double)HS);
 
     // K / V tiles travel global -> registers -> LDS; the next tile's loads are in flight while the current one is consumed (clamped

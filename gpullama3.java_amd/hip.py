@@ -22,7 +22,11 @@ T_IDS = {"token_embd.weight": 0, "output_norm.weight": 1, "output.weight": 2, "a
          "attn_q.weight": 4, "attn_k.weight": 5, "attn_v.weight": 6, "attn_output.weight": 7,
          "ffn_norm.weight": 8, "ffn_gate.weight": 9, "ffn_down.weight": 10, "ffn_up.weight": 11,
          "attn_q_norm.weight": 12, "attn_k_norm.weight": 13, "attn_q.bias": 14, "attn_k.bias": 15, "attn_v.bias": 16,
-         "attn_qkv.weight": 17}
+         "attn_qkv.weight": 17,
+         # qwen2moe (Qwen2MoEModelLoader.java:97-105): router, stacked experts, shared-expert gate; the shared expert's matrices
+         # take the dense FFN ids
+         "ffn_gate_inp.weight": 19, "ffn_gate_exps.weight": 20, "ffn_up_exps.weight": 21, "ffn_down_exps.weight": 22,
+         "ffn_gate_inp_shexp.weight": 23, "ffn_gate_shexp.weight": 9, "ffn_down_shexp.weight": 10, "ffn_up_shexp.weight": 11}
 T_W13 = 18          # phi3: blk.L.ffn_up.weight holds gate | up (forwardJavaPhi3)
 
 
@@ -32,7 +36,8 @@ class ModelDesc(C.Structure):
                 ("vocab", C.c_int32), ("ctx", C.c_int32), ("rms_eps", C.c_float), ("weight_type", C.c_int32),
                 ("max_batch", C.c_int32), ("device", C.c_int32), ("tp_rank", C.c_int32), ("tp_size", C.c_int32),
                 ("flags", C.c_uint32), ("n_seqs", C.c_int32), ("embedding_scale", C.c_float), ("attention_scale", C.c_float),
-                ("residual_scale", C.c_float), ("logit_scale", C.c_float)]
+                ("residual_scale", C.c_float), ("logit_scale", C.c_float),
+                ("n_experts", C.c_int32), ("n_experts_used", C.c_int32), ("moe_hidden", C.c_int32)]
 
 
 class KernelTimes(C.Structure):

@@ -43,7 +43,8 @@ class HipMasterPlan:
         d = hip.ModelDesc(C.sizeof(hip.ModelDesc), c.arch, c.dim, c.hidden, c.n_layers, c.n_heads, c.n_kv_heads,
                           c.head_size, c.vocab, c.ctx, c.rms_eps, model.wtype, prefill_batch_size, device, tp_rank,
                           tp_size, flags, n_seqs, getattr(c, "embedding_scale", 1.0), getattr(c, "attention_scale", 0.0),
-                          getattr(c, "residual_scale", 1.0), getattr(c, "logit_scale", 1.0))
+                          getattr(c, "residual_scale", 1.0), getattr(c, "logit_scale", 1.0),
+                          getattr(c, "n_experts", 0), getattr(c, "n_experts_used", 0), getattr(c, "moe_hidden", 0))
         hip.check(L.gl3_create(C.byref(d), C.byref(self._ctx)))
         self.tp_size, self.tp_rank = tp_size, tp_rank
         self.max_batch = prefill_batch_size
@@ -119,7 +120,8 @@ class HipMasterPlan:
         finally:
             L.gl3_gguf_close(g)
         self.cfg = synth.ModelConfig(nm, d.arch, d.dim, d.hidden, d.n_layers, d.n_heads, d.n_kv_heads, d.head_size, d.vocab, d.ctx,
-                                     d.rms_eps, float(theta.value), tied)
+                                     d.rms_eps, float(theta.value), tied, n_experts=d.n_experts, n_experts_used=d.n_experts_used,
+                                     moe_hidden=d.moe_hidden)
         opts = hip.ModelDesc()
         opts.struct_size = C.sizeof(hip.ModelDesc)
         opts.ctx, opts.max_batch, opts.device, opts.tp_size, opts.flags, opts.n_seqs = ctx, prefill_batch_size, device, 1, flags, n_seqs

@@ -19,8 +19,9 @@ import numpy as np
 from . import gguf
 from .gguf import GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0
 
-ARCH_LLAMA, ARCH_QWEN3, ARCH_QWEN2, ARCH_GRANITE, ARCH_PHI3 = 0, 1, 2, 3, 4
-_ARCH_NAME = {ARCH_LLAMA: "llama", ARCH_QWEN3: "qwen3", ARCH_QWEN2: "qwen2", ARCH_GRANITE: "granite", ARCH_PHI3: "phi3"}
+ARCH_LLAMA, ARCH_QWEN3, ARCH_QWEN2, ARCH_GRANITE, ARCH_PHI3, ARCH_QWEN2MOE = 0, 1, 2, 3, 4, 5
+_ARCH_NAME = {ARCH_LLAMA: "llama", ARCH_QWEN3: "qwen3", ARCH_QWEN2: "qwen2", ARCH_GRANITE: "granite", ARCH_PHI3: "phi3",
+              ARCH_QWEN2MOE: "qwen2moe"}
 
 
 @dataclass
@@ -47,6 +48,11 @@ class ModelConfig:
     # the YaRN RoPE table, and the metadata prefix / general.architecture of the file ("mistral3")
     yarn: tuple | None = None
     gguf_arch: str | None = None
+    # Qwen2-MoE only (Qwen2MoEModelLoader.java:56-84): expert_count, expert_used_count, the routed experts' hidden size (rows of
+    # blk.0.ffn_down_exps.weight's first dimension); ``hidden`` is the shared expert's size (qwen2moe.feed_forward_length)
+    n_experts: int = 0
+    n_experts_used: int = 0
+    moe_hidden: int = 0
 
     @property
     def q_dim(self):
@@ -88,6 +94,15 @@ CONFIGS = {
                                   yarn=(8.0, 32.0, 1.0, 1.0, 4096), gguf_arch="mistral3"),
     "mid-devstral": ModelConfig("mid-devstral-random", ARCH_LLAMA, 2560, 4096, 2, 32, 8, 128, 4096, 160, 1e-5, 1000000.0, False,
                                  yarn=(48.0, 32.0, 1.0, 1.0, 8192), gguf_arch="mistral3"),
+    # Qwen1.5-MoE shape (forwardJavaQwen2MoE): qwen2 attention + F32 router over n_experts, top-k routed experts, gated shared
+    # expert.  mid: 60 experts / top-4 as Qwen1.5-MoE-A2.7B with narrow experts; a2.7b-moe-layer: one layer at the model's own
+    # sizes (dim 2048, 16 / 16 heads of 128, experts 1408, shared expert 5632)
+    "tiny-qwen2moe": ModelConfig("tiny-qwen2moe-random", ARCH_QWEN2MOE, 256, 512, 2, 8, 2, 32, 512, 64, 1e-6, 1000000.0, False,
+                                  n_experts=8, n_experts_used=2, moe_hidden=128),
+    "mid-qwen2moe": ModelConfig("mid-qwen2moe-random", ARCH_QWEN2MOE, 2048, 1536, 2, 16, 16, 128, 2048, 160, 1e-6, 1000000.0, False,
+                                 n_experts=60, n_experts_used=4, moe_hidden=384),
+    "a2.7b-moe-layer": ModelConfig("Qwen1.5-MoE-A2.7B-1layer-random", ARCH_QWEN2MOE, 2048, 5632, 1, 16, 16, 128, 2048, 160, 1e-6,
+                                    1000000.0, False, n_experts=60, n_experts_used=4, moe_hidden=1408),
     "mha-llama": ModelConfig("mha-llama-random", ARCH_LLAMA, 1024, 2048, 2, 8, 8, 128, 1024, 160, 1e-5, 10000.0, False),
     # full-size SHAPES of the BASELINE models with few layers / a small vocabulary, so that the CPU oracle finishes in seconds:
     # one Llama-3-8B layer (K = 14336: 112 tile groups, activation quads == 14 * 256 exactly), the 128256-row vocabulary
@@ -213,12 +228,24 @@ def tensor_specs(cfg: ModelConfig, wtype: int):
             (p + "attn_v.weight", cfg.kv_dim, cfg.dim, wtype, "mat"),
             (p + "attn_output.weight", cfg.dim, cfg.q_dim, wtype, "mat"),
         ]
-        if cfg.arch == ARCH_QWEN2:
+        if cfg.arch in (ARCH_QWEN2, ARCH_QWEN2MOE):
             specs += [(p + "attn_q.bias", 1, cfg.q_dim, GGML_F32, "bias"), (p + "attn_k.bias", 1, cfg.kv_dim, GGML_F32, "bias"),
                       (p + "attn_v.bias", 1, cfg.kv_dim, GGML_F32, "bias")]
         if cfg.arch == ARCH_QWEN3:
             specs += [(p + "attn_q_norm.weight", 1, cfg.head_size, GGML_F32, "norm"),
                       (p + "attn_k_norm.weight", 1, cfg.head_size, GGML_F32, "norm")]
+        if cfg.arch == ARCH_QWEN2MOE:      # Qwen2MoEModelLoader.java:97-105; router and shared-expert gate are F32 in the published files
+            E, mh = cfg.n_experts, cfg.moe_hidden
+            specs += [(p + "ffn_norm.weight", 1, cfg.dim, GGML_F32, "norm"),
+                      (p + "ffn_gate_inp.weight", E, cfg.dim, GGML_F32, "router"),
+                      (p + "ffn_gate_exps.weight", E * mh, cfg.dim, wtype, "mat"),
+                      (p + "ffn_up_exps.weight", E * mh, cfg.dim, wtype, "mat"),
+                      (p + "ffn_down_exps.weight", E * cfg.dim, mh, wtype, "mat"),
+                      (p + "ffn_gate_shexp.weight", cfg.hidden, cfg.dim, wtype, "mat"),
+                      (p + "ffn_up_shexp.weight", cfg.hidden, cfg.dim, wtype, "mat"),
+                      (p + "ffn_down_shexp.weight", cfg.dim, cfg.hidden, wtype, "mat"),
+                      (p + "ffn_gate_inp_shexp.weight", 1, cfg.dim, GGML_F32, "router")]
+            continue
         specs += [
             (p + "ffn_norm.weight", 1, cfg.dim, GGML_F32, "norm"),
             (p + "ffn_gate.weight", cfg.hidden, cfg.dim, wtype, "mat"),
@@ -267,7 +294,7 @@ class SynthModel:
         return dict(arch=c.arch, dim=c.dim, hidden=c.hidden, n_layers=c.n_layers, n_heads=c.n_heads,
                     n_kv_heads=c.n_kv_heads, head_size=c.head_size, vocab=c.vocab, ctx=c.ctx, rms_eps=c.rms_eps,
                     embedding_scale=c.embedding_scale, attention_scale=c.attention_scale, residual_scale=c.residual_scale,
-                    logit_scale=c.logit_scale)
+                    logit_scale=c.logit_scale, n_experts=c.n_experts, n_experts_used=c.n_experts_used, moe_hidden=c.moe_hidden)
 
     def weight_bytes(self):
         return sum(v[0].nbytes for v in self.tensors.values())
@@ -287,6 +314,9 @@ class SynthModel:
         if c.arch == ARCH_GRANITE:
             md.update({"granite.embedding_scale": float(c.embedding_scale), "granite.attention.scale": float(c.attention_scale),
                        "granite.residual_scale": float(c.residual_scale), "granite.logit_scale": float(c.logit_scale)})
+        if c.arch == ARCH_QWEN2MOE:
+            md.update({f"{a}.expert_count": c.n_experts, f"{a}.expert_used_count": c.n_experts_used,
+                       f"{a}.expert_feed_forward_length": c.moe_hidden, f"{a}.expert_shared_feed_forward_length": c.hidden})
         if c.yarn:
             md.update({f"{a}.rope.scaling.type": "yarn", f"{a}.rope.scaling.factor": float(c.yarn[0]),
                        f"{a}.rope.scaling.yarn_beta_fast": float(c.yarn[1]), f"{a}.rope.scaling.yarn_beta_slow": float(c.yarn[2]),
@@ -301,6 +331,8 @@ class SynthModel:
         ts = []
         for name, (raw, ty, rows, cols) in self.tensors.items():
             dims = [cols] if rows == 1 and ty == GGML_F32 else [cols, rows]
+            if "_exps." in name:                  # stacked experts: [n_experts x rows / n_experts x cols], ne = {cols, rows / E, E}
+                dims = [cols, rows // self.cfg.n_experts, self.cfg.n_experts]
             ts.append((name, dims, ty, raw))
         gguf.write_gguf(path, self.metadata(), ts)
 
@@ -323,10 +355,12 @@ class SynthModel:
                           md[f"{a}.rope.freq_base"], "output.weight" not in g.tensors,
                           embedding_scale=md.get("granite.embedding_scale", 1.0), attention_scale=md.get("granite.attention.scale", 0.0),
                           residual_scale=md.get("granite.residual_scale", 1.0), logit_scale=md.get("granite.logit_scale", 1.0),
-                          yarn=yarn, gguf_arch=a if a == "mistral3" else None)
+                          yarn=yarn, gguf_arch=a if a == "mistral3" else None,
+                          n_experts=md.get(f"{a}.expert_count", 0), n_experts_used=md.get(f"{a}.expert_used_count", 0),
+                          moe_hidden=g.tensors["blk.0.ffn_down_exps.weight"][0][0] if "blk.0.ffn_down_exps.weight" in g.tensors else 0)
         tensors = {}
         for name, (dims, ty, raw) in g.tensors.items():
-            rows = dims[1] if len(dims) > 1 else 1
+            rows = int(np.prod(dims[1:])) if len(dims) > 1 else 1
             tensors[name] = (raw, ty, rows, dims[0])
         m = SynthModel(cfg, g.tensors["token_embd.weight"][1], tensors)
         m._gguf = g
@@ -341,6 +375,8 @@ def make_numpy(cfg: ModelConfig, wtype: int = GGML_Q8_0, seed: int = 42, sigma: 
         w = rng.standard_normal((rows, cols), dtype=np.float32) * np.float32(sigma)
         if kind == "norm":
             w = w + np.float32(1.0)
+        if kind == "router":              # wider router rows: peaked, token-dependent expert choices
+            w = w * np.float32(5.0)
         tensors[name] = (encode(w, ty), ty, rows, cols)
     return SynthModel(cfg, wtype, tensors)
 
@@ -389,6 +425,8 @@ def iter_torch(cfg: ModelConfig, wtype: int = GGML_Q8_0, seed: int = 42, sigma: 
             w = torch.randn((r, cols), generator=g, device=device, dtype=torch.float32) * sigma
             if kind == "norm":
                 w = w + 1.0
+            if kind == "router":
+                w = w * 5.0
             if ty == GGML_F32:
                 b = w.contiguous().view(torch.uint8).reshape(-1)
             elif ty == GGML_F16:

@@ -62,7 +62,11 @@ typedef enum {
  * NeoX RoPE); QWEN2: forwardJavaQwen2 :434-563 (q/k/v bias, NeoX RoPE; Qwen2.5, DeepSeek-R1-Distill-Qwen). */
 enum { GL3_ARCH_LLAMA = 0, GL3_ARCH_QWEN3 = 1, GL3_ARCH_QWEN2 = 2,
        GL3_ARCH_GRANITE = 3, /* InferenceCore.forwardGranite :814-924: the Llama graph + embedding / attention / residual / logit scalars */
-       GL3_ARCH_PHI3 = 4     /* InferenceCore.forwardJavaPhi3 :699-800: fused attn_qkv and gate|up tensors (GL3_T_WQKV, GL3_T_W13), NeoX RoPE */ };
+       GL3_ARCH_PHI3 = 4,    /* InferenceCore.forwardJavaPhi3 :699-800: fused attn_qkv and gate|up tensors (GL3_T_WQKV, GL3_T_W13), NeoX RoPE */
+       GL3_ARCH_QWEN2MOE = 5 /* InferenceCore.forwardJavaQwen2MoE :263-422 (Qwen1.5-MoE / Qwen2-MoE): the Qwen2 attention; the FFN is an F32
+                              * router over n_experts (softmax over all, top n_experts_used by strict >, no renormalisation), the
+                              * selected experts' SwiGLU FFNs accumulated into x in selection order, then the always-on shared
+                              * expert scaled by sigmoid(ffn_gate_inp_shexp . xb).  Q8_0 matrices, one rank, max_batch <= 1. */ };
 
 /* ggml tensor types of the wire format (J/tensor/GGMLType.java:5-21) */
 enum { GL3_TYPE_F32 = 0, GL3_TYPE_F16 = 1, GL3_TYPE_Q4_0 = 2, GL3_TYPE_Q8_0 = 8,
@@ -90,7 +94,14 @@ enum {
     GL3_T_BV = 16,          /* blk.L.attn_v.bias        [kv_dim]       F32, qwen2 */
     GL3_T_WQKV = 17,        /* blk.L.attn_qkv.weight    [(qDim + 2 kvDim) x dim]  phi3: rows q | k | v (Phi3ModelLoader.java:112)          */
     GL3_T_W13 = 18,         /* blk.L.ffn_up.weight      [2 hidden x dim]          phi3: rows gate | up (forwardJavaPhi3 :778-780)          */
-    GL3_T_COUNT = 19
+    /* qwen2moe (Qwen2MoEModelLoader.java:97-105).  The shared expert's ffn_{gate,up,down}_shexp.weight are uploaded as
+     * GL3_T_W1 / GL3_T_W3 / GL3_T_W2 with gl3_model_desc.hidden = qwen2moe.feed_forward_length (sharedExpertHiddenDim). */
+    GL3_T_FFN_GATE_INP = 19,       /* blk.L.ffn_gate_inp.weight        [n_experts x dim]               F32 (router)            */
+    GL3_T_FFN_GATE_EXPS = 20,      /* blk.L.ffn_gate_exps.weight       [n_experts x moe_hidden x dim]  stacked routed experts  */
+    GL3_T_FFN_UP_EXPS = 21,        /* blk.L.ffn_up_exps.weight         [n_experts x moe_hidden x dim]                          */
+    GL3_T_FFN_DOWN_EXPS = 22,      /* blk.L.ffn_down_exps.weight       [n_experts x dim x moe_hidden]                          */
+    GL3_T_FFN_GATE_INP_SHEXP = 23, /* blk.L.ffn_gate_inp_shexp.weight  [dim]                           F32 (shared-expert gate) */
+    GL3_T_COUNT = 24
 };
 
 /* gl3_model_desc.flags */
@@ -131,6 +142,9 @@ typedef struct {
      * granite.logit_scale): x *= embedding_scale after the embedding lookup, score *= attention_scale (instead of / sqrt(head_size)),
      * block output *= residual_scale before the residual add, logits *= logit_scale */
     float embedding_scale, attention_scale, residual_scale, logit_scale;
+    /* GL3_ARCH_QWEN2MOE only (Qwen2MoEModelLoader.java:56-84: qwen2moe.expert_count, qwen2moe.expert_used_count, and the first
+     * dimension of blk.0.ffn_down_exps.weight); 0 for every other architecture */
+    int32_t n_experts, n_experts_used, moe_hidden;
 } gl3_model_desc;
 
 /* Per-kernel-class device time of one instrumented decode step (HIP events around every launch). */

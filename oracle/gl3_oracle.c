@@ -43,17 +43,28 @@ enum {
     ORC_T_FFN_NORM = 8, ORC_T_W1 = 9, ORC_T_W2 = 10, ORC_T_W3 = 11,
     ORC_T_ATTN_Q_NORM = 12, ORC_T_ATTN_K_NORM = 13,
     ORC_T_BQ = 14, ORC_T_BK = 15, ORC_T_BV = 16,       /* qwen2: blk.L.attn_{q,k,v}.bias, F32 */
-    ORC_T_COUNT = 17
+    ORC_T_WQKV = 17, ORC_T_W13 = 18,                   /* phi3 fused tensors: not used here (row views are handed over instead) */
+    /* qwen2moe (Qwen2MoEModelLoader.java:97-105): router, stacked routed experts, shared-expert gate; the shared expert's
+     * gate / up / down matrices are W1 / W3 / W2 with hidden = sharedExpertHiddenDim */
+    ORC_T_GATE_INP = 19,        /* blk.L.ffn_gate_inp.weight        [n_experts x dim]              F32 */
+    ORC_T_GATE_EXPS = 20,       /* blk.L.ffn_gate_exps.weight       [n_experts x moe_hidden x dim]     */
+    ORC_T_UP_EXPS = 21,         /* blk.L.ffn_up_exps.weight         [n_experts x moe_hidden x dim]     */
+    ORC_T_DOWN_EXPS = 22,       /* blk.L.ffn_down_exps.weight       [n_experts x dim x moe_hidden]     */
+    ORC_T_GATE_INP_SHEXP = 23,  /* blk.L.ffn_gate_inp_shexp.weight  [dim]                          F32 */
+    ORC_T_COUNT = 24
 };
 
 typedef struct {
     int32_t arch;       /* 0 = llama (InferenceCore.forwardJava), 1 = qwen3 (forwardJavaQwen3), 2 = qwen2 (forwardJavaQwen2),
                            3 = granite (forwardGranite :814-924: the llama graph + the four scalars below),
                            4 = phi3 (forwardJavaPhi3 :699-800: NeoX RoPE pairs, no bias, no per-head norm; the fused attn_qkv / gate|up
-                               tensors are handed to this oracle as row views wq | wk | wv and w1 | w3 of the same bytes) */
+                               tensors are handed to this oracle as row views wq | wk | wv and w1 | w3 of the same bytes),
+                           5 = qwen2moe (forwardJavaQwen2MoE :263-422: the qwen2 attention + router / top-k routed experts /
+                               gated shared expert instead of the dense FFN) */
     int32_t dim, hidden, n_layers, n_heads, n_kv_heads, head_size, vocab, ctx;
     float   rms_eps;
     float   embedding_scale, attention_scale, residual_scale, logit_scale;   /* granite only (GraniteLoader.java:55-58) */
+    int32_t n_experts, n_experts_used, moe_hidden;   /* qwen2moe only (Qwen2MoEModelLoader.java:56-84); hidden = sharedExpertHiddenDim */
 } orc_config;
 
 typedef struct { const void* p; int type; } orc_tensor;
@@ -70,6 +81,9 @@ typedef struct {
     float *key_cache, *value_cache;       /* [L][ctx][kvDim] */
     int8_t* aq; float* ascale;            /* hoisted activation quantisation scratch */
     int q_dim, kv_dim;
+    float *router, *hbe, *hbe2, *ytmp;    /* Qwen2MoEState.java:15-32: routerLogits, hbE, hbE2, yTmp */
+    int moe_sel[64]; float moe_w[64];     /* experts selected by the last layer of the last step and their routing weights (parity tap) */
+    float moe_shared_w;
 } orc_ctx;
 
 /* ---- Float.float16ToFloat / Float.floatToFloat16 (IEEE binary16, RNE) ---- */
@@ -336,6 +350,67 @@ static void attention(orc_ctx* o, int l, int pos) {
     }
 }
 
+/* dense SwiGLU on hb / hb2 — InferenceCore.java:155-158 (and :397-398, :408-409 of the MoE forward): exp in double */
+static void swiglu(float* hb, const float* hb2, int n) {
+    for (int i = 0; i < n; i++) {
+        float v = hb[i];
+        v = v / (float)(1.0 + exp(-(double)v));
+        hb[i] = v * hb2[i];
+    }
+}
+
+/* FloatTensor.matmul / InferenceCore.matmulExpert :430-432 on rows [row0, row0 + d0) of a stacked tensor: the same per-row dot */
+static void matmul_rows(orc_ctx* o, const orc_tensor* w, size_t row0, const float* x, float* out, int d0, int d1) {
+    orc_tensor sub = *w;
+    size_t rb = w->type == ORC_Q8_0 ? (size_t)(d1 / 32) * 34 : w->type == ORC_Q4_0 ? (size_t)(d1 / 32) * 18 : w->type == ORC_F16 ? (size_t)d1 * 2 : (size_t)d1 * 4;
+    sub.p = (const uint8_t*)w->p + row0 * rb;
+    matmul(o, &sub, x, out, d0, d1);
+}
+
+/* Router probabilities and expert selection — InferenceCore.java:374-390: softmaxInPlace over ALL experts, then top-k by
+ * repeated strict-> scans (the first index wins a tie); the selected probabilities are used as they are, not renormalised. */
+static void moe_route(float* router, int E, int topk, int* sel, float* w) {
+    softmax(router, E);
+    for (int i = 0; i < topk; i++) {
+        float best = -INFINITY; int index = -1;
+        for (int j = 0; j < E; j++) if (router[j] > best) { best = router[j]; index = j; }
+        sel[i] = index; w[i] = best;
+        router[index] = -INFINITY;
+    }
+}
+ORC_API void orc_moe_route(float* router_logits, int n_experts, int topk, int32_t* sel, float* w) {
+    int s[64];
+    moe_route(router_logits, n_experts, topk > 64 ? 64 : topk, s, w);
+    for (int i = 0; i < topk && i < 64; i++) sel[i] = s[i];
+}
+
+/* The MoE feed-forward block of forwardJavaQwen2MoE — InferenceCore.java:363-415.  o->xb holds rmsnorm(x) on entry. */
+static void moe_ffn(orc_ctx* o, int l) {
+    const orc_config* c = &o->c;
+    int dim = c->dim, E = c->n_experts, topk = c->n_experts_used, mh = c->moe_hidden;
+    /* router: routerGate[l].matmul(xb, routerLogits, E, dim) (:373) then softmaxInPlace over ALL experts (:374) */
+    matmul(o, &o->layer[ORC_T_GATE_INP][l], o->xb, o->router, E, dim);
+    moe_route(o->router, E, topk, o->moe_sel, o->moe_w);
+    /* routed experts in selection order, each accumulated into x with saxpy (:392-402) */
+    for (int j = 0; j < topk; j++) {
+        int e = o->moe_sel[j];
+        matmul_rows(o, &o->layer[ORC_T_GATE_EXPS][l], (size_t)e * mh, o->xb, o->hbe, mh, dim);
+        matmul_rows(o, &o->layer[ORC_T_UP_EXPS][l], (size_t)e * mh, o->xb, o->hbe2, mh, dim);
+        swiglu(o->hbe, o->hbe2, mh);
+        matmul_rows(o, &o->layer[ORC_T_DOWN_EXPS][l], (size_t)e * dim, o->hbe, o->ytmp, dim, mh);
+        for (int i = 0; i < dim; i++) o->x[i] = o->moe_w[j] * o->ytmp[i] + o->x[i];
+    }
+    /* the always-on shared expert (:405-410) gated by sigmoid(sharedGateInp . xb) (:413-415) */
+    matmul(o, &o->layer[ORC_T_W1][l], o->xb, o->hb, c->hidden, dim);
+    matmul(o, &o->layer[ORC_T_W3][l], o->xb, o->hb2, c->hidden, dim);
+    swiglu(o->hb, o->hb2, c->hidden);
+    matmul(o, &o->layer[ORC_T_W2][l], o->hb, o->ytmp, dim, c->hidden);
+    float gate_score = dot_scalar(&o->layer[ORC_T_GATE_INP_SHEXP][l], 0, o->xb, dim);
+    float sw = 1.f / (1.f + (float)exp(-(double)gate_score));
+    o->moe_shared_w = sw;
+    for (int i = 0; i < dim; i++) o->x[i] = sw * o->ytmp[i] + o->x[i];
+}
+
 /* One transformer step.  arch 0: InferenceCore.forwardJava :50-172;
  * arch 1: forwardJavaQwen3 :565-697; arch 2: forwardJavaQwen2 :434-563 (q/k/v bias
  * :456-459, NeoX RoPE :461-478, no per-head norm).  want_logits=0 reproduces the prefill
@@ -357,7 +432,7 @@ static void forward(orc_ctx* o, int token, int pos, int want_logits, float* laye
         matmul(o, &o->layer[ORC_T_WK][l], o->xb, o->k, kvd, dim);
         matmul(o, &o->layer[ORC_T_WV][l], o->xb, o->v, kvd, dim);
 
-        if (c->arch == 2) {
+        if (c->arch == 2 || c->arch == 5) {
             /* state.q.addInPlace(weights.q_bias[l]) ... — InferenceCore.java:456-459 */
             for (int i = 0; i < qd; i++) o->q[i] = o->q[i] + t_get(&o->layer[ORC_T_BQ][l], i);
             for (int i = 0; i < kvd; i++) o->k[i] = o->k[i] + t_get(&o->layer[ORC_T_BK][l], i);
@@ -410,6 +485,7 @@ static void forward(orc_ctx* o, int token, int pos, int want_logits, float* laye
         for (int i = 0; i < dim; i++) o->x[i] = o->x[i] + o->xb2[i];
 
         rmsnorm(o->xb, o->x, &o->layer[ORC_T_FFN_NORM][l], 0, dim, c->rms_eps);
+        if (c->arch == 5) { moe_ffn(o, l); if (layer_x) memcpy(layer_x + (size_t)l * dim, o->x, sizeof(float) * dim); continue; }
         matmul(o, &o->layer[ORC_T_W1][l], o->xb, o->hb, c->hidden, dim);
         matmul(o, &o->layer[ORC_T_W3][l], o->xb, o->hb2, c->hidden, dim);
         /* SwiGLU — InferenceCore.java:155-158: exp in double */
@@ -445,7 +521,11 @@ ORC_API orc_ctx* orc_create(const orc_config* cfg) {
     o->att = calloc((size_t)c->n_heads * c->ctx, 4); o->logits = calloc(c->vocab, 4);
     o->key_cache = calloc((size_t)c->n_layers * c->ctx * o->kv_dim, 4);
     o->value_cache = calloc((size_t)c->n_layers * c->ctx * o->kv_dim, 4);
+    if (c->moe_hidden > maxk) maxk = c->moe_hidden;
     o->aq = malloc(maxk); o->ascale = malloc(sizeof(float) * (maxk / 32 + 1));
+    if (c->arch == 5) {
+        o->router = calloc(c->n_experts, 4); o->hbe = calloc(c->moe_hidden, 4); o->hbe2 = calloc(c->moe_hidden, 4); o->ytmp = calloc(c->dim, 4);
+    }
     return o;
 }
 
@@ -454,6 +534,7 @@ ORC_API void orc_destroy(orc_ctx* o) {
     for (int i = 0; i < ORC_T_COUNT; i++) free(o->layer[i]);
     free(o->x); free(o->xb); free(o->xb2); free(o->q); free(o->k); free(o->v); free(o->hb); free(o->hb2);
     free(o->att); free(o->logits); free(o->key_cache); free(o->value_cache); free(o->aq); free(o->ascale);
+    free(o->router); free(o->hbe); free(o->hbe2); free(o->ytmp);
     free(o);
 }
 
@@ -474,6 +555,12 @@ ORC_API void orc_forward(orc_ctx* o, int token, int pos, float* logits_out, floa
 
 ORC_API void orc_prefill(orc_ctx* o, const int32_t* tokens, int n, int start_pos) {
     for (int b = 0; b < n; b++) forward(o, tokens[b], start_pos + b, 0, NULL);
+}
+
+/* routing decision of the last layer of the last step: expert ids, their weights, the shared expert's gate */
+ORC_API void orc_get_moe_routing(orc_ctx* o, int32_t* sel, float* w, float* shared_w) {
+    for (int i = 0; i < o->c.n_experts_used; i++) { if (sel) sel[i] = o->moe_sel[i]; if (w) w[i] = o->moe_w[i]; }
+    if (shared_w) *shared_w = o->moe_shared_w;
 }
 
 ORC_API void orc_get_x(orc_ctx* o, float* out) { memcpy(out, o->x, sizeof(float) * o->c.dim); }

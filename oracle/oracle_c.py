@@ -17,14 +17,18 @@ _SO = os.environ.get("GL3_ORACLE_LIB") or os.path.join(_DIR, "libgl3_oracle.so")
 T_IDS = {"token_embd.weight": 0, "output_norm.weight": 1, "output.weight": 2, "attn_norm.weight": 3,
          "attn_q.weight": 4, "attn_k.weight": 5, "attn_v.weight": 6, "attn_output.weight": 7,
          "ffn_norm.weight": 8, "ffn_gate.weight": 9, "ffn_down.weight": 10, "ffn_up.weight": 11,
-         "attn_q_norm.weight": 12, "attn_k_norm.weight": 13, "attn_q.bias": 14, "attn_k.bias": 15, "attn_v.bias": 16}
+         "attn_q_norm.weight": 12, "attn_k_norm.weight": 13, "attn_q.bias": 14, "attn_k.bias": 15, "attn_v.bias": 16,
+         # qwen2moe (Qwen2MoEModelLoader.java:97-105); the shared expert's matrices take the dense FFN slots
+         "ffn_gate_inp.weight": 19, "ffn_gate_exps.weight": 20, "ffn_up_exps.weight": 21, "ffn_down_exps.weight": 22,
+         "ffn_gate_inp_shexp.weight": 23, "ffn_gate_shexp.weight": 9, "ffn_down_shexp.weight": 10, "ffn_up_shexp.weight": 11}
 
 
 class OrcConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("arch", "dim", "hidden", "n_layers", "n_heads", "n_kv_heads",
                                           "head_size", "vocab", "ctx")] + [("rms_eps", C.c_float), ("embedding_scale", C.c_float),
                                                                            ("attention_scale", C.c_float), ("residual_scale", C.c_float),
-                                                                           ("logit_scale", C.c_float)]
+                                                                           ("logit_scale", C.c_float)] + \
+               [(n, C.c_int32) for n in ("n_experts", "n_experts_used", "moe_hidden")]
 
 
 def build(force: bool = False):
@@ -48,6 +52,8 @@ def lib():
         _MAX_THREADS[0] = L.orc_num_threads()
         L.orc_create.argtypes = [C.POINTER(OrcConfig)]
         L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_get_moe_routing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_get_moe_routing.restype = None
         L.orc_set_tensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_set_rope.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -96,7 +102,7 @@ class COracle:
         self.cfg = c
         oc = OrcConfig(c.arch, c.dim, c.hidden, c.n_layers, c.n_heads, c.n_kv_heads, c.head_size, c.vocab, c.ctx, c.rms_eps,
                        getattr(c, "embedding_scale", 1.0), getattr(c, "attention_scale", 0.0), getattr(c, "residual_scale", 1.0),
-                       getattr(c, "logit_scale", 1.0))
+                       getattr(c, "logit_scale", 1.0), getattr(c, "n_experts", 0), getattr(c, "n_experts_used", 0), getattr(c, "moe_hidden", 0))
         self._h = L.orc_create(C.byref(oc))
         assert L.orc_set_vector_bits(self._h, vector_bits) == 0
         L.orc_set_f32_activation(self._h, 1 if f32_activation else 0)
@@ -137,6 +143,13 @@ class COracle:
         self._pool()
         t = np.ascontiguousarray(tokens, np.int32)
         lib().orc_prefill(self._h, _p(t), len(t), start_pos)
+
+    def moe_routing(self):
+        """(expert ids, routing weights, shared-expert gate) of the last layer of the last step."""
+        k = self.cfg.n_experts_used
+        sel, w, sw = np.empty(k, np.int32), np.empty(k, np.float32), C.c_float()
+        lib().orc_get_moe_routing(self._h, _p(sel), _p(w), C.byref(sw))
+        return sel, w, np.float32(sw.value)
 
     def x(self):
         out = np.empty(self.cfg.dim, np.float32)

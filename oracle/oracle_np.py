@@ -233,6 +233,41 @@ class NpOracle:
         raw, ty = self.t[name]
         return dequant(raw, ty, n)
 
+    def _mm_rows(self, name, row0, x, d0, d1):
+        """InferenceCore.matmulExpert :430-432: rows [row0, row0 + d0) of a stacked [E x d0 x d1] tensor, the same per-row dot."""
+        raw, ty = self.t[name]
+        bs, ts = BLOCK[ty]
+        rb = d1 // bs * ts
+        sub = raw.view(np.uint8).reshape(-1)[row0 * rb:(row0 + d0) * rb]
+        if self.vector_bits == 256 and (ty in (GGML_F16, GGML_Q4_0) or (ty == GGML_Q8_0 and self.f32_activation)):
+            return matmul_v256(sub, ty, x, d0, d1)
+        return matmul(sub, ty, x, d0, d1)
+
+    def _moe_ffn(self, p, x, xb):
+        """The MoE block of forwardJavaQwen2MoE (InferenceCore.java:363-415); xb = rmsnorm(x) on entry, returns the new x."""
+        c = self.c
+        dim, E, topk, mh, sh = c["dim"], c["n_experts"], c["n_experts_used"], c["moe_hidden"], c["hidden"]
+        probs = softmax(self._mm(p + "ffn_gate_inp.weight", xb, E, dim))        # :373-374, over all experts
+        sel, wts = [], []
+        for _ in range(topk):                                                     # :376-390: strict >, first index wins, no renormalisation
+            idx = int(np.argmax(probs))
+            sel.append(idx)
+            wts.append(F32(probs[idx]))
+            probs[idx] = -np.inf
+        silu = lambda h: (h / (1.0 + np.exp(-h.astype(np.float64))).astype(F32)).astype(F32)
+        for e, w in zip(sel, wts):                                                # :392-402
+            hb = self._mm_rows(p + "ffn_gate_exps.weight", e * mh, xb, mh, dim)
+            hb2 = self._mm_rows(p + "ffn_up_exps.weight", e * mh, xb, mh, dim)
+            y = self._mm_rows(p + "ffn_down_exps.weight", e * dim, (silu(hb) * hb2).astype(F32), dim, mh)
+            x = ((w * y).astype(F32) + x).astype(F32)                             # saxpyInPlace: a * that + this, two roundings
+        hb = self._mm(p + "ffn_gate_shexp.weight", xb, sh, dim)                   # :405-410
+        hb2 = self._mm(p + "ffn_up_shexp.weight", xb, sh, dim)
+        y = self._mm(p + "ffn_down_shexp.weight", (silu(hb) * hb2).astype(F32), dim, sh)
+        gate = seq_sum(self._f32(p + "ffn_gate_inp_shexp.weight", dim) * xb)      # :413 FP32FloatTensor.dot = scalarDot
+        sw = F32(1.0) / (F32(1.0) + F32(np.exp(-np.float64(gate))))               # :414
+        self.moe_sel, self.moe_w, self.moe_shared_w = sel, wts, F32(sw)
+        return ((F32(sw) * y).astype(F32) + x).astype(F32)
+
     def forward(self, token: int, pos: int, want_logits: bool = True, layer_x: list | None = None):
         c = self.c
         dim, hs, kvd, qd, hid = c["dim"], c["head_size"], self.kv_dim, self.q_dim, c["hidden"]
@@ -255,7 +290,7 @@ class NpOracle:
             q = self._mm(p + "attn_q.weight", xb, qd, dim)
             k = self._mm(p + "attn_k.weight", xb, kvd, dim)
             v = self._mm(p + "attn_v.weight", xb, kvd, dim)
-            if c["arch"] == 2:   # qwen2: q/k/v bias, InferenceCore.java:456-459
+            if c["arch"] in (2, 5):   # qwen2 (and qwen2moe :289-291): q/k/v bias, InferenceCore.java:456-459
                 q = q + self._f32(p + "attn_q.bias", qd)
                 k = k + self._f32(p + "attn_k.bias", kvd)
                 v = v + self._f32(p + "attn_v.bias", kvd)
@@ -297,6 +332,11 @@ class NpOracle:
             ao = self._mm(p + "attn_output.weight", xb, dim, qd)
             x = x + ((ao * F32(c["residual_scale"])).astype(F32) if granite else ao)
             xb = rmsnorm(x, self._f32(p + "ffn_norm.weight", dim), eps)
+            if c["arch"] == 5:
+                x = self._moe_ffn(p, x, xb)
+                if layer_x is not None:
+                    layer_x.append(x.copy())
+                continue
             hb = self._mm(p + "ffn_gate.weight", xb, hid, dim)
             hb2 = self._mm(p + "ffn_up.weight", xb, hid, dim)
             sig = (1.0 + np.exp(-hb.astype(np.float64))).astype(F32)   # (float)(1.0 + Math.exp(-value))

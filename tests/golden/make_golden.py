@@ -27,6 +27,7 @@ CASES = [  # (fixture, config, ggml type, seed, prompt tokens, greedy steps, vec
     ("tiny_granite_q8_0", "tiny-granite", 8, 19, 5, 12, 0),          # forwardGranite: llama graph + embedding / attention / residual / logit scalars
     ("tiny_phi3_q8_0", "tiny-phi3", 8, 23, 5, 12, 0),                # forwardJavaPhi3: fused attn_qkv / gate|up, NeoX RoPE
     ("tiny_devstral_q8_0", "tiny-devstral", 8, 29, 5, 12, 0),        # forwardJavaDevstral: head_size != dim / heads, YaRN table
+    ("tiny_qwen2moe_q8_0", "tiny-qwen2moe", 8, 31, 5, 12, 0),        # forwardJavaQwen2MoE: router / top-2 of 8 experts / gated shared expert
     ("tiny_llama_f16_v256", "tiny-llama", 1, 7, 4, 8, 256),          # Vector-API dots, 256-bit species (the reference's default order)
     ("tiny_llama_tied_q4_0_v256", "tiny-llama-tied", 2, 11, 4, 8, 256),
     # Q8_0 weights with vector bits 256 = -Dllama.quantizeActivation=false: Q8_0FloatTensor.vectorDot on the f32 activation

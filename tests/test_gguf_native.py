@@ -142,6 +142,38 @@ def test_devstral_gguf_metadata_round_trip(pkg, hip, tmp_path):
         L.gl3_gguf_close(g)
 
 
+def test_qwen2moe_gguf_metadata_round_trip(pkg, hip, tmp_path):
+    """A "qwen2moe" file (Qwen2MoEModelLoader.java:56-110): expert counts from the metadata, the experts' hidden size from the first
+    dimension of the 3-D blk.0.ffn_down_exps.weight, the shared expert's from feed_forward_length; stacked experts are 3-D tensors."""
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-qwen2moe"], seed=3)
+    path = str(tmp_path / "moe.gguf")
+    m.write_gguf(path)
+    L = hip.lib()
+    g = C.c_void_p()
+    hip.check_gguf(L.gl3_gguf_open(path.encode(), C.byref(g)))
+    try:
+        d = hip.ModelDesc()
+        hip.check_gguf(L.gl3_gguf_model_desc(g, C.byref(d), None), g)
+        c = m.cfg
+        assert (d.arch, d.dim, d.hidden, d.n_experts, d.n_experts_used, d.moe_hidden) == (5, c.dim, c.hidden, c.n_experts, c.n_experts_used, c.moe_hidden)
+        dims = {}
+        for i in range(L.gl3_gguf_tensor_count(g)):
+            name, ty, ne = C.c_char_p(), C.c_int32(), (C.c_uint64 * 4)()
+            assert L.gl3_gguf_tensor_info(g, i, C.byref(name), C.byref(ty), ne, None, None) == 0
+            dims[name.value.decode()] = (ty.value, list(ne))
+        assert dims["blk.0.ffn_gate_exps.weight"] == (8, [c.dim, c.moe_hidden, c.n_experts, 1])
+        assert dims["blk.1.ffn_down_exps.weight"] == (8, [c.moe_hidden, c.dim, c.n_experts, 1])
+        assert dims["blk.0.ffn_gate_inp.weight"] == (0, [c.dim, c.n_experts, 1, 1])
+        assert dims["blk.0.ffn_gate_inp_shexp.weight"][0] == 0
+    finally:
+        L.gl3_gguf_close(g)
+    back = pkg.synth.SynthModel.from_gguf(path)
+    assert (back.cfg.arch, back.cfg.n_experts, back.cfg.n_experts_used, back.cfg.moe_hidden, back.cfg.hidden) == (5, c.n_experts, c.n_experts_used, c.moe_hidden, c.hidden)
+    for name, (raw, ty, rows, cols) in m.tensors.items():
+        r2, t2, rows2, cols2 = back.tensors[name]
+        assert (t2, rows2, cols2) == (ty, rows, cols) and np.array_equal(np.asarray(r2).view(np.uint8).reshape(-1), raw.view(np.uint8).reshape(-1)), name
+
+
 def test_reader_rejects_bad_files(hip, tmp_path):
     L = hip.lib()
     g = C.c_void_p()

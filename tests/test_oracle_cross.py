@@ -11,7 +11,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = [("tiny_llama_q8_0", "tiny-llama", 8, 7, 0), ("tiny_llama_f16", "tiny-llama", 1, 7, 0),
          ("tiny_llama_tied_q4_0", "tiny-llama-tied", 2, 11, 0), ("tiny_qwen3_q8_0", "tiny-qwen3", 8, 5, 0),
          ("tiny_qwen2_q8_0", "tiny-qwen2", 8, 13, 0), ("tiny_granite_q8_0", "tiny-granite", 8, 19, 0), ("tiny_phi3_q8_0", "tiny-phi3", 8, 23, 0),
-         ("tiny_devstral_q8_0", "tiny-devstral", 8, 29, 0),
+         ("tiny_devstral_q8_0", "tiny-devstral", 8, 29, 0), ("tiny_qwen2moe_q8_0", "tiny-qwen2moe", 8, 31, 0),
          # Vector-API dot order (256-bit species) for F16 / Q4_0 matrices: FP16FloatTensor.vectorDot / Q4_0FloatTensor.vectorDot
          ("tiny_llama_f16_v256", "tiny-llama", 1, 7, 256), ("tiny_llama_tied_q4_0_v256", "tiny-llama-tied", 2, 11, 256),
          # Q8_0 + 256 = -Dllama.quantizeActivation=false: Q8_0FloatTensor.vectorDot on the f32 activation (SURVEY 8 a4')
@@ -40,12 +40,59 @@ def test_c_oracle_matches_golden_bitwise(pkg, orc, fx, cfg, wt, seed, vbits):
 def test_numpy_and_c_agree_on_fresh_seed(pkg, orc):
     # qwen2: q/k/v bias + NeoX RoPE; mha-llama: n_heads == n_kv_heads (kvMul = 1), head_size 128
     for cfg, wt in [("tiny-llama-tied", 8), ("tiny-qwen3", 1), ("tiny-qwen2", 8), ("tiny-qwen2", 2), ("mha-llama", 8), ("tiny-granite", 8), ("tiny-granite", 1), ("tiny-phi3", 8), ("tiny-phi3", 2),
-                    ("tiny-devstral", 8), ("tiny-devstral", 1)]:       # devstral: q_dim 512 on dim 256, YaRN table
+                    ("tiny-devstral", 8), ("tiny-devstral", 1),        # devstral: q_dim 512 on dim 256, YaRN table
+                    ("tiny-qwen2moe", 8), ("tiny-qwen2moe", 1)]:       # qwen2moe: F32 router, top-2 of 8 experts, gated shared expert
         m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wt, seed=1234)
         co = orc.COracle(m)
         no = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope)
         for pos, t in enumerate(pkg.javarand.bench_tokens(m.cfg.vocab, 4, seed=9)):
             assert np.array_equal(co.forward(t, pos), no.forward(t, pos))
+
+
+def test_moe_routing_known_answers(orc):
+    """InferenceCore.java:374-390 on hand-made router logits: the weights are the softmax over ALL experts (not renormalised over
+    the chosen ones), selection is by strict > so the lowest index wins a tie, and the order is by descending probability."""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_moe_route.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_moe_route.restype = None
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def route(logits, k):
+        lg = np.array(logits, np.float32)
+        sel, w = np.empty(k, np.int32), np.empty(k, np.float32)
+        L.orc_moe_route(p(lg), lg.size, k, p(sel), p(w))
+        return sel.tolist(), w
+    # four equal logits: probabilities exactly 0.25 each, picked in index order
+    sel, w = route([1.5, 1.5, 1.5, 1.5], 3)
+    assert sel == [0, 1, 2] and w.tolist() == [0.25, 0.25, 0.25]
+    # a tie between experts 1 and 3 for the top place: 1 first, then 3; weights sum to less than one
+    sel, w = route([0.0, 2.0, -1.0, 2.0, 1.0], 2)
+    assert sel == [1, 3] and w[0] == w[1] and 0.7 < float(w.sum()) < 0.8
+    e = np.exp(np.array([0.0, 2.0, -1.0, 2.0, 1.0], np.float32).astype(np.float64) - 2.0).astype(np.float32)
+    s = np.float32(0)
+    for v in e:
+        s = np.float32(s + v)                       # sequential f32 sum, FloatTensor.sum
+    assert w[0] == np.float32(e[1] / s)
+    # top-k = all experts: a full descending ordering with the softmax itself as weights
+    sel, w = route([0.1, -0.3, 0.7, 0.2], 4)
+    assert sel == [2, 3, 0, 1] and abs(float(w.sum()) - 1.0) < 1e-6 and all(w[i] > w[i + 1] for i in range(3))
+
+
+def test_moe_block_structure(pkg, orc):
+    """The MoE layer of the C oracle against an explicit NumPy composition of its parts for one token of tiny-qwen2moe: x_out =
+    x + sum_j w_j * expert_j(xb) + sigmoid(g . xb) * shared(xb) accumulated in selection order (saxpy), each expert a SwiGLU FFN
+    on the Q8_0 dot of the reference."""
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-qwen2moe"], seed=77)
+    co = orc.COracle(m)
+    no = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope)
+    for pos, t in enumerate(pkg.javarand.bench_tokens(m.cfg.vocab, 5, seed=3)):
+        a, b = co.forward(t, pos), no.forward(t, pos)
+        assert np.array_equal(a, b)
+        sel, w, sw = co.moe_routing()
+        assert sel.tolist() == no.moe_sel and np.array_equal(w, np.array(no.moe_w, np.float32)) and sw == no.moe_shared_w
+        assert len(set(sel.tolist())) == m.cfg.n_experts_used and w[0] >= w[1] and 0.0 < float(sw) < 1.0
+        assert float(w.sum()) < 1.0                                               # not renormalised over the selected experts
 
 
 def test_vector_api_dot_order_numpy_and_c_agree_and_stay_close_to_scalar(pkg, orc):

@@ -117,7 +117,8 @@ int main(int argc, char** argv) {
     gl3_gguf* g = nullptr;
     gl3_model_desc d{};
     if (gl3_gguf_open(path.c_str(), &g) != GL3_OK || gl3_gguf_model_desc(g, &d, nullptr) != GL3_OK) { fprintf(stderr, "cannot read %s: %s\n", path.c_str(), gl3_gguf_last_error(g)); return 1; }
-    if (protocol.empty()) protocol = d.arch == GL3_ARCH_QWEN3 ? "qwen3" : "llama";
+    // Qwen2.java:115, Qwen2MoE.java:98, Qwen3.java:98 all run generateTokensGPUQwen3; Llama / Mistral / Devstral generateTokensGPULlama
+    if (protocol.empty()) protocol = (d.arch == GL3_ARCH_QWEN3 || d.arch == GL3_ARCH_QWEN2 || d.arch == GL3_ARCH_QWEN2MOE) ? "qwen3" : "llama";
     if (protocol != "llama" && protocol != "qwen3") { fprintf(stderr, "gl3_run: --protocol llama|qwen3\n"); return 2; }
     if (bos < 0) {
         double v = 0;
