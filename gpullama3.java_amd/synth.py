@@ -97,6 +97,9 @@ CONFIGS = {
     # Qwen1.5-MoE shape (forwardJavaQwen2MoE): qwen2 attention + F32 router over n_experts, top-k routed experts, gated shared
     # expert.  mid: 60 experts / top-4 as Qwen1.5-MoE-A2.7B with narrow experts; a2.7b-moe-layer: one layer at the model's own
     # sizes (dim 2048, 16 / 16 heads of 128, experts 1408, shared expert 5632)
+    # Qwen1.5-MoE-A2.7B (14.3 B parameters, 2.7 B active per token): 24 layers, 60 routed experts of 1408, top-4, shared expert 5632
+    "qwen1.5-moe-a2.7b": ModelConfig("Qwen1.5-MoE-A2.7B-random", ARCH_QWEN2MOE, 2048, 5632, 24, 16, 16, 128, 151936, 648, 1e-6, 1000000.0,
+                                      False, n_experts=60, n_experts_used=4, moe_hidden=1408),
     "tiny-qwen2moe": ModelConfig("tiny-qwen2moe-random", ARCH_QWEN2MOE, 256, 512, 2, 8, 2, 32, 512, 64, 1e-6, 1000000.0, False,
                                   n_experts=8, n_experts_used=2, moe_hidden=128),
     "mid-qwen2moe": ModelConfig("mid-qwen2moe-random", ARCH_QWEN2MOE, 2048, 1536, 2, 16, 16, 128, 2048, 160, 1e-6, 1000000.0, False,
