@@ -160,8 +160,9 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
 
 // Routed experts of a Qwen2-MoE layer: one launch, blockIdx.y = slot of the top-k selection (matvec_q8t_kernel<.., SEL>).
 // stack holds n_experts sub-matrices of `rows` rows each; x / out advance by x_slot / out_slot floats per slot.
-static void launch_matvec_sel(gl3_ctx* ctx, int pro, int epi, const Q8Mat& stack, const Q8Mat* stack2, int rows, const float* x,
-                              const float* norm_w, float* out, int x_slot, int out_slot) {
+// which: record of this layer (0 = gate/up with the shared expert's chunks as extra slots, 1 = gate/up alone, 2 = down).
+static void launch_matvec_sel(gl3_ctx* ctx, int layer, int which, const Q8Mat& stack, const Q8Mat* stack2, int rows, const float* x,
+                              const float* norm_w, float* out, int shared_rows) {
     const gl3_model_desc& d = ctx->d;
     static const int max_wgs = getenv("GL3_WGS") ? atoi(getenv("GL3_WGS")) : 512;
     Q8Mat sub = stack;
@@ -169,12 +170,35 @@ static void launch_matvec_sel(gl3_ctx* ctx, int pro, int epi, const Q8Mat& stack
     MatvecArgs a{};
     a.w = stack.w; a.w2 = stack2 ? stack2->w : nullptr; a.rows = rows; a.k = stack.k; a.ng = stack.ng; a.nstrips = sub.nstrips;
     a.x = x; a.norm_w = norm_w; a.eps = d.rms_eps; a.out = out; a.resid_in = nullptr; a.out_scale = 1.0f;
-    a.sel = ctx->moe_sel; a.sel_stride = (size_t)sub.nstrips * stack.ng * TILE_BYTES; a.x_slot_stride = x_slot; a.out_slot_stride = out_slot;
+    a.moe = reinterpret_cast<const MoeSlots*>(ctx->moe_slots) + (size_t)layer * 3 + which;
+    const int slots = d.n_experts_used + (which == 0 ? (shared_rows + rows - 1) / rows : 0);
     const int wgs = sub.nstrips < max_wgs ? sub.nstrips : max_wgs;
-    const size_t smem = matvec_smem(pro, epi, sub);
-    const dim3 grid(wgs, d.n_experts_used);
-    if (pro == PRO_RMS) hipLaunchKernelGGL((matvec_q8t_kernel<PRO_RMS, EPI_SWIGLU, true, 4, true>), grid, dim3(mv_threads(4)), smem, ctx->stream, a);
-    else hipLaunchKernelGGL((matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 4, true>), grid, dim3(mv_threads(4)), smem, ctx->stream, a);
+    const dim3 grid(wgs, slots);
+    if (which != 2) hipLaunchKernelGGL((matvec_q8t_kernel<PRO_RMS, EPI_SWIGLU, true, 4, true>), grid, dim3(mv_threads(4)), matvec_smem(PRO_RMS, EPI_SWIGLU, sub), ctx->stream, a);
+    else hipLaunchKernelGGL((matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 4, true>), grid, dim3(mv_threads(4)), matvec_smem(PRO_QUANT, EPI_RESID, sub), ctx->stream, a);
+}
+
+// The slot records of every layer's two routed-expert launches (MoeSlots, gl3_decode_kernels.h); pointers are final after gl3_create.
+static int32_t moe_build_slots(gl3_ctx* ctx) {
+    const gl3_model_desc& d = ctx->d;
+    std::vector<MoeSlots> h((size_t)d.n_layers * 3);
+    for (int l = 0; l < d.n_layers; ++l) {
+        const gl3_layer& L = ctx->layers[l];
+        MoeSlots gu{};
+        gu.sel = ctx->moe_sel; gu.sel_stride = (size_t)(d.moe_hidden / 16) * L.gate_exps.ng * TILE_BYTES;
+        gu.x_slot_stride = 0; gu.out_slot_stride = d.moe_hidden; gu.n_sel = d.n_experts_used;
+        gu.sh_rows = L.w1.rows; gu.sh_w = L.w1.w; gu.sh_w2 = L.w3.w; gu.sh_out = ctx->hb;
+        h[(size_t)l * 3 + 0] = gu;
+        gu.sh_rows = 0; gu.sh_w = gu.sh_w2 = nullptr; gu.sh_out = nullptr;
+        h[(size_t)l * 3 + 1] = gu;
+        MoeSlots dn{};
+        dn.sel = ctx->moe_sel; dn.sel_stride = (size_t)(d.dim / 16) * L.down_exps.ng * TILE_BYTES;
+        dn.x_slot_stride = d.moe_hidden; dn.out_slot_stride = d.dim; dn.n_sel = d.n_experts_used;
+        h[(size_t)l * 3 + 2] = dn;
+    }
+    GL3_HIP(hipMalloc(&ctx->moe_slots, h.size() * sizeof(MoeSlots)));
+    GL3_HIP(hipMemcpy(ctx->moe_slots, h.data(), h.size() * sizeof(MoeSlots), hipMemcpyHostToDevice));
+    return GL3_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ decode step
@@ -214,27 +238,33 @@ static uint64_t mv_bytes(const Q8Mat& w) { return w.algo_bytes() + (uint64_t)w.k
 // The MoE feed-forward block of one decode step — InferenceCore.forwardJavaQwen2MoE :363-415 (kernels: gl3_moe_kernels.h).
 // x is read by every projection (each normalises it in its own prologue) and only rewritten by the final combine launch, so the
 // order of the launches in between is free; the accumulation order into x is the reference's (selection order, then shared).
-static void enqueue_moe_ffn(gl3_ctx* ctx, gl3_layer& L, Prof& pr) {
+static void enqueue_moe_ffn(gl3_ctx* ctx, int l, Prof& pr) {
+    gl3_layer& L = ctx->layers[l];
     const gl3_model_desc& d = ctx->d;
     hipStream_t s = ctx->stream;
     const int E = d.n_experts, topk = d.n_experts_used, mh = d.moe_hidden;
     const uint64_t row34 = (uint64_t)(d.dim / 32) * 34;
+    // GL3_MOE_MERGE_SHARED=0: the shared expert's gate/up as its own launch instead of extra slots of the routed experts' launch
+    static const bool merge_shared = env_flag("GL3_MOE_MERGE_SHARED", true);
     pr.begin(GL3_K_OTHER, (uint64_t)(E + 1) * d.dim * 4 + d.dim * 8);
     {   Gl3Range g("moe: rmsnorm + router + top-k");
-        const size_t sm = (size_t)(d.dim + 32) * 4 + ss_scratch_bytes(d.dim) + 64;
-        hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3(1), dim3(256), sm, s, ctx->x, d.dim, L.ffn_norm, d.rms_eps, ctx->xn);
-        hipLaunchKernelGGL(moe_router_kernel, dim3(E + 1), dim3(256), (size_t)d.dim * 4, s, L.gate_inp, L.gate_inp_shexp, ctx->xn, d.dim, E, topk,
-                           ctx->moe_logits, ctx->moe_w);
-        hipLaunchKernelGGL(moe_select_kernel, dim3(1), dim3(64), (size_t)(E + 4) * 4, s, ctx->moe_logits, E, topk, ctx->moe_sel, ctx->moe_w); }
+        MoeRouterArgs ra{};
+        ra.x = ctx->x; ra.norm_w = L.ffn_norm; ra.eps = d.rms_eps; ra.gate_inp = L.gate_inp; ra.gate_inp_shexp = L.gate_inp_shexp;
+        ra.dim = d.dim; ra.n_experts = E; ra.topk = topk; ra.logits = ctx->moe_logits; ra.w_out = ctx->moe_w; ra.sel = ctx->moe_sel;
+        ra.ticket = ctx->moe_sel + topk;
+        hipLaunchKernelGGL(moe_router_kernel, dim3(moe_router_wgs(E)), dim3(256), moe_router_smem(d.dim, E), s, ra); }
     pr.end();
     pr.begin(GL3_K_MATVEC_GATEUP, (uint64_t)2 * topk * mh * row34 + mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4);
     {   Gl3Range g("moe: expert + shared gate/up + swiglu");
-        launch_matvec_sel(ctx, PRO_RMS, EPI_SWIGLU, L.gate_exps, &L.up_exps, mh, ctx->x, L.ffn_norm, ctx->moe_hb, 0, mh);
-        launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb, nullptr); }
+        if (merge_shared) launch_matvec_sel(ctx, l, 0, L.gate_exps, &L.up_exps, mh, ctx->x, L.ffn_norm, ctx->moe_hb, L.w1.rows);
+        else {
+            launch_matvec_sel(ctx, l, 1, L.gate_exps, &L.up_exps, mh, ctx->x, L.ffn_norm, ctx->moe_hb, 0);
+            launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb, nullptr);
+        } }
     pr.end();
     pr.begin(GL3_K_MATVEC_DOWN, (uint64_t)topk * d.dim * (mh / 32) * 34 + mv_bytes(L.w2));
     {   Gl3Range g("moe: expert + shared down");
-        launch_matvec_sel(ctx, PRO_QUANT, EPI_RESID, L.down_exps, nullptr, d.dim, ctx->moe_hb, nullptr, ctx->moe_y, mh, d.dim);
+        launch_matvec_sel(ctx, l, 2, L.down_exps, nullptr, d.dim, ctx->moe_hb, nullptr, ctx->moe_y, 0);
         launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->moe_y + (size_t)topk * d.dim, nullptr); }
     pr.end();
     pr.begin(GL3_K_OTHER, (uint64_t)(topk + 3) * d.dim * 4);
@@ -315,7 +345,7 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         if (!ctx->wo_replicated && (r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
 
         if (d.arch == GL3_ARCH_QWEN2MOE) {
-            enqueue_moe_ffn(ctx, L, pr);
+            enqueue_moe_ffn(ctx, l, pr);
             if (ctx->taps) hipMemcpyAsync(ctx->taps + (size_t)l * d.dim, ctx->x, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, s);
             continue;
         }
@@ -407,7 +437,9 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
         if (d.weight_type != GL3_TYPE_Q8_0 || (d.flags & GL3_FLAG_F32_ACTIVATION))
             return bail(GL3_E_UNSUPPORTED, "qwen2moe: Q8_0 matrices with the int8 activation only");
         if (d.tp_size > 1 || (d.flags & GL3_FLAG_FORCE_RCCL)) return bail(GL3_E_UNSUPPORTED, "qwen2moe: tensor parallelism is not built");
-        if (d.max_batch > 1 || d.n_seqs > 1) return bail(GL3_E_UNSUPPORTED, "qwen2moe: batched prefill / static-batched decode are not built (max_batch <= 1, n_seqs <= 1)");
+        // max_batch > 1 is accepted: a prefill chunk then runs token by token, as the reference prefills this family (and as the
+        // scalar-dot plans do); there are no batched buffers, so static-batched decode is refused
+        if (d.n_seqs > 1) return bail(GL3_E_UNSUPPORTED, "qwen2moe: static-batched decode is not built (n_seqs <= 1)");
         if (d.n_experts < 1 || d.n_experts > 4096 || d.n_experts_used < 1 || d.n_experts_used > d.n_experts || d.n_experts_used > 64)
             return bail(GL3_E_ARG, "qwen2moe: need 1 <= n_experts_used <= min(n_experts, 64), n_experts <= 4096");
         if (d.moe_hidden < 32 || d.moe_hidden % 32) return bail(GL3_E_ARG, "qwen2moe: moe_hidden must be a positive multiple of 32");
@@ -498,10 +530,10 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     if (moe) {
         TRY(dmalloc(ctx, &ctx->moe_logits, d.n_experts));
         TRY(dmalloc(ctx, &ctx->moe_w, d.n_experts_used + 1));
-        TRY(dmalloc(ctx, &ctx->moe_sel, d.n_experts_used));
+        TRY(dmalloc(ctx, &ctx->moe_sel, d.n_experts_used + 1));          // + the router kernel's arrival ticket
         TRY(dmalloc(ctx, &ctx->moe_hb, (size_t)d.n_experts_used * d.moe_hidden));
         TRY(dmalloc(ctx, &ctx->moe_y, (size_t)(d.n_experts_used + 1) * d.dim));
-        TRYHIP(hipMemset(ctx->moe_sel, 0, sizeof(int) * d.n_experts_used));
+        TRYHIP(hipMemset(ctx->moe_sel, 0, sizeof(int) * (d.n_experts_used + 1)));
         TRYHIP(hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO_RMS, EPI_SWIGLU, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         TRYHIP(hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         TRYHIP(hipFuncSetAttribute((const void*)moe_router_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -527,6 +559,7 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
         TRY(dmalloc(ctx, &ctx->logits, d.vocab));
     }
     TRY(dmalloc(ctx, &ctx->att, (size_t)ctx->heads_l * d.ctx));
+    if (moe) TRY(moe_build_slots(ctx));          // after hb: the merged gate/up launch writes the shared expert's SwiGLU output there
     TRYHIP((allow_big_lds<PRO_RMS, EPI_STORE>()));
     TRYHIP((allow_big_lds<PRO_QUANT, EPI_RESID>()));
     TRYHIP((allow_big_lds<PRO_RMS, EPI_SWIGLU>()));
@@ -565,7 +598,7 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     {
         const bool int8_path = d.weight_type == GL3_TYPE_Q8_0 && !(d.flags & GL3_FLAG_F32_ACTIVATION);
         const bool vl_path = !int8_path && !(d.flags & GL3_FLAG_SCALAR_DOT);      // r4: tensor-parallel ranks too (rank-chunked activations)
-        if (d.max_batch > 1 && (int8_path || vl_path)) TRY(gl3_prefill_alloc(ctx));
+        if (d.max_batch > 1 && (int8_path || vl_path) && !moe) TRY(gl3_prefill_alloc(ctx));
     }
     if (getenv("GL3_DEBUG_ALLOC")) {
         fprintf(stderr, "[gl3 alloc] ctx %p emb %p (+%zu) kcache %p vcache %p (%zu floats) x %p qkv %p xb %p hb %p logits %p att %p xn %p\n", (void*)ctx, (void*)ctx->emb.w,
@@ -604,7 +637,7 @@ void gl3_destroy(gl3_ctx* ctx) {
         f(L.attn_norm); f(L.ffn_norm); f(L.qnorm); f(L.knorm); f(L.bq); f(L.bk); f(L.bv);
         f(L.gate_exps.w); f(L.up_exps.w); f(L.down_exps.w); f(L.gate_inp); f(L.gate_inp_shexp);
     }
-    f(ctx->moe_logits); f(ctx->moe_w); f(ctx->moe_sel); f(ctx->moe_hb); f(ctx->moe_y);
+    f(ctx->moe_logits); f(ctx->moe_w); f(ctx->moe_sel); f(ctx->moe_hb); f(ctx->moe_y); f(ctx->moe_slots);
     f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->xn); f(ctx->qkv);
     if (!ctx->arena.base) { f(ctx->x); f(ctx->xb); f(ctx->hb); f(ctx->logits); }
     gl3_tp_arena_free(ctx);

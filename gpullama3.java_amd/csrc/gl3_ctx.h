@@ -153,7 +153,8 @@ struct gl3_ctx {
     // gate), selected expert ids [topk], the selected experts' SwiGLU outputs [topk][moe_hidden], the down-projected outputs
     // [topk + 1][dim] (last = shared expert)
     float *moe_logits = nullptr, *moe_w = nullptr, *moe_hb = nullptr, *moe_y = nullptr;
-    int* moe_sel = nullptr;
+    int* moe_sel = nullptr;                       // [topk] expert ids, then the router kernel's arrival ticket
+    void* moe_slots = nullptr;                    // MoeSlots[n_layers][3]: gate/up with the shared expert merged, gate/up alone, down
     int *dyn = nullptr, *argmax = nullptr;        // dyn[0] = token, dyn[1] = position
     int* h_dyn = nullptr;                         // pinned
     const int* dyn_cur = nullptr;                 // (token, position) pair the next launches read: dyn, or an entry of dyn_seq

@@ -67,12 +67,23 @@ struct MatvecArgs {
     const float* resid_in;   // may be NULL (tensor-parallel ranks > 0)
     float out_scale;         // EPI_STORE / EPI_RESID: the row result is multiplied by this first (1 except Granite: residualScale after wo /
                              // down, logitScale on the logits — InferenceCore.forwardGranite :893-894, :911-912, :921; x * 1.0f is exact)
-    // SEL instantiations only (Qwen2-MoE routed experts, InferenceCore.matmulExpert :430-432): blockIdx.y = slot j of the top-k
-    // selection; the launch works on expert sel[j] of a stacked tensor: w / w2 += sel[j] * sel_stride bytes,
-    // x += j * x_slot_stride floats (the slot's own hbE for the down projection), out += j * out_slot_stride floats
+    const struct MoeSlots* moe;   // SEL instantiations only (Qwen2-MoE): what each blockIdx.y slot of the launch works on
+};
+
+// Qwen2-MoE launches of matvec_q8t_kernel<.., SEL = true> (InferenceCore.matmulExpert :430-432): blockIdx.y = slot.  Slots j < n_sel
+// are the top-k selection: the launch works on expert sel[j] of a stacked tensor — w / w2 += sel[j] * sel_stride bytes,
+// x += j * x_slot_stride floats (the slot's own hbE for the down projection), out += j * out_slot_stride floats.  Slots >= n_sel
+// (gate/up launch only) are chunk c = slot - n_sel of the SHARED expert's dense matrices sh_w / sh_w2: `rows` rows per chunk out of
+// sh_rows, result to sh_out + c * rows — the shared expert rides in the routed experts' launch.  One record per (layer, launch) in
+// device memory, written once at plan creation.
+struct MoeSlots {
     const int* sel;
     size_t sel_stride;
     int x_slot_stride, out_slot_stride;
+    int n_sel, sh_rows;
+    const uint8_t* sh_w;
+    const uint8_t* sh_w2;
+    float* sh_out;
 };
 
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
@@ -187,11 +198,22 @@ __global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_
     MatvecArgs a = a_in;
     if (SEL) {                                          // wave-uniform: one scalar load of the expert id
         const int slot = blockIdx.y;
-        const size_t woff = (size_t)a.sel[slot] * a.sel_stride;
-        a.w += woff;
-        if (a.w2) a.w2 += woff;
-        a.x += (size_t)slot * a.x_slot_stride;
-        a.out += (size_t)slot * a.out_slot_stride;
+        const MoeSlots m = *a.moe;
+        if (slot < m.n_sel) {
+            const size_t woff = (size_t)m.sel[slot] * m.sel_stride;
+            a.w += woff;
+            if (a.w2) a.w2 += woff;
+            a.x += (size_t)slot * m.x_slot_stride;
+            a.out += (size_t)slot * m.out_slot_stride;
+        } else {
+            const int c = slot - m.n_sel;
+            const size_t woff = (size_t)c * m.sel_stride;
+            a.w = m.sh_w + woff;
+            a.w2 = m.sh_w2 ? m.sh_w2 + woff : nullptr;
+            a.out = m.sh_out + (size_t)c * a.rows;
+            const int left = m.sh_rows - c * a.rows;
+            if (left < a.rows) { a.rows = left; a.nstrips = (left + 15) / 16; }
+        }
     }
     constexpr int MV_PRODUCERS = NPW;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];

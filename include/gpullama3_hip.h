@@ -66,7 +66,7 @@ enum { GL3_ARCH_LLAMA = 0, GL3_ARCH_QWEN3 = 1, GL3_ARCH_QWEN2 = 2,
        GL3_ARCH_QWEN2MOE = 5 /* InferenceCore.forwardJavaQwen2MoE :263-422 (Qwen1.5-MoE / Qwen2-MoE): the Qwen2 attention; the FFN is an F32
                               * router over n_experts (softmax over all, top n_experts_used by strict >, no renormalisation), the
                               * selected experts' SwiGLU FFNs accumulated into x in selection order, then the always-on shared
-                              * expert scaled by sigmoid(ffn_gate_inp_shexp . xb).  Q8_0 matrices, one rank, max_batch <= 1. */ };
+                              * expert scaled by sigmoid(ffn_gate_inp_shexp . xb).  Q8_0 matrices, one rank, one sequence; a prefill chunk runs token by token. */ };
 
 /* ggml tensor types of the wire format (J/tensor/GGMLType.java:5-21) */
 enum { GL3_TYPE_F32 = 0, GL3_TYPE_F16 = 1, GL3_TYPE_Q4_0 = 2, GL3_TYPE_Q8_0 = 8,

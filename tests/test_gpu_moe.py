@@ -75,7 +75,7 @@ def test_moe_sequential_prefill_then_decode(pkg, orc, planmod):
     """tornadoVMForwardPrefill token by token (the only prefill of this family, as in the reference) leaves the oracle's KV cache."""
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS["mid-qwen2moe"], seed=5)
-    plan = plan_mod.HipMasterPlan(m)
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=16)      # accepted; chunks of 16 + 4 run token by token
     o = orc.COracle(m)
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 24)
     plan.prefill(toks[:20], 0)
@@ -139,7 +139,7 @@ def test_moe_plan_limits_are_reported_at_create(pkg, planmod):
     L = hip.lib()
     assert L.gl3_create(C.byref(desc()), C.byref(h)) == 0
     L.gl3_destroy(h)
-    for over in (dict(max_batch=8), dict(n_seqs=2), dict(tp_size=2), dict(weight_type=1), dict(flags=hip.FLAG_F32_ACTIVATION)):
+    for over in (dict(n_seqs=2), dict(tp_size=2), dict(weight_type=1), dict(flags=hip.FLAG_F32_ACTIVATION)):
         assert L.gl3_create(C.byref(desc(**over)), C.byref(h)) == -2, over
     for over in (dict(n_experts_used=0), dict(n_experts_used=9), dict(moe_hidden=48)):
         assert L.gl3_create(C.byref(desc(**over)), C.byref(h)) == -1, over
