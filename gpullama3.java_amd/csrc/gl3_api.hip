@@ -443,6 +443,9 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
         if (d.n_experts < 1 || d.n_experts > 4096 || d.n_experts_used < 1 || d.n_experts_used > d.n_experts || d.n_experts_used > 64)
             return bail(GL3_E_ARG, "qwen2moe: need 1 <= n_experts_used <= min(n_experts, 64), n_experts <= 4096");
         if (d.moe_hidden < 32 || d.moe_hidden % 32) return bail(GL3_E_ARG, "qwen2moe: moe_hidden must be a positive multiple of 32");
+        // the router keeps the products of MOE_RR rows in LDS (gl3_moe_kernels.h): dim <= ~4500 with 60 experts
+        if (d.dim > 0 && moe_router_smem(d.dim, d.n_experts) > (size_t)160 * 1024 - 256)
+            return bail(GL3_E_UNSUPPORTED, "qwen2moe: dim too large for the router kernel's LDS staging");
     } else if (d.n_experts || d.n_experts_used || d.moe_hidden)
         return bail(GL3_E_ARG, "n_experts / n_experts_used / moe_hidden belong to GL3_ARCH_QWEN2MOE");
     // Granite: the Llama graph (adjacent-pair RoPE) + four scalars; Phi-3: NeoX pairs like Qwen2, without biases

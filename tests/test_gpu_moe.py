@@ -139,7 +139,8 @@ def test_moe_plan_limits_are_reported_at_create(pkg, planmod):
     L = hip.lib()
     assert L.gl3_create(C.byref(desc()), C.byref(h)) == 0
     L.gl3_destroy(h)
-    for over in (dict(n_seqs=2), dict(tp_size=2), dict(weight_type=1), dict(flags=hip.FLAG_F32_ACTIVATION)):
+    for over in (dict(n_seqs=2), dict(tp_size=2), dict(weight_type=1), dict(flags=hip.FLAG_F32_ACTIVATION),
+                 dict(dim=8192, n_heads=64, n_kv_heads=16, head_size=128)):       # the router's LDS staging (8 rows of products) stops near dim 4500
         assert L.gl3_create(C.byref(desc(**over)), C.byref(h)) == -2, over
     for over in (dict(n_experts_used=0), dict(n_experts_used=9), dict(moe_hidden=48)):
         assert L.gl3_create(C.byref(desc(**over)), C.byref(h)) == -1, over
