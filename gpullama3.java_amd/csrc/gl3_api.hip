@@ -299,7 +299,7 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
     aa.win = ctx->attn_win;
     const size_t sm2 = ((size_t)ctx->attn_win + (size_t)pv_rows * PV_COLS) * 4;
     if (which == 0 && short_ctx && ctx->fused_attn_ok) {      // positions < AF_MAXN: one launch
-        hipLaunchKernelGGL(attn_head_kernel, dim3(ctx->heads_l), dim3(256), attn_head_smem(d.head_size), ctx->stream, aa);
+        attn_head_dispatch(d.head_size, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ctx->heads_l), dim3(256), attn_head_smem(d.head_size), ctx->stream, aa); });
         return;
     }
     if (which != 2) hipLaunchKernelGGL(attn_scores_kernel, dim3(ctx->n_tsplit, ctx->kv_heads_l), dim3(64 * kvmul), sm1, ctx->stream, aa);
@@ -569,7 +569,11 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     {
         // one launch per layer for positions < AF_MAXN (attn_head_kernel); head_size 256 does not fit its K / V tiles in LDS
         ctx->fused_attn_ok = d.head_size % 4 == 0 && attn_head_smem(d.head_size) <= 150 * 1024 && !env_flag("GL3_NO_FUSED_ATTN", false);
-        if (ctx->fused_attn_ok) TRYHIP(hipFuncSetAttribute((const void*)attn_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        if (ctx->fused_attn_ok) {
+            hipError_t ae = hipSuccess;
+            attn_head_dispatch(d.head_size, [&](auto kern) { ae = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); });
+            TRYHIP(ae);
+        }
     }
     TRYHIP(hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
 #define GL3_RL_LDS(...) TRYHIP(hipFuncSetAttribute((const void*)matvec_rl_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))

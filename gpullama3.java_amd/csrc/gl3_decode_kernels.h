@@ -121,6 +121,44 @@ __device__ __forceinline__ float seq_sum_lds(const float* v, int n, float start 
     return s;
 }
 
+// a * b as one v_mul_f32 the SLP vectoriser cannot pair: v_pk_mul_f32 wants its operands in aligned register pairs, and the
+// v_mov shuffles it inserts for that read freshly issued LDS results, i.e. wait for them — which is what a read ring is there to avoid.
+__device__ __forceinline__ float mul_f32_scalar(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// seq_sum_lds<false> with the LDS reads three 16-element groups ahead of the adds, pinned there with sched_barrier (the scheduler
+// otherwise sinks every read next to its use and the chain waits an LDS round trip per group: 11 cycles per element instead of ~6,
+// scripts/probes/seqsum_time.hip).  Same adds in the same order.  v may differ per lane (lane = row) or be uniform.
+__device__ __forceinline__ float seq_sum_lds_ring(const float* v, int n, float start = 0.f) {
+    float s = start;
+    const int G = n >> 4;
+    int i = 0;
+    if (G >= 3) {
+        float4 a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+#define SSR_LD(G_, V0_, V1_, V2_, V3_) do { const float* q_ = v + 16 * min((G_), G - 1); V0_ = *reinterpret_cast<const float4*>(q_); \
+        V1_ = *reinterpret_cast<const float4*>(q_ + 4); V2_ = *reinterpret_cast<const float4*>(q_ + 8); V3_ = *reinterpret_cast<const float4*>(q_ + 12); } while (0)
+#define SSR_ADD(V0_, V1_, V2_, V3_) do { s = seq_add4<false>(s, V0_); s = seq_add4<false>(s, V1_); s = seq_add4<false>(s, V2_); s = seq_add4<false>(s, V3_); } while (0)
+        SSR_LD(0, a0, a1, a2, a3); SSR_LD(1, b0, b1, b2, b3); SSR_LD(2, c0, c1, c2, c3);
+        int g = 0;
+        for (; g + 3 <= G; g += 3) {
+            SSR_ADD(a0, a1, a2, a3); SSR_LD(g + 3, a0, a1, a2, a3); __builtin_amdgcn_sched_barrier(0);
+            SSR_ADD(b0, b1, b2, b3); SSR_LD(g + 4, b0, b1, b2, b3); __builtin_amdgcn_sched_barrier(0);
+            SSR_ADD(c0, c1, c2, c3); SSR_LD(g + 5, c0, c1, c2, c3); __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g < G) { SSR_ADD(a0, a1, a2, a3); ++g; }
+        if (g < G) { SSR_ADD(b0, b1, b2, b3); ++g; }
+#undef SSR_ADD
+#undef SSR_LD
+        i = 16 * G;
+    }
+    for (; i + 4 <= n; i += 4) s = seq_add4<false>(s, *reinterpret_cast<const float4*>(v + i));
+    for (; i < n; ++i) s = s + v[i];
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Activation quantisation into LDS (Q8_0FloatTensor.java:96-118): 8 consecutive threads own one 32-block.
 // xq[32*b ..] = int8 quants of block b, xs[b] = f16-rounded activation scale.  v = value already normalised.
@@ -609,9 +647,11 @@ __host__ __device__ inline size_t attn_head_smem(int hs, int group = 1) {
     return ((size_t)group * hs + (size_t)AF_MAXN * (hs + 4) + (size_t)AF_MAXN * hs + (size_t)group * AF_MAXN + hs + 16) * 4;
 }
 
+// HS: head size as a compile-time constant (64 / 128: LDS row strides become immediate offsets and the index arithmetic folds), 0 = a.hs
+template <int HS>
 static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads, half = hs >> 1, pitch = hs + 4, q4 = hs >> 2;
+    const int hs = HS > 0 ? HS : a.hs, kvmul = a.n_heads / a.n_kv_heads, half = hs >> 1, pitch = hs + 4, q4 = hs >> 2;
     // float4 index -> (row, column quad) of a K / V tile: shift / mask for the power-of-two head sizes, division otherwise
     // (head_size 96: Phi-3-mini / Phi-3.5-mini, forwardJavaPhi3 with headSize = dim / heads)
     const int q4sh = (q4 & (q4 - 1)) == 0 ? __ffs(q4) - 1 : -1;
@@ -726,7 +766,7 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
         if (t < n) { ex = (float)exp((double)(sc - mx)); e_s[t] = ex; }
         __syncthreads();
         ATT_STAMP(4);
-        if (wave == 0) { const float sum = seq_sum_lds<false>(e_s, n); if (lane == 0) red[4] = sum; }
+        if (wave == 0) { const float sum = seq_sum_lds_ring(e_s, n); if (lane == 0) red[4] = sum; }
         __syncthreads();
         if (t < n) e_s[t] = ex / red[4];
         __syncthreads();
@@ -742,7 +782,7 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const float sum = seq_sum_lds<false>(e, n);
+            const float sum = seq_sum_lds_ring(e, n);
             __builtin_amdgcn_wave_barrier();
             if (lane < n) e[lane] = e0 / sum;
             if (lane + 64 < n) e[lane + 64] = e1 / sum;
@@ -754,14 +794,36 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
     for (int idx = t; idx < G * hs; idx += 256) {
         const int g = idx / hs, j = idx - g * hs;
         const float* e = e_s + g * AF_MAXN;
+        const float* vj = vt + j;
         float acc = 0.f;
         int tt = 0;
-        for (; tt + 4 <= n; tt += 4) {
-            const float4 a4 = *reinterpret_cast<const float4*>(e + tt);
-            const float v0 = vt[tt * hs + j], v1 = vt[(tt + 1) * hs + j], v2 = vt[(tt + 2) * hs + j], v3 = vt[(tt + 3) * hs + j];
-            acc = a4.x * v0 + acc; acc = a4.y * v1 + acc; acc = a4.z * v2 + acc; acc = a4.w * v3 + acc;
+        // Groups of 4 timesteps (one 16-byte read of the weights, four 4-byte reads of this column of V), three groups = 15 LDS
+        // reads in flight ahead of the dependent mul / add chain.  The sched_barrier after every refill keeps the order "use group A,
+        // refill A, use group B, ..."; left alone the scheduler puts the five reads of a group right in front of their use and the
+        // wavefront (the only one on its SIMD) waits a full LDS round trip per 4 timesteps (seen in the ISA: s_waitcnt lgkmcnt(0) two
+        // instructions after the reads, ~150 cycles per iteration for 40 cycles of arithmetic).
+        const int NG = n >> 2;
+        if (NG >= 3) {
+            float4 ea, eb, ec;
+            float a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+#define PV_LD(G_, E_, V0_, V1_, V2_, V3_) do { const int r_ = 4 * min((G_), NG - 1); E_ = *reinterpret_cast<const float4*>(e + r_); \
+            const float* vr_ = vj + r_ * hs; V0_ = vr_[0]; V1_ = vr_[hs]; V2_ = vr_[2 * hs]; V3_ = vr_[3 * hs]; } while (0)
+#define PV_ACC(E_, V0_, V1_, V2_, V3_) do { acc = mul_f32_scalar(E_.x, V0_) + acc; acc = mul_f32_scalar(E_.y, V1_) + acc; \
+            acc = mul_f32_scalar(E_.z, V2_) + acc; acc = mul_f32_scalar(E_.w, V3_) + acc; } while (0)
+            PV_LD(0, ea, a0, a1, a2, a3); PV_LD(1, eb, b0, b1, b2, b3); PV_LD(2, ec, c0, c1, c2, c3);
+            int gq = 0;
+            for (; gq + 3 <= NG; gq += 3) {
+                PV_ACC(ea, a0, a1, a2, a3); PV_LD(gq + 3, ea, a0, a1, a2, a3); __builtin_amdgcn_sched_barrier(0);
+                PV_ACC(eb, b0, b1, b2, b3); PV_LD(gq + 4, eb, b0, b1, b2, b3); __builtin_amdgcn_sched_barrier(0);
+                PV_ACC(ec, c0, c1, c2, c3); PV_LD(gq + 5, ec, c0, c1, c2, c3); __builtin_amdgcn_sched_barrier(0);
+            }
+            if (gq < NG) { PV_ACC(ea, a0, a1, a2, a3); ++gq; }
+            if (gq < NG) { PV_ACC(eb, b0, b1, b2, b3); ++gq; }
+#undef PV_ACC
+#undef PV_LD
+            tt = 4 * NG;
         }
-        for (; tt < n; ++tt) acc = e[tt] * vt[tt * hs + j] + acc;
+        for (; tt < n; ++tt) acc = e[tt] * vj[tt * hs] + acc;
         if (a.xq_out) {
             // Q8_0 activation quantisation of the 32-element block this half-wavefront holds (Q8_0FloatTensor.java:96-118; head
             // sizes are multiples of 32, so a block never straddles heads or passes): block maximum over 32 lanes, round half
@@ -788,6 +850,14 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
         }
     }
     ATT_STAMP(6);
+}
+
+// Picks the instantiation for the head size (host side).
+template <typename F>
+static inline void attn_head_dispatch(int hs, F&& f) {
+    if (hs == 128) f(attn_head_kernel<128>);
+    else if (hs == 64) f(attn_head_kernel<64>);
+    else f(attn_head_kernel<0>);
 }
 
 // Decode attention, part 2: softmax + weighted V sum.   Grid = n_heads x hs/16, block = 256.

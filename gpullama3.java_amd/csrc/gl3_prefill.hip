@@ -1266,7 +1266,7 @@ static void pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
         ha.eps = d.rms_eps; ha.arch = ctx->rope_arch; ha.att_mul = ctx->att_mul; ha.seqv = seq; ha.posv = pos; ha.seq_stride = ctx->kv_seq_stride;
         ha.group = bd_group;
         if (fuse_q) { ha.xq_out = p->XQ; ha.xs_out = p->XS; ha.xq_slots = bd_tslots(n); }
-        hipLaunchKernelGGL(attn_head_kernel, dim3(H / bd_group, n), dim3(256), attn_head_smem(hs, bd_group), s, ha);
+        attn_head_dispatch(hs, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(H / bd_group, n), dim3(256), attn_head_smem(hs, bd_group), s, ha); });
         return;
     }
     hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(H + KVH, n), dim3(64), 0, s, ra);
