@@ -808,6 +808,7 @@ int32_t gl3_upload_rope(gl3_ctx* ctx, const float* cr, const float* ci, uint64_t
 }
 
 static int32_t capture(gl3_ctx* ctx, bool want_logits, bool short_ctx, hipGraph_t* g, hipGraphExec_t* ge) {
+    ctx->tp_dbg_prev_n4 = 0;
     GL3_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     int32_t r = enqueue_decode(ctx, want_logits, nullptr, short_ctx);
     hipError_t e = hipStreamEndCapture(ctx->stream, g);

@@ -118,8 +118,9 @@ struct gl3_tp_arena {
     size_t bytes = 0;
     size_t off[8] = {};                           // byte offset of buffer GB_*; 0 = not allocated
     int pf_logits_rows = 0;                       // capacity of the batched-decode logits buffer (rows)
+    bool pooled = false;                          // base goes back to the process-wide arena pool, not to hipFree (gl3_tp.hip)
 };
-constexpr size_t GL3_ARENA_HDR = 256, GL3_ARENA_SEQ = 64, GL3_ARENA_ARRIVE = 68;
+constexpr size_t GL3_ARENA_HDR = 1024, GL3_ARENA_SEQ = 64, GL3_ARENA_ARRIVE = 68;      // bytes 256..511: checksums of GL3_TP_DEBUG (gl3_tp.hip)
 
 struct gl3_ctx {
     gl3_model_desc d{};
@@ -185,6 +186,7 @@ struct gl3_ctx {
     uint8_t* peer_base[GL3_MAX_TP] = {};          // arena of every rank as mapped into this process (peer_base[tp_rank] = arena.base)
     void* ipc_opened[GL3_MAX_TP] = {};            // mappings to close (hipIpcCloseMemHandle)
     uint32_t* h_tp_err = nullptr;                 // pinned, device-visible: set by a gather kernel whose peers never arrived
+    size_t tp_dbg_prev_off = 0, tp_dbg_prev_n4 = 0;   // GL3_TP_DEBUG: the previous gather of this forward call (re-checked by the next one)
     std::vector<hipEvent_t> ev;
     hipEvent_t prof_ev0 = nullptr, prof_ev1 = nullptr;   // non-null: the next matvec launch carries them as start / stop events
     // metrics

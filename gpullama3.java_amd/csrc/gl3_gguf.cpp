@@ -441,13 +441,17 @@ void gl3_rope_table_yarn(int32_t ctx, int32_t head_size, float theta, float fact
         }
 }
 
-// <arch>.rope.scaling.* of a YaRN file (DevstralModelLoader.java:80-86).  Returns 1 and fills the five parameters when
-// rope.scaling.type == "yarn" and the required keys are present, 0 when the file asks for the plain table.
+// <arch>.rope.scaling.* of a YaRN file (DevstralModelLoader.java:80-86).  Returns 1 and fills the five parameters when the file's
+// architecture is "mistral3", rope.scaling.type == "yarn" and the required keys are present and usable; 0 when the plain table
+// applies.  ONLY the Devstral loader of the reference reads these keys: the llama / qwen2 / qwen3 / ... loaders ignore them and
+// build the plain table even for a long-context file that carries yarn metadata, so the same is done here (r4 advisor finding).
+// factor <= 0 or original_context_length <= 0 would put inf / NaN into the table: such a file gets -1 (rejected by gl3_load_gguf).
 int32_t gl3_gguf_yarn_params(gl3_gguf* g, float* factor, float* beta_fast, float* beta_slow, float* log_multiplier, int32_t* original_ctx) {
     if (!g) return 0;
     auto it = g->meta.find("general.architecture");
     if (it == g->meta.end()) return 0;
     const std::string a = it->second.str;
+    if (a != "mistral3") return 0;
     auto ty = g->meta.find(a + ".rope.scaling.type");
     if (ty == g->meta.end() || ty->second.type != GT_STRING || ty->second.str != "yarn") return 0;
     double f, bf, bs, lm = 0.0, oc;
@@ -455,6 +459,7 @@ int32_t gl3_gguf_yarn_params(gl3_gguf* g, float* factor, float* beta_fast, float
         !meta_num(g, a + ".rope.scaling.yarn_beta_slow", &bs) || !meta_num(g, a + ".rope.scaling.original_context_length", &oc))
         return 0;
     meta_num(g, a + ".rope.scaling.yarn_log_multiplier", &lm);
+    if (!(f > 0.0) || !(oc >= 1.0) || oc > 2147483647.0 || !std::isfinite(f) || !std::isfinite(bf) || !std::isfinite(bs) || !std::isfinite(lm)) return -1;
     if (factor) *factor = (float)f;
     if (beta_fast) *beta_fast = (float)bf;
     if (beta_slow) *beta_slow = (float)bs;
@@ -477,6 +482,10 @@ int32_t gl3_load_gguf(const char* path, const gl3_model_desc* opts, gl3_ctx** ou
     if (opts) d = *opts;
     float theta = 10000.f;
     if ((r = gl3_gguf_model_desc(g, &d, &theta)) != GL3_OK) { g_open_err = g->err; gl3_gguf_close(g); return r; }
+    float yf = 0, ybf = 0, ybs = 0, ylm = 0;
+    int32_t yoc = 0;
+    const int32_t yarn = gl3_gguf_yarn_params(g, &yf, &ybf, &ybs, &ylm, &yoc);
+    if (yarn < 0) { g_open_err = "mistral3.rope.scaling: factor and original_context_length must be finite and > 0"; gl3_gguf_close(g); return GL3_E_ARG; }
     gl3_ctx* ctx = nullptr;
     if ((r = gl3_create(&d, &ctx)) != GL3_OK) { g_open_err = gl3_last_error(nullptr); gl3_gguf_close(g); return r; }
     std::vector<uint8_t> kq;          // Q8_0 image of the K-quant tensor being uploaded
@@ -539,9 +548,7 @@ int32_t gl3_load_gguf(const char* path, const gl3_model_desc* opts, gl3_ctx** ou
     if (r == GL3_OK) {
         const size_t n = (size_t)d.ctx * (d.head_size / 2);
         std::vector<float> cr(n), ci(n);
-        float yf, ybf, ybs, ylm;
-        int32_t yoc;
-        if (gl3_gguf_yarn_params(g, &yf, &ybf, &ybs, &ylm, &yoc)) gl3_rope_table_yarn(d.ctx, d.head_size, theta, yf, ybf, ybs, ylm, yoc, cr.data(), ci.data());
+        if (yarn > 0) gl3_rope_table_yarn(d.ctx, d.head_size, theta, yf, ybf, ybs, ylm, yoc, cr.data(), ci.data());
         else gl3_rope_table(d.ctx, d.head_size, theta, cr.data(), ci.data());
         r = gl3_upload_rope(ctx, cr.data(), ci.data(), n);
     }

@@ -25,10 +25,44 @@
 // No hardware curve exists until the driver's 8-GPU run (SCALE_rNN.json); in CI the SAME kernel runs between ranks that are
 // host threads of one process on one GPU (gl3_local_group) and between processes sharing one GPU over IPC handles.
 #include <cstring>
+#include <tuple>
 
 #include "gl3_ctx.h"
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ------------------------------------------------------------------------------------------------ arena pool
+// An UNCACHED allocation is never handed back to the HIP allocator while the process lives: freed arenas wait here, keyed by
+// (device, size), for the next plan of the same shape.  Root cause of round 4's "stale activation rows" (profiles/r05_tp_flake.md):
+// with hipFree, the pages of a freed uncached arena were recycled by later hipMalloc calls of the same process under the CACHED
+// policy (and freed cached buffers came back as the next arena); kernels of the next plans then computed on stale lines — in-process
+// test ranks failed 8-9 runs of 10 from the second plan of a process on, and 0 of 20 with the arena never freed, with a cached or
+// with a fine-grained arena; the gather's own checksums (GL3_TP_DEBUG) were clean in every failing run, i.e. the transport
+// protocol was never at fault.  One process per GPU with one plan per process (production) never recycles; a server that
+// re-creates tensor-parallel plans does, so the pool is always on.
+namespace {
+struct ArenaPool {
+    std::mutex mu;
+    std::vector<std::tuple<int, size_t, uint8_t*>> free_list;
+};
+ArenaPool& arena_pool() { static ArenaPool* p = new ArenaPool(); return *p; }      // never destroyed: outlives every plan
+uint8_t* arena_pool_take(int device, size_t bytes) {
+    ArenaPool& P = arena_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (size_t i = 0; i < P.free_list.size(); ++i)
+        if (std::get<0>(P.free_list[i]) == device && std::get<1>(P.free_list[i]) == bytes) {
+            uint8_t* b = std::get<2>(P.free_list[i]);
+            P.free_list.erase(P.free_list.begin() + (long)i);
+            return b;
+        }
+    return nullptr;
+}
+void arena_pool_give(int device, size_t bytes, uint8_t* base) {
+    ArenaPool& P = arena_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.free_list.emplace_back(device, bytes, base);
+}
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------ arena
 int32_t gl3_tp_arena_alloc(gl3_ctx* ctx) {
@@ -46,12 +80,19 @@ int32_t gl3_tp_arena_alloc(gl3_ctx* ctx) {
     }
     A.bytes = o;
     // Uncached device memory (what RCCL uses for its own peer buffers): a peer's writes arrive over xGMI behind the owner's
-    // L2, so the owner must never hold a stale line.  GL3_TP_ARENA=cached selects plain hipMalloc (kernel-boundary
-    // invalidation only) for experiments.
+    // L2, so the owner must never hold a stale line.  Experiments: GL3_TP_ARENA=cached selects plain hipMalloc (kernel-boundary
+    // invalidation only), =finegrained hipDeviceMallocFinegrained, =unpooled the uncached arena returned with hipFree (reproduces
+    // the recycling fault described at the pool above).
     const char* mode = getenv("GL3_TP_ARENA");
-    hipError_t e = (mode && !strcmp(mode, "cached")) ? hipMalloc((void**)&A.base, A.bytes)
-                                                     : hipExtMallocWithFlags((void**)&A.base, A.bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) { A.base = nullptr; ctx->err = std::string("tensor-parallel arena: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? GL3_E_OOM : GL3_E_HIP; }
+    const int kind = (mode && !strcmp(mode, "cached")) ? 1 : (mode && !strcmp(mode, "finegrained")) ? 2 : (mode && !strcmp(mode, "unpooled")) ? 3 : 0;
+    A.base = kind == 0 ? arena_pool_take(d.device, A.bytes) : nullptr;
+    A.pooled = kind == 0;
+    if (!A.base) {
+        hipError_t e = kind == 1 ? hipMalloc((void**)&A.base, A.bytes)
+                       : kind == 2 ? hipExtMallocWithFlags((void**)&A.base, A.bytes, hipDeviceMallocFinegrained)
+                                   : hipExtMallocWithFlags((void**)&A.base, A.bytes, hipDeviceMallocUncached);
+        if (e != hipSuccess) { A.base = nullptr; ctx->err = std::string("tensor-parallel arena: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? GL3_E_OOM : GL3_E_HIP; }
+    }
     GL3_HIP(hipMemset(A.base, 0, A.bytes));
     GL3_HIP(hipHostMalloc((void**)&ctx->h_tp_err, sizeof(uint32_t)));
     *ctx->h_tp_err = 0;
@@ -62,7 +103,10 @@ int32_t gl3_tp_arena_alloc(gl3_ctx* ctx) {
 void gl3_tp_arena_free(gl3_ctx* ctx) {
     for (int p = 0; p < GL3_MAX_TP; ++p)
         if (ctx->ipc_opened[p]) { hipIpcCloseMemHandle(ctx->ipc_opened[p]); ctx->ipc_opened[p] = nullptr; }
-    if (ctx->arena.base) hipFree(ctx->arena.base);
+    if (ctx->arena.base) {
+        if (ctx->arena.pooled) arena_pool_give(ctx->d.device, ctx->arena.bytes, ctx->arena.base);
+        else hipFree(ctx->arena.base);
+    }
     ctx->arena.base = nullptr;
     if (ctx->h_tp_err) hipHostFree(ctx->h_tp_err);
     ctx->h_tp_err = nullptr;
@@ -128,6 +172,101 @@ __global__ __launch_bounds__(1024) void tp_gather_kernel(const TpGatherArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: drop anything cached before the peers' data landed
 }
 
+// GL3_TP_DEBUG=1 — diagnostic twin of tp_gather_kernel (ONE workgroup): every pushed slice travels with a position-weighted
+// checksum (written into the peers' arena headers before the flag), and the receiver
+//   phase 0: re-computes the checksum of every peer's slice right after its flag wait (a mismatch = the flag was visible before
+//            the data, i.e. a visibility / ordering fault of the transport), and
+//   phase 1: at the START of its next gather re-checks the previous gather's peer slices (nothing on this rank writes them in
+//            between; a mismatch = a peer's later push landed while this rank could still be reading: a write-after-read fault).
+// Mismatches are printed from the device.  Neither firing while results are wrong = the fault is not in the transport.
+struct TpGatherDbg { size_t prev_off, prev_n4; };
+constexpr size_t GL3_ARENA_DBG = 256;      // u32 sums[4][GL3_MAX_TP]: sums[k & 3][p] = checksum of rank p's slice of gather k
+
+__device__ __forceinline__ unsigned tp_dbg_sum(const v4f_tp* p, size_t n4, int t, unsigned* sh) {
+    unsigned h = 0;
+    for (size_t i = t; i < n4; i += 1024) {
+        const v4f_tp v = p[i];
+        const unsigned w0 = __builtin_bit_cast(unsigned, v.x), w1 = __builtin_bit_cast(unsigned, v.y), w2 = __builtin_bit_cast(unsigned, v.z), w3 = __builtin_bit_cast(unsigned, v.w);
+        const unsigned m = (unsigned)(4 * i) * 2654435761u;
+        h += w0 * (m | 1u) + w1 * ((m + 0x9E3779B9u) | 1u) + w2 * ((m + 0x3C6EF372u) | 1u) + w3 * ((m + 0xDAA66D2Bu) | 1u);
+    }
+    __syncthreads();
+    if (t == 0) *sh = 0;
+    __syncthreads();
+    atomicAdd(sh, h);
+    __syncthreads();
+    return *sh;
+}
+
+__global__ __launch_bounds__(1024) void tp_gather_dbg_kernel(const TpGatherArgs a, const TpGatherDbg g) {
+    __shared__ unsigned sh, kk;
+    const int t = threadIdx.x;
+    uint8_t* own = a.peer[a.me];
+    uint32_t* seq = reinterpret_cast<uint32_t*>(own + GL3_ARENA_SEQ);
+    unsigned* sums = reinterpret_cast<unsigned*>(own + GL3_ARENA_DBG);
+    if (t == 0) kk = __hip_atomic_load(seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    __syncthreads();
+    const uint32_t k = kk;
+    // ---- phase 1: the previous gather's peer slices must still be what their owners pushed
+    if (g.prev_n4) {
+        for (int j = 1; j < a.tp; ++j) {
+            const int p = (a.me + j) % a.tp;
+            const unsigned got = tp_dbg_sum(reinterpret_cast<const v4f_tp*>(own + g.prev_off) + (size_t)p * g.prev_n4, g.prev_n4, t, &sh);
+            const unsigned want = __hip_atomic_load(sums + ((k - 1) & 3) * GL3_MAX_TP + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (t == 0 && got != want)
+                printf("[gl3 tp dbg] rank %d gather %u: slice of rank %d from gather %u (arena offset %zu, %zu float4) CHANGED before the next gather: %08x != %08x (write-after-read)\n",
+                       a.me, k, p, k - 1, g.prev_off, g.prev_n4, got, want);
+        }
+    }
+    // ---- push (as tp_gather_kernel) + checksum of my slice into the peers' headers
+    const v4f_tp* src = reinterpret_cast<const v4f_tp*>(own + a.buf_off) + (size_t)a.me * a.n4;
+    for (size_t i = t; i < a.n4; i += 1024) {
+        const v4f_tp v = src[i];
+        for (int j = 1; j < a.tp; ++j) {
+            const int p = (a.me + j) % a.tp;
+            reinterpret_cast<v4f_tp*>(a.peer[p] + a.buf_off)[(size_t)a.me * a.n4 + i] = v;
+        }
+    }
+    const unsigned mine = tp_dbg_sum(src, a.n4, t, &sh);
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) {
+        for (int j = 1; j < a.tp; ++j) {
+            const int p = (a.me + j) % a.tp;
+            __hip_atomic_store(reinterpret_cast<unsigned*>(a.peer[p] + GL3_ARENA_DBG) + (k & 3) * GL3_MAX_TP + a.me, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __threadfence_system();
+        for (int j = 1; j < a.tp; ++j) {
+            const int p = (a.me + j) % a.tp;
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(a.peer[p]) + a.me, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const uint32_t* flags = reinterpret_cast<const uint32_t*>(own);
+        bool ok = true;
+        for (int j = 1; j < a.tp && ok; ++j) {
+            const int p = (a.me + j) % a.tp;
+            unsigned spins = 0;
+            while ((int32_t)(__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - k) < 0) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > a.spin_limit) { ok = false; break; }
+            }
+        }
+        if (!ok) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(seq, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // ---- phase 0: what the peers pushed is what is visible here now
+    for (int j = 1; j < a.tp; ++j) {
+        const int p = (a.me + j) % a.tp;
+        const unsigned got = tp_dbg_sum(reinterpret_cast<const v4f_tp*>(own + a.buf_off) + (size_t)p * a.n4, a.n4, t, &sh);
+        const unsigned want = __hip_atomic_load(sums + (k & 3) * GL3_MAX_TP + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (t == 0 && got != want)
+            printf("[gl3 tp dbg] rank %d gather %u: slice of rank %d (arena offset %zu, %zu float4) NOT COMPLETE when its flag was seen: %08x != %08x (visibility)\n",
+                   a.me, k, p, a.buf_off, a.n4, got, want);
+    }
+}
+
 static int32_t all_gather_p2p(gl3_ctx* ctx, int which, size_t count_per_rank) {
     const gl3_model_desc& d = ctx->d;
     if (!ctx->arena.off[which]) GL3_FAIL(GL3_E_STATE, "gathered buffer is not part of the tensor-parallel arena");
@@ -139,6 +278,13 @@ static int32_t all_gather_p2p(gl3_ctx* ctx, int which, size_t count_per_rank) {
     a.spin_limit = limit; a.err = ctx->h_tp_err;
     size_t wgs = (a.n4 * 16 + 65535) / 65536;           // 64 KB of slice per workgroup
     wgs = wgs < 1 ? 1 : wgs > 64 ? 64 : wgs;
+    static const bool dbg = env_flag("GL3_TP_DEBUG", false);
+    if (dbg) {
+        TpGatherDbg g{ctx->tp_dbg_prev_off, ctx->tp_dbg_prev_n4};
+        hipLaunchKernelGGL(tp_gather_dbg_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, g);
+        ctx->tp_dbg_prev_off = a.buf_off; ctx->tp_dbg_prev_n4 = a.n4;
+        return GL3_OK;
+    }
     hipLaunchKernelGGL(tp_gather_kernel, dim3((unsigned)wgs), dim3(1024), 0, ctx->stream, a);
     return GL3_OK;
 }
@@ -152,6 +298,7 @@ int32_t gl3_all_gather(gl3_ctx* ctx, int which, size_t count_per_rank) {
 }
 
 int32_t gl3_tp_check(gl3_ctx* ctx) {
+    ctx->tp_dbg_prev_n4 = 0;                 // GL3_TP_DEBUG: the next forward call's first gather has no predecessor to re-check
     if (ctx->h_tp_err && *ctx->h_tp_err) {
         *ctx->h_tp_err = 0;
         GL3_FAIL(GL3_E_RCCL, "tensor-parallel all-gather timed out waiting for a peer rank");

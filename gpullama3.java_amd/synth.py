@@ -346,9 +346,13 @@ class SynthModel:
         a = md["general.architecture"]
         arch = ARCH_LLAMA if a == "mistral3" else {v: k for k, v in _ARCH_NAME.items()}[a]
         yarn = None
-        if md.get(f"{a}.rope.scaling.type") == "yarn":
+        # only the reference's Devstral loader reads rope.scaling.* (DevstralModelLoader.java:80-93); the llama / qwen2 / qwen3 loaders
+        # build the plain table whatever the file says
+        if a == "mistral3" and md.get(f"{a}.rope.scaling.type") == "yarn":
             yarn = (md[f"{a}.rope.scaling.factor"], md[f"{a}.rope.scaling.yarn_beta_fast"], md[f"{a}.rope.scaling.yarn_beta_slow"],
                     md.get(f"{a}.rope.scaling.yarn_log_multiplier", 0.0), md[f"{a}.rope.scaling.original_context_length"])
+            if not (yarn[0] > 0 and yarn[4] > 0):
+                raise ValueError("mistral3.rope.scaling: factor and original_context_length must be > 0")
         dim, nh = md[f"{a}.embedding_length"], md[f"{a}.attention.head_count"]
         hs = md.get(f"{a}.attention.key_length", dim // nh)
         cfg = ModelConfig(md["general.name"], arch, dim, md[f"{a}.feed_forward_length"], md[f"{a}.block_count"], nh,

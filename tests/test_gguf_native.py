@@ -142,6 +142,62 @@ def test_devstral_gguf_metadata_round_trip(pkg, hip, tmp_path):
         L.gl3_gguf_close(g)
 
 
+def _write_with_extra_metadata(model, path, extra):
+    """model.write_gguf with extra metadata keys (the synthetic writer only emits rope.scaling.* for cfg.yarn models)."""
+    base = model.metadata
+    model.metadata = lambda: {**base(), **extra}
+    try:
+        model.write_gguf(path)
+    finally:
+        model.metadata = base
+
+
+@pytest.mark.parametrize("cfg", ["tiny-qwen3", "tiny-llama"])
+def test_yarn_keys_outside_mistral3_are_ignored(pkg, hip, tmp_path, cfg):
+    """Only DevstralModelLoader reads <arch>.rope.scaling.* (DevstralModelLoader.java:80-93); LlamaModelLoader.java:68 and
+    Qwen3ModelLoader.java:78 call RoPE.precomputeFreqsCis whatever the file says.  A qwen3 / llama file that carries yarn keys
+    (128K variants do) must therefore get the PLAIN table in the native loader and in the Python reader (r4 advisor finding)."""
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], seed=3)
+    a = "qwen3" if "qwen3" in cfg else "llama"
+    path = str(tmp_path / "y.gguf")
+    _write_with_extra_metadata(m, path, {f"{a}.rope.scaling.type": "yarn", f"{a}.rope.scaling.factor": 4.0, f"{a}.rope.scaling.yarn_beta_fast": 32.0,
+                                         f"{a}.rope.scaling.yarn_beta_slow": 1.0, f"{a}.rope.scaling.original_context_length": 64})
+    L = hip.lib()
+    g = C.c_void_p()
+    hip.check_gguf(L.gl3_gguf_open(path.encode(), C.byref(g)))
+    try:
+        assert L.gl3_gguf_yarn_params(g, None, None, None, None, None) == 0
+    finally:
+        L.gl3_gguf_close(g)
+    back = pkg.synth.SynthModel.from_gguf(path)
+    assert back.cfg.yarn is None
+    assert np.array_equal(back.rope[0], m.rope[0]) and np.array_equal(back.rope[1], m.rope[1])
+
+
+@pytest.mark.parametrize("key,val", [("factor", 0.0), ("factor", -2.0), ("original_context_length", 0)])
+def test_unusable_yarn_parameters_are_rejected(pkg, hip, tmp_path, key, val):
+    """factor == 0 would put 1 / 0 into every interpolated frequency (NaN table); the native reader reports -1 and gl3_load_gguf /
+    the Python reader refuse the file."""
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-devstral"], seed=3)
+    path = str(tmp_path / "bad.gguf")
+    _write_with_extra_metadata(m, path, {f"mistral3.rope.scaling.{key}": val})
+    L = hip.lib()
+    g = C.c_void_p()
+    hip.check_gguf(L.gl3_gguf_open(path.encode(), C.byref(g)))
+    try:
+        assert L.gl3_gguf_yarn_params(g, None, None, None, None, None) == -1
+    finally:
+        L.gl3_gguf_close(g)
+    with pytest.raises(ValueError):
+        pkg.synth.SynthModel.from_gguf(path)
+    ctx = C.c_void_p()
+    opts = hip.ModelDesc()
+    opts.struct_size = C.sizeof(hip.ModelDesc)
+    opts.ctx = 64
+    assert L.gl3_load_gguf(path.encode(), C.byref(opts), C.byref(ctx)) == hip.E_ARG      # refused before any device work
+    assert b"rope.scaling" in L.gl3_gguf_last_error(None)
+
+
 def test_qwen2moe_gguf_metadata_round_trip(pkg, hip, tmp_path):
     """A "qwen2moe" file (Qwen2MoEModelLoader.java:56-110): expert counts from the metadata, the experts' hidden size from the first
     dimension of the 3-D blk.0.ffn_down_exps.weight, the shared expert's from feed_forward_length; stacked experts are 3-D tensors."""
