@@ -443,6 +443,10 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
         if (d.n_experts < 1 || d.n_experts > 4096 || d.n_experts_used < 1 || d.n_experts_used > d.n_experts || d.n_experts_used > 64)
             return bail(GL3_E_ARG, "qwen2moe: need 1 <= n_experts_used <= min(n_experts, 64), n_experts <= 4096");
         if (d.moe_hidden < 32 || d.moe_hidden % 32) return bail(GL3_E_ARG, "qwen2moe: moe_hidden must be a positive multiple of 32");
+        // the stacked expert tensors are addressed with int row counts (alloc_mat / upload_q8): n_experts * moe_hidden and
+        // n_experts * dim must fit, and moe_hidden comes from an untrusted GGUF's ne[0] (r4 advisor finding)
+        if (d.moe_hidden > (1 << 24) || (int64_t)d.n_experts * d.moe_hidden > INT32_MAX || (int64_t)d.n_experts * d.dim > INT32_MAX)
+            return bail(GL3_E_ARG, "qwen2moe: n_experts * moe_hidden / n_experts * dim exceed the supported range");
         // the router keeps the products of MOE_RR rows in LDS (gl3_moe_kernels.h): dim <= ~4500 with 60 experts
         if (d.dim > 0 && moe_router_smem(d.dim, d.n_experts) > (size_t)160 * 1024 - 256)
             return bail(GL3_E_UNSUPPORTED, "qwen2moe: dim too large for the router kernel's LDS staging");

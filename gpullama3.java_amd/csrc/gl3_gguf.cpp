@@ -392,8 +392,11 @@ int32_t gl3_gguf_model_desc(gl3_gguf* g, gl3_model_desc* d, float* rope_theta) {
         if (!need("expert_count", &ne) || !need("expert_used_count", &nu)) return fail(g, GL3_E_ARG, "qwen2moe: expert_count / expert_used_count missing");
         auto de = g->by_name.find("blk.0.ffn_down_exps.weight");
         if (de == g->by_name.end() || g->tensors[de->second].n_dims != 3) return fail(g, GL3_E_ARG, "qwen2moe: blk.0.ffn_down_exps.weight missing or not 3-D");
+        const uint64_t mh = g->tensors[de->second].ne[0];
+        if (!(ne >= 1 && ne <= 4096) || !(nu >= 1 && nu <= ne) || mh < 32 || mh > (1u << 24))       // range-checked BEFORE the int32 casts (untrusted file)
+            return fail(g, GL3_E_ARG, "qwen2moe: expert_count / expert_used_count / expert hidden size out of range");
         d->n_experts = (int32_t)ne; d->n_experts_used = (int32_t)nu;
-        d->moe_hidden = (int32_t)g->tensors[de->second].ne[0];                  // dimensions()[0] of the down stack = experts' hidden size
+        d->moe_hidden = (int32_t)mh;                  // dimensions()[0] of the down stack = experts' hidden size
     }
     // K-quant files run as Q8_0 after the load-time conversion (ModelLoader.loadTornadoTensor :163-164)
     d->weight_type = (emb.type == GL3_TYPE_Q4_K || emb.type == GL3_TYPE_Q5_K || emb.type == GL3_TYPE_Q6_K) ? GL3_TYPE_Q8_0 : emb.type;

@@ -24,6 +24,7 @@ using namespace gl3;
 #include "gl3_bd_gemm.h"      // GemmArgs, bdw_gemm_kernel (expects the gl3 names in scope)
 // gl3_prefill_gemm2.hip (own translation unit, -fno-slp-vectorize): the > 64-token GEMM with the scale products on the matrix pipe (r4)
 void gl3_gemm2_launch(int epi, const GemmArgs& a, int rows, int ntok, int mode, hipStream_t s);
+hipError_t gl3_gemm2_allow_lds();
 
 struct gl3_prefill_state {
     int max_batch = 0;
@@ -1144,6 +1145,7 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_GEMM_LDS(EPI_SWIGLU, 1, 4);
     GL3_GEMM_LDS(EPI_STORE, 1, 4, 32); GL3_GEMM_LDS(EPI_RESID, 1, 4, 32); GL3_GEMM_LDS(EPI_SWIGLU, 1, 4, 32);
 #undef GL3_GEMM_LDS
+    GL3_HIP(gl3_gemm2_allow_lds());                      // pf_gemm2_kernel instantiations (own translation unit)
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1210,7 +1212,7 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     // Default: the gate/up GEMM (two matrices per workgroup, the dominant launch) on the r4 kernel — measured 246-250 us against 266-272
     // for the r3 kernel at 512 tokens of the 8B layer; the other shapes stay on the r3 kernel (qkv 79 vs 80, wo 57 vs 45, down 222 vs 139:
     // profiles/r04_gemm_experiments.md).  GL3_PF_GEMM2=0: r3 kernel everywhere; GL3_PF_GEMM2_ALL=1: r4 kernel for every shape;
-    // GL3_PF_GEMM2=1 / 4: A/B forms (-B s on the VALU / one tile per wavefront).
+    // GL3_PF_GEMM2=1: A/B form (-B s on the VALU).
     static const int g2 = getenv("GL3_PF_GEMM2") ? atoi(getenv("GL3_PF_GEMM2")) : 2;
     static const bool g2_all = getenv("GL3_PF_GEMM2_ALL") && atoi(getenv("GL3_PF_GEMM2_ALL"));
     if (g2 && (EPI == EPI_SWIGLU || g2_all)) { gl3_gemm2_launch(EPI, a, w.rows, ntok, g2, ctx->stream); return; }

@@ -7,16 +7,39 @@
 using namespace gl3;
 #include "gl3_bd_gemm.h"          // GemmArgs
 #include "gl3_prefill_gemm2.h"
-#include "gl3_prefill_gemm4.h"
 
-// LDS request of a variant; set once (dynamic LDS above 64 KB needs the attribute, below it is harmless)
+template <int EPI, int RF>
+constexpr int g2_lds_bytes() { return G2_RING * g2_stage_bytes((EPI == EPI_SWIGLU ? 2 : 1) * RF * 64); }
+
 template <int EPI, int RF, int NW, int OCC, int MODE>
 static void g2_launch(const GemmArgs& a, dim3 grid, hipStream_t s) {
-    constexpr int AROWS = (EPI == EPI_SWIGLU ? 2 : 1) * RF * 64;
-    constexpr int LDS = G2_RING * g2_stage_bytes(AROWS);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)pf_gemm2_kernel<EPI, RF, NW, OCC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-    hipLaunchKernelGGL((pf_gemm2_kernel<EPI, RF, NW, OCC, MODE>), grid, dim3(64 * NW), LDS, s, a);
+    hipLaunchKernelGGL((pf_gemm2_kernel<EPI, RF, NW, OCC, MODE>), grid, dim3(64 * NW), (g2_lds_bytes<EPI, RF>()), s, a);
+}
+
+// Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize (below it the call is harmless).  Called by
+// gl3_prefill_alloc for every plan, after hipSetDevice, like the attributes of the other kernels: the attribute belongs to the
+// (function, device) pair, and a once-per-process flag would leave a second device's plan — or a second in-process rank racing on
+// the flag — without it (r4 advisor finding).
+template <int EPI, int RF, int NW, int OCC>
+static hipError_t g2_allow_lds() {
+    hipError_t e = hipFuncSetAttribute((const void*)pf_gemm2_kernel<EPI, RF, NW, OCC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g2_lds_bytes<EPI, RF>());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)pf_gemm2_kernel<EPI, RF, NW, OCC, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g2_lds_bytes<EPI, RF>());
+}
+template <int EPI>
+static hipError_t g2_allow_lds_epi() {
+    hipError_t e = g2_allow_lds<EPI, 1, 4, 2>();
+    if constexpr (EPI != EPI_SWIGLU) {
+        if (e == hipSuccess) e = g2_allow_lds<EPI, 2, 4, 2>();
+        if (e == hipSuccess) e = g2_allow_lds<EPI, 1, 8, 1>();
+    }
+    return e;
+}
+hipError_t gl3_gemm2_allow_lds() {
+    hipError_t e = g2_allow_lds_epi<EPI_SWIGLU>();
+    if (e == hipSuccess) e = g2_allow_lds_epi<EPI_RESID>();
+    if (e == hipSuccess) e = g2_allow_lds_epi<EPI_STORE>();
+    return e;
 }
 
 // out[b][row] (=, +=, SwiGLU) for ntok > 64 tokens; tile shape by the matrix's row count so that the grid fills the chip:
@@ -41,33 +64,7 @@ static void g2_dispatch(GemmArgs a, int rows, int ntok, int mode, hipStream_t s)
 #undef GL3_G2
 }
 
-// One tile per wavefront, four wavefronts per SIMD (gl3_prefill_gemm4.h): 128-row workgroup tiles (16 wavefronts, one workgroup per
-// CU) when they give every CU a workgroup, else 64-row tiles (8 wavefronts, two workgroups per CU).
-template <int EPI, int WR>
-static void g4_launch(GemmArgs a, int rows, int ntok, hipStream_t s) {
-    constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1, RPM = 32 * WR / NM;
-    constexpr int LDS = G2_RING * g2_stage_bytes(32 * WR);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)pf_gemm4_kernel<EPI, WR, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-    a.ntt = (ntok + 127) / 128;
-    a.nrt = (rows + RPM - 1) / RPM;
-    hipLaunchKernelGGL((pf_gemm4_kernel<EPI, WR, 4>), dim3(8 * ((a.ntt * a.nrt + 7) / 8)), dim3(256 * WR), LDS, s, a);
-}
-template <int EPI>
-static void g4_dispatch(const GemmArgs& a, int rows, int ntok, hipStream_t s) {
-    constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1;
-    const int ntt = (ntok + 127) / 128;
-    if ((size_t)ntt * ((rows + 128 / NM - 1) / (128 / NM)) >= 256) g4_launch<EPI, 4>(a, rows, ntok, s);
-    else g4_launch<EPI, 2>(a, rows, ntok, s);
-}
-
 void gl3_gemm2_launch(int epi, const GemmArgs& a, int rows, int ntok, int mode, hipStream_t s) {
-    if (mode >= 4) {
-        if (epi == EPI_SWIGLU) g4_dispatch<EPI_SWIGLU>(a, rows, ntok, s);
-        else if (epi == EPI_RESID) g4_dispatch<EPI_RESID>(a, rows, ntok, s);
-        else g4_dispatch<EPI_STORE>(a, rows, ntok, s);
-        return;
-    }
     if (epi == EPI_SWIGLU) g2_dispatch<EPI_SWIGLU>(a, rows, ntok, mode, s);
     else if (epi == EPI_RESID) g2_dispatch<EPI_RESID>(a, rows, ntok, mode, s);
     else g2_dispatch<EPI_STORE>(a, rows, ntok, mode, s);

@@ -13,6 +13,7 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("GL3_LIB") or os.path.join(_DIR, "libgpullama_hip.so")      # GL3_LIB: an experimental build of the same library
 
 GL3_OK = 0
+E_ARG, E_UNSUPPORTED, E_OOM, E_HIP, E_RCCL, E_STATE = -1, -2, -3, -4, -5, -6
 ERR_NAMES = {0: "GL3_OK", -1: "GL3_E_ARG", -2: "GL3_E_UNSUPPORTED", -3: "GL3_E_OOM", -4: "GL3_E_HIP", -5: "GL3_E_RCCL",
              -6: "GL3_E_STATE"}
 FLAG_NO_GRAPH, FLAG_LAYER_TAPS, FLAG_FORCE_RCCL, FLAG_SCALAR_DOT, FLAG_F32_ACTIVATION = 1, 2, 4, 8, 16

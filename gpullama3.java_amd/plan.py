@@ -117,11 +117,20 @@ class HipMasterPlan:
                 L.gl3_gguf_tensor_info(g, i, C.byref(tn), None, None, None, None)
                 if tn.value == b"output.weight":
                     tied = False
+            # Devstral 2 ("mistral3"): the native loader uploads the YaRN table, so the host-side config must describe it too — an
+            # oracle or KV comparison built from plan.cfg would otherwise compute the plain table (r4 advisor finding)
+            ga = C.c_char_p()
+            gguf_arch = ga.value.decode() if L.gl3_gguf_meta_string(g, b"general.architecture", C.byref(ga)) == 0 else None
+            yf, ybf, ybs, ylm, yoc = C.c_float(), C.c_float(), C.c_float(), C.c_float(), C.c_int32()
+            yr = L.gl3_gguf_yarn_params(g, C.byref(yf), C.byref(ybf), C.byref(ybs), C.byref(ylm), C.byref(yoc))
+            if yr < 0:
+                raise hip.Gl3Error(hip.E_ARG, "mistral3.rope.scaling: factor and original_context_length must be finite and > 0")
+            yarn = (yf.value, ybf.value, ybs.value, ylm.value, yoc.value) if yr > 0 else None
         finally:
             L.gl3_gguf_close(g)
         self.cfg = synth.ModelConfig(nm, d.arch, d.dim, d.hidden, d.n_layers, d.n_heads, d.n_kv_heads, d.head_size, d.vocab, d.ctx,
                                      d.rms_eps, float(theta.value), tied, n_experts=d.n_experts, n_experts_used=d.n_experts_used,
-                                     moe_hidden=d.moe_hidden)
+                                     moe_hidden=d.moe_hidden, yarn=yarn, gguf_arch=gguf_arch if gguf_arch == "mistral3" else None)
         opts = hip.ModelDesc()
         opts.struct_size = C.sizeof(hip.ModelDesc)
         opts.ctx, opts.max_batch, opts.device, opts.tp_size, opts.flags, opts.n_seqs = ctx, prefill_batch_size, device, 1, flags, n_seqs

@@ -2,7 +2,6 @@
 runs the batched-prefill parity tests (tiny shapes to the 8B layer at 512 tokens) in its own pytest subprocess.
    default            r4 kernel (scale products on the matrix pipe) for gate/up, r3 kernel elsewhere   — covered by the normal suite
    GL3_PF_GEMM2_ALL=1 r4 kernel for EVERY shape (qkv / wo / down epilogues: store, residual)
-   GL3_PF_GEMM2=4     one tile per wavefront (pf_gemm4_kernel), every shape
    GL3_PF_GEMM2=1     -B s on the VALU
    GL3_PF_GEMM2=0     r3 kernel everywhere; GL3_PF_FUSED_ATTN=0: the three-kernel prefill attention"""
 import os
@@ -15,8 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("env", [{"GL3_PF_GEMM2_ALL": "1"}, {"GL3_PF_GEMM2": "4", "GL3_PF_GEMM2_ALL": "1"}, {"GL3_PF_GEMM2": "1", "GL3_PF_GEMM2_ALL": "1"},
-                                 {"GL3_PF_GEMM2": "0", "GL3_PF_FUSED_ATTN": "0"}], ids=["r4-all-shapes", "one-tile-per-wavefront", "nbs-on-valu", "r3-kernels"])
+@pytest.mark.parametrize("env", [{"GL3_PF_GEMM2_ALL": "1"}, {"GL3_PF_GEMM2": "1", "GL3_PF_GEMM2_ALL": "1"},
+                                 {"GL3_PF_GEMM2": "0", "GL3_PF_FUSED_ATTN": "0"}], ids=["r4-all-shapes", "nbs-on-valu", "r3-kernels"])
 def test_prefill_parity_of_a_gemm_form(env):
     e = dict(os.environ, **env)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_decode.py"), os.path.join(ROOT, "tests", "test_gpu_fullsize.py"),

@@ -12,7 +12,11 @@
 //           no begin-of-text; prompt token k at startPosition + k; after the LAST prompt token the position is advanced twice
 //           (`position++` and the loop's `++position`, :431,:413), so the first sampled token is forwarded at startPosition + N + 1
 //           and KV row startPosition + N stays as State left it (zero).  Mirrored exactly: a drop-in must produce the ids the
-//           reference produces, quirks included.
+//           reference produces, quirks included.  ONE deliberate deviation at the loop bound: the reference's qwen3 loop runs
+//           `position < maxTokens` with the raw maxTokens (:413), i.e. it generates nothing for maxTokens <= 0 and would index
+//           past the KV cache for maxTokens > contextLength; this tool needs a cache to size, so without -n it substitutes the
+//           file's context length and always stops at it.  Pass -n to get the reference's bound (for -n <= contextLength the
+//           id sequences are identical).
 // Sampling: temperature 0 = greedy (Sampler.TENSOR_ARGMAX, first index of the maximum); else gl3_forward_decode_sample with the
 // caller-side coin rng.nextFloat(1f) — RandomGeneratorFactory.getDefault().create(seed) = L32X64MixRandom in the reference
 // (J/inference/sampler/Sampler.java:76-123); --rng lcg selects java.util.Random instead.  One coin per sampled token.
