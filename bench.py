@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--wtype", default="q8_0", choices=["q8_0", "f16", "q4_0", "q8_0_f32act"],
                     help="ggml type of the matrices (default: the headline Q8_0); q8_0_f32act = Q8_0 with -Dllama.quantizeActivation=false "
                          "(f32 activation, Q8_0FloatTensor.vectorDot)")
+    ap.add_argument("--depth", default="", help="comma list of context depths (llama-bench -d): after the headline measurement, tg<n-gen> is timed again "
+                    "behind an untimed batched prefill of d positions (LlamaBench.runTest :233-254) and reported as depth_rows")
     ap.add_argument("--decode-batch", type=int, default=0, help="BASELINE configs[4]: static-batched decode of B independent sequences "
                     "(e.g. --model qwen3-4b --decode-batch 32); prints its own JSON line instead of the tg/pp line")
     args = ap.parse_args()
@@ -138,8 +140,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    depths = [int(x) for x in args.depth.split(",") if x.strip()]
     cfg = synth.CONFIGS[args.model]
-    cfg = synth.ModelConfig(**{**cfg.__dict__, "ctx": args.n_prompt + args.n_gen + 8})   # LlamaBench: max(depth+tokens)+8
+    cfg = synth.ModelConfig(**{**cfg.__dict__, "ctx": max([args.n_prompt + args.n_gen] + [d + args.n_gen for d in depths]) + 8})   # LlamaBench: max(depth+tokens)+8
     if args.decode_batch > 0:
         return bench_decode_batch(args, cfg, synth, plan_mod, pkg, torch, np, dev)
     t0 = time.time()
@@ -148,7 +151,7 @@ def main():
     WT = args.wtype.upper()
     bpe = {"q8_0": 34 / 32, "f16": 2.0, "q4_0": 18 / 32, "q8_0_f32act": 34 / 32}[args.wtype]          # weight bytes per element
     plan_flags = hip.FLAG_F32_ACTIVATION if args.wtype == "q8_0_f32act" else 0
-    toks = pkg.javarand.bench_tokens(cfg.vocab, args.n_prompt + args.n_gen)
+    toks = pkg.javarand.bench_tokens(cfg.vocab, max([args.n_prompt + args.n_gen] + [d + args.n_gen for d in depths]))
 
     def build_plan(transport):
         uid, exchange = None, None
@@ -224,6 +227,35 @@ def main():
                 row = dict(batch=b, error=str(e))
             pp_rows.append(row)
         pp = pp_rows[0]
+
+    # ---- llama-bench -d: tg behind an untimed prefill of d positions (token ids indexed by absolute position).  The KV rows below d
+    # are written ONCE per depth (the reference re-runs the untimed prefill before every repetition; the timed window is the same)
+    depth_rows = []
+    for d in depths:
+        try:
+            t_pf = time.perf_counter()
+            plan.prefill(toks[:d], 0, batch=args.batch if args.batch > 1 else None)
+            torch.cuda.synchronize()
+            t_pf = time.perf_counter() - t_pf
+
+            def tg_at_depth(d=d):
+                for i in range(args.n_gen):
+                    plan.forward_decode(toks[d + i], d + i, copy=False)
+            steps_d = max(1, min(args.steps, 3))
+            tot, smp = timed(tg_at_depth, steps_d, 1)
+            k = plan.profile_decode(toks[d + 64], d + 64)
+            att = k.get("attention", {})
+            kv_read = 2 * cfg.n_layers * (d + 64 + 1) * (cfg.kv_dim // world) * 4
+            depth_rows.append(dict(depth=d, test="tg%d@d%d" % (args.n_gen, d), tok_s=round(steps_d * args.n_gen / tot, 2), steps=steps_d,
+                                   samples_tok_s=[round(args.n_gen / x, 2) for x in smp], untimed_prefill_s=round(t_pf, 2),
+                                   attention_us_per_layer=round(att["ms"] * 1e3 / cfg.n_layers, 2) if att.get("launches") else None,
+                                   attention_launches_per_layer=(att["launches"] // cfg.n_layers) if att.get("launches") else None,
+                                   kv_read_bytes_per_token=int(kv_read),
+                                   kv_read_us_per_layer_at_hbm_peak=round(kv_read / cfg.n_layers / (HBM_PEAK_GBS * 1e9) * 1e6, 2)))
+        except hip.Gl3Error as e:
+            depth_rows.append(dict(depth=d, error=str(e)))
+    if depths:
+        plan.reset_kv()
 
     # ---- roofline of the dominant kernel: instrumented (eager, HIP events per launch) decode steps mid-sequence
     acc = None
@@ -372,6 +404,7 @@ def main():
                        "ctx": cfg.ctx, "tokens": "java.util.Random(42)"},
             "tg_tok_s_mean": round(float(mean), 3), "tg_tok_s_stddev": round(sd, 3),
             "pp": pp, "pp_rows": pp_rows,
+            **({"depth_rows": depth_rows} if depths else {}),
             "roofline": roofline, "roofline_pp": roofline_pp,
             "token_level": {"algorithmic_bytes_per_token": int(token_bytes), "achieved_gbs": round(token_gbs, 1),
                             "frac_of_hbm_peak": round(token_gbs / HBM_PEAK_GBS / max(world, 1), 4),

@@ -282,7 +282,15 @@ static int32_t all_gather(gl3_ctx* ctx, int which, int count_per_rank, Prof& pr)
     return GL3_OK;
 }
 
-static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores, 2 softmax+pv */, bool short_ctx = false) {
+// Decode attention by context depth (the host knows the position): ATT_SHORT = one launch (attn_head_kernel, positions < AF_MAXN),
+// ATT_MID = scores + the r2 softmax-and-PV kernel (two launches; below ~768 positions two more ~5 us launches cost more than the chains
+// they shorten: tg128@d256 18.5 vs 21.8 us per 8B layer, profiles/r05_tg_depth.md), ATT_LONG = scores, exp, sum, PV (gl3_decode_kernels.h).
+enum { ATT_LONG = 0, ATT_SHORT = 1, ATT_MID = 2 };
+static int attn_mode(const gl3_ctx* ctx, int pos) {
+    return (ctx->fused_attn_ok && pos < AF_MAXN) ? ATT_SHORT : pos < ctx->attn_mid ? ATT_MID : ATT_LONG;
+}
+
+static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores, 2 softmax+pv */, int amode = ATT_LONG) {
     const gl3_model_desc& d = ctx->d;
     gl3_layer& L = ctx->layers[l];
     const size_t kv_layer = (size_t)d.ctx * ctx->kv_dim_l;
@@ -297,17 +305,24 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
     const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 4) + d.head_size) * 4;
     const int pv_rows = d.ctx < PV_ROWS ? d.ctx : PV_ROWS;
     aa.win = ctx->attn_win;
+    aa.att_stride = (d.ctx + 3) & ~3;
+    aa.att_t = ctx->att_t; aa.tmax = ctx->att_tmax; aa.sums = ctx->att_sums;
     const size_t sm2 = ((size_t)ctx->attn_win + (size_t)pv_rows * PV_COLS) * 4;
-    if (which == 0 && short_ctx && ctx->fused_attn_ok) {      // positions < AF_MAXN: one launch
+    if (which == 0 && amode == ATT_SHORT && ctx->fused_attn_ok) {      // positions < AF_MAXN: one launch
         attn_head_dispatch(d.head_size, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ctx->heads_l), dim3(256), attn_head_smem(d.head_size), ctx->stream, aa); });
         return;
     }
     if (which != 2) hipLaunchKernelGGL(attn_scores_kernel, dim3(ctx->n_tsplit, ctx->kv_heads_l), dim3(64 * kvmul), sm1, ctx->stream, aa);
-    if (which != 1) hipLaunchKernelGGL(attn_softmax_pv_kernel, dim3(ctx->heads_l * (d.head_size / PV_COLS)), dim3(256), sm2, ctx->stream, aa);
+    if (which != 1 && amode == ATT_LONG) {
+        hipLaunchKernelGGL(attn_exp_kernel, dim3((d.ctx + EXP_ROW - 1) / EXP_ROW, ctx->heads_l), dim3(256), 0, ctx->stream, aa, ctx->n_tsplit);
+        hipLaunchKernelGGL(attn_sum_kernel, dim3(ctx->heads_l), dim3(256), attn_sum_smem(), ctx->stream, aa);
+        hipLaunchKernelGGL(attn_pv_kernel, dim3(ctx->kv_heads_l * attn_pv_hq(kvmul) * (d.head_size / PV_COLS16)), dim3(64 * PV_WAVES), attn_pv_smem(), ctx->stream, aa);
+    } else if (which != 1)
+        hipLaunchKernelGGL(attn_softmax_pv_kernel, dim3(ctx->heads_l * (d.head_size / PV_COLS)), dim3(256), sm2, ctx->stream, aa);
 }
 
-// short_ctx: the position is known (by the host) to be < AF_MAXN
-static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* kt, bool short_ctx) {
+// amode: attn_mode(position) — the host knows the position of the step
+static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* kt, int amode) {
     const gl3_model_desc& d = ctx->d;
     hipStream_t s = ctx->stream;
     Prof pr{ctx, kt};
@@ -333,7 +348,7 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         pr.end();
 
         pr.begin(GL3_K_ATTENTION, 0);
-        { Gl3Range g("rope + kv write + attention"); launch_attention(ctx, l, 0, short_ctx); }
+        { Gl3Range g("rope + kv write + attention"); launch_attention(ctx, l, 0, amode); }
         pr.end();
         if ((r = all_gather(ctx, GB_XB, ctx->q_dim_l, pr)) != GL3_OK) return r;
 
@@ -549,9 +564,9 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     ctx->kv_seq_stride = (size_t)d.n_layers * d.ctx * ctx->kv_dim_l;
     const size_t kvn = ctx->kv_seq_stride * ctx->n_seqs;
     TRY(dmalloc(ctx, &ctx->kcache, kvn));
-    TRY(dmalloc(ctx, &ctx->vcache, kvn));
+    TRY(dmalloc(ctx, &ctx->vcache, kvn + (size_t)PVT * ctx->kv_dim_l));      // + PVT rows: attn_pv_kernel's last tile reads past position n - 1 unclamped (masked)
     TRYHIP(hipMemset(ctx->kcache, 0, kvn * 4));
-    TRYHIP(hipMemset(ctx->vcache, 0, kvn * 4));
+    TRYHIP(hipMemset(ctx->vcache, 0, (kvn + (size_t)PVT * ctx->kv_dim_l) * 4));
     TRY(dmalloc(ctx, &ctx->xn, d.dim));
     TRY(dmalloc(ctx, &ctx->qkv, ctx->q_dim_l + 2 * ctx->kv_dim_l));
     if (ctx->use_rccl) {          // gathered buffers live in the tensor-parallel arena (one allocation the peers map, gl3_tp.hip)
@@ -565,7 +580,11 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
         TRY(dmalloc(ctx, &ctx->hb, d.hidden));
         TRY(dmalloc(ctx, &ctx->logits, d.vocab));
     }
-    TRY(dmalloc(ctx, &ctx->att, (size_t)ctx->heads_l * d.ctx));
+    TRY(dmalloc(ctx, &ctx->att, (size_t)ctx->heads_l * ((d.ctx + 3) & ~3)));      // score rows padded to float4 (AttnArgs.att_stride)
+    TRY(dmalloc(ctx, &ctx->att_t, attn_att_t_floats(ctx->kv_heads_l, d.n_heads / d.n_kv_heads, (d.ctx + 3) & ~3)));      // normalised weights, attn_pv_kernel's order (+ PVT rows: see vcache)
+    TRYHIP(hipMemset(ctx->att_t, 0, attn_att_t_floats(ctx->kv_heads_l, d.n_heads / d.n_kv_heads, (d.ctx + 3) & ~3) * 4));
+    TRY(dmalloc(ctx, &ctx->att_tmax, (size_t)ctx->heads_l * ctx->n_tsplit));
+    TRY(dmalloc(ctx, &ctx->att_sums, (size_t)ctx->heads_l));
     if (moe) TRY(moe_build_slots(ctx));          // after hb: the merged gate/up launch writes the shared expert's SwiGLU output there
     TRYHIP((allow_big_lds<PRO_RMS, EPI_STORE>()));
     TRYHIP((allow_big_lds<PRO_QUANT, EPI_RESID>()));
@@ -587,6 +606,8 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP(hipFuncSetAttribute((const void*)rmsnorm_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     TRYHIP(hipFuncSetAttribute((const void*)attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     TRYHIP(hipFuncSetAttribute((const void*)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    TRYHIP(hipFuncSetAttribute((const void*)attn_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_sum_smem()));
+    TRYHIP(hipFuncSetAttribute((const void*)attn_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_pv_smem()));
     // softmax rows longer than the LDS window (16384 positions; GL3_ATTN_WINDOW, a multiple of 1024, shrinks it for tests) run in
     // windows with the sequential sum carried across them: no cap on the context length (r2 rejected contexts above ~20 k)
     {
@@ -594,6 +615,9 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
         int wmax = wv && *wv ? atoi(wv) : 16384;
         if (wmax < PV_ROWS || wmax % PV_ROWS != 0 || wmax > 16384) return bail(GL3_E_ARG, "GL3_ATTN_WINDOW must be a multiple of 1024 between 1024 and 16384");
         ctx->attn_win = d.ctx <= wmax ? ((d.ctx + 3) & ~3) : wmax;
+        // depth below which the two-launch attention is used (GL3_ATTN_MID: 0 = always the four-launch long-context path)
+        const char* mv = getenv("GL3_ATTN_MID");
+        ctx->attn_mid = mv && *mv ? atoi(mv) : 768;
     }
     TRY(dmalloc(ctx, &ctx->dyn, 4));
     ctx->dyn_cur = ctx->dyn;
@@ -634,6 +658,8 @@ void gl3_destroy(gl3_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph_exec_s) hipGraphExecDestroy(ctx->graph_exec_s);
+    if (ctx->graph_exec_m) hipGraphExecDestroy(ctx->graph_exec_m);
+    if (ctx->graph_m) hipGraphDestroy(ctx->graph_m);
     if (ctx->graph_s) hipGraphDestroy(ctx->graph_s);
     if (ctx->graph) hipGraphDestroy(ctx->graph);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
@@ -652,7 +678,7 @@ void gl3_destroy(gl3_ctx* ctx) {
     f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->xn); f(ctx->qkv);
     if (!ctx->arena.base) { f(ctx->x); f(ctx->xb); f(ctx->hb); f(ctx->logits); }
     gl3_tp_arena_free(ctx);
-    f(ctx->att); f(ctx->dyn); f(ctx->dyn_seq); f(ctx->argmax); f(ctx->taps); f(ctx->staging);
+    f(ctx->att); f(ctx->att_t); f(ctx->att_tmax); f(ctx->att_sums); f(ctx->dyn); f(ctx->dyn_seq); f(ctx->argmax); f(ctx->taps); f(ctx->staging);
     for (auto& pr : ctx->pinned) hipHostUnregister(pr.first);
     ctx->pinned.clear();
     if (ctx->h_dyn) hipHostFree(ctx->h_dyn);
@@ -811,10 +837,10 @@ int32_t gl3_upload_rope(gl3_ctx* ctx, const float* cr, const float* ci, uint64_t
     return GL3_OK;
 }
 
-static int32_t capture(gl3_ctx* ctx, bool want_logits, bool short_ctx, hipGraph_t* g, hipGraphExec_t* ge) {
+static int32_t capture(gl3_ctx* ctx, bool want_logits, int amode, hipGraph_t* g, hipGraphExec_t* ge) {
     ctx->tp_dbg_prev_n4 = 0;
     GL3_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    int32_t r = enqueue_decode(ctx, want_logits, nullptr, short_ctx);
+    int32_t r = enqueue_decode(ctx, want_logits, nullptr, amode);
     hipError_t e = hipStreamEndCapture(ctx->stream, g);
     if (r != GL3_OK) return r;
     GL3_HIP(e);
@@ -854,10 +880,11 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
     ctx->finalized = true;
     if (!(d.flags & GL3_FLAG_NO_GRAPH) && !env_flag("GL3_NO_GRAPH", false) && !gl3_roctx_on()) {
         const double t0 = now_ms();
-        int32_t r = capture(ctx, true, false, &ctx->graph, &ctx->graph_exec);
-        if (r == GL3_OK && ctx->fused_attn_ok) r = capture(ctx, true, true, &ctx->graph_s, &ctx->graph_exec_s);
+        int32_t r = capture(ctx, true, ATT_LONG, &ctx->graph, &ctx->graph_exec);
+        if (r == GL3_OK && ctx->fused_attn_ok) r = capture(ctx, true, ATT_SHORT, &ctx->graph_s, &ctx->graph_exec_s);
+        if (r == GL3_OK && ctx->attn_mid > (ctx->fused_attn_ok ? AF_MAXN : 0)) r = capture(ctx, true, ATT_MID, &ctx->graph_m, &ctx->graph_exec_m);
         if (r != GL3_OK) {   // e.g. a collective that cannot be captured: run eagerly instead
-            ctx->graph_exec = nullptr; ctx->graph_exec_s = nullptr;
+            ctx->graph_exec = nullptr; ctx->graph_exec_s = nullptr; ctx->graph_exec_m = nullptr;
             (void)hipGetLastError();
             fprintf(stderr, "[gl3] hipGraph capture failed (%s); falling back to eager launches\n", ctx->err.c_str());
         }
@@ -878,14 +905,20 @@ static int32_t set_dyn(gl3_ctx* ctx, int32_t token, int32_t pos) {
     return GL3_OK;
 }
 
+static hipGraphExec_t step_graph(gl3_ctx* ctx, int amode) {
+    if (amode == ATT_SHORT && ctx->graph_exec_s) return ctx->graph_exec_s;
+    if (amode == ATT_MID && ctx->graph_exec_m) return ctx->graph_exec_m;
+    return ctx->graph_exec;          // the ATT_LONG step is correct at every position
+}
+
 int32_t gl3_forward_decode(gl3_ctx* ctx, int32_t token, int32_t pos, float* logits_out, int32_t* argmax_out) {
     if (!ctx) return GL3_E_ARG;
     int32_t r = set_dyn(ctx, token, pos);
     if (r != GL3_OK) return r;
     const bool want_logits = logits_out || argmax_out;
-    const bool short_ctx = ctx->fused_attn_ok && pos < AF_MAXN;
-    if (ctx->graph_exec && want_logits) GL3_HIP(hipGraphLaunch(short_ctx && ctx->graph_exec_s ? ctx->graph_exec_s : ctx->graph_exec, ctx->stream));
-    else if ((r = enqueue_decode(ctx, want_logits, nullptr, short_ctx)) != GL3_OK) return r;
+    const int amode = attn_mode(ctx, pos);
+    if (ctx->graph_exec && want_logits) GL3_HIP(hipGraphLaunch(step_graph(ctx, amode), ctx->stream));
+    else if ((r = enqueue_decode(ctx, want_logits, nullptr, amode)) != GL3_OK) return r;
     if (argmax_out) {
         hipLaunchKernelGGL(argmax_kernel, dim3(AMX_WGS), dim3(256), 0, ctx->stream, ctx->logits, ctx->d.vocab, ctx->argmax);
         GL3_HIP(hipMemcpyAsync(ctx->h_argmax, ctx->argmax, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -912,9 +945,9 @@ int32_t gl3_forward_decode_sample(gl3_ctx* ctx, int32_t token, int32_t pos, floa
     if (!(coin >= 0.f && coin < 1.f)) GL3_FAIL(GL3_E_ARG, "coin must be rng.nextFloat(1f): in [0, 1)");
     int32_t r = set_dyn(ctx, token, pos);
     if (r != GL3_OK) return r;
-    const bool short_ctx = ctx->fused_attn_ok && pos < AF_MAXN;
-    if (ctx->graph_exec) GL3_HIP(hipGraphLaunch(short_ctx && ctx->graph_exec_s ? ctx->graph_exec_s : ctx->graph_exec, ctx->stream));
-    else if ((r = enqueue_decode(ctx, true, nullptr, short_ctx)) != GL3_OK) return r;
+    const int amode = attn_mode(ctx, pos);
+    if (ctx->graph_exec) GL3_HIP(hipGraphLaunch(step_graph(ctx, amode), ctx->stream));
+    else if ((r = enqueue_decode(ctx, true, nullptr, amode)) != GL3_OK) return r;
     if ((r = gl3_sample_run(ctx, ctx->logits, temperature, topp, coin, token_out)) != GL3_OK) return r;
     return gl3_tp_check(ctx);
 }
@@ -957,7 +990,7 @@ int32_t gl3_forward_prefill_seq(gl3_ctx* ctx, int32_t seq, const int32_t* tokens
     int32_t r = GL3_OK;
     for (int i = 0; i < n && r == GL3_OK; ++i) {
         ctx->dyn_cur = ctx->dyn_seq + 2 * i;
-        r = enqueue_decode(ctx, false, nullptr, ctx->fused_attn_ok && start_pos + i < AF_MAXN);
+        r = enqueue_decode(ctx, false, nullptr, attn_mode(ctx, start_pos + i));
     }
     ctx->dyn_cur = ctx->dyn;
     if (r != GL3_OK) return r;
@@ -990,7 +1023,7 @@ int32_t gl3_profile_decode(gl3_ctx* ctx, int32_t token, int32_t pos, gl3_kernel_
     memset(out, 0, sizeof(*out));
     int32_t r = set_dyn(ctx, token, pos);
     if (r != GL3_OK) return r;
-    return enqueue_decode(ctx, true, out, ctx->fused_attn_ok && pos < AF_MAXN);
+    return enqueue_decode(ctx, true, out, attn_mode(ctx, pos));
 }
 
 int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* out_us, uint64_t* bytes_per_launch) {
@@ -1011,8 +1044,8 @@ int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* o
             case GL3_K_MATVEC_WO: launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->qkv, nullptr); break;
             case GL3_K_MATVEC_GATEUP: launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr); break;
             case GL3_K_MATVEC_DOWN: launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->qkv, nullptr); break;
-            case GL3_K_ATTENTION: launch_attention(ctx, l, 0, ctx->fused_attn_ok && ctx->h_dyn[1] < AF_MAXN); break;   // whole attention at the last position
-            case GL3_K_OTHER: launch_attention(ctx, l, 2); break;          // softmax + PV only
+            case GL3_K_ATTENTION: launch_attention(ctx, l, 0, attn_mode(ctx, ctx->h_dyn[1])); break;   // whole attention at the last position
+            case GL3_K_OTHER: launch_attention(ctx, l, 2, attn_mode(ctx, ctx->h_dyn[1]) == ATT_LONG ? ATT_LONG : ATT_MID); break;          // behind the scores only
             default: launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm, ctx->logits + (size_t)rank * ctx->vocab_l, nullptr); break;
             }
         }

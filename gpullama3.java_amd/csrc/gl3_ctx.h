@@ -148,6 +148,7 @@ struct gl3_ctx {
     int n_seqs = 1;
     size_t kv_seq_stride = 0;                     // floats per sequence
     float *x = nullptr, *qkv = nullptr, *xb = nullptr, *hb = nullptr, *logits = nullptr, *att = nullptr;
+    float *att_t = nullptr, *att_tmax = nullptr, *att_sums = nullptr;   // long-context decode: softmax numerators in attn_pv_kernel's operand order, per-tile score maxima, denominators
     float* xn = nullptr;                          // RMS-normalised activation (F16 / Q4_0 path only)
     float* taps = nullptr;                        // [L][dim] when GL3_FLAG_LAYER_TAPS
     // qwen2moe scratch (Qwen2MoEState.java:15-32): router logits [n_experts], routing weights [topk + 1] (last = shared-expert
@@ -177,6 +178,9 @@ struct gl3_ctx {
     hipGraphExec_t graph_exec = nullptr;          // decode step incl. logits
     hipGraph_t graph_s = nullptr;
     hipGraphExec_t graph_exec_s = nullptr;        // same step with the fused short-context attention (pos < AF_MAXN)
+    hipGraph_t graph_m = nullptr;
+    hipGraphExec_t graph_exec_m = nullptr;        // same step with the two-launch attention (AF_MAXN <= pos < attn_mid)
+    int attn_mid = 0;                             // see attn_mode (gl3_api.hip)
     bool fused_attn_ok = false;                   // shape admits attn_head_kernel (one launch per layer for positions < AF_MAXN)
     ncclComm_t comm = nullptr;
     gl3_local_group* lgrp = nullptr;

@@ -48,7 +48,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ long long gl3_mv_stamp[32];
 #define ATT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) gl3_mv_stamp[i] = wall_clock64(); } while (0)
 #define MV_STAMP(i, cond) do { if (blockIdx.x == 0 && (cond)) gl3_mv_stamp[i] = clock64(); } while (0)
+#define PV_T(...) __VA_ARGS__
 #else
+#define PV_T(...)
 #define MV_STAMP(i, cond)
 #define ATT_STAMP(i)
 #endif
@@ -502,6 +504,10 @@ struct AttnArgs {
     int qkv_stride, xb_stride;   // floats between consecutive tokens' rows of qkv / xb
     float att_mul;           // 0: score / sqrt(head_size); Granite: score * attentionScale (forwardGranite :870-872)
     int win;                 // attn_softmax_pv_kernel: floats of the softmax row held in LDS (a multiple of PV_ROWS); longer rows run in windows
+    int att_stride;          // floats between the score rows of consecutive heads in att (a multiple of 4, >= ctx)
+    float* att_t;            // softmax numerators e_t in attn_pv_kernel's operand order (attn_att_t_floats)
+    float* tmax;             // [n_heads][score tiles]: per-tile maxima of the scores (attn_scores_kernel -> attn_exp_kernel); NULL = not wanted
+    float* sums;             // [n_heads]: softmax denominators (attn_sum_kernel -> attn_pv_kernel)
     int group;               // attn_head_kernel: query heads per workgroup (0 / 1: one; kvMul: the whole group of a kv head)
     // attn_head_kernel, static-batched decode on one rank: the output leaves the kernel as the wo projection's int8 operand in the
     // small-batch layout (gl3_bd_gemm.h: XQ2 / XS2, xq_slots token slots) instead of f32 xb; NULL = write xb
@@ -612,6 +618,7 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
         }
     }
     const int hq = t >> 6, r = t & 63;           // wavefront = query head of the group, lane = timestep
+    float my_score = -INFINITY;
     if (hq < kvmul && t0 + r < t1) {
         const float* q = q_s + hq * hs;
         const float* kk = kt + r * pitch;
@@ -624,7 +631,13 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
         }
         score = score + qv.x * kv.x; score = score + qv.y * kv.y; score = score + qv.z * kv.z; score = score + qv.w * kv.w;
         const float sqrt_hs = (float)sqrt((double)hs);
-        a.att[(size_t)(kvh * kvmul + hq) * a.ctx + t0 + r] = a.att_mul != 0.f ? score * a.att_mul : score / sqrt_hs;
+        my_score = a.att_mul != 0.f ? score * a.att_mul : score / sqrt_hs;
+        a.att[(size_t)(kvh * kvmul + hq) * a.att_stride + t0 + r] = my_score;
+    }
+    // the tile's maximum per head (attn_exp_kernel folds the tiles: max is order-independent)
+    if (a.tmax && hq < kvmul) {
+        const float m = wave_max(my_score);
+        if (r == 0) a.tmax[(size_t)(kvh * kvmul + hq) * gridDim.x + sp] = m;
     }
 }
 
@@ -901,7 +914,7 @@ static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnA
     ATT_STAMP(0);
     stage_issue(0, min(n, PV_ROWS));
     ATT_STAMP(1);
-    const float* sc = a.att + (size_t)h * a.ctx;
+    const float* sc = a.att + (size_t)h * a.att_stride;
     const int W = a.win;                              // LDS window of the row
     float mx = -INFINITY, sum = 0.f;
     {   // softmax of the head: max, exp in double, strictly sequential f32 sum, divide (FloatTensor.softmaxInPlace :195-219)
@@ -977,6 +990,246 @@ static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnA
 #pragma unroll
         for (int r = 0; r < 4; ++r) a.xb[h * hs + j0 + 4 * (lane >> 4) + r] = acc[r];
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Long-context decode attention, round 5: the softmax and the weighted V sum as TWO launches shaped after what bounds them.
+// At depth (llama-bench -d) the one-launch pair above spends its time in two strictly sequential chains per workgroup: the
+// softmax denominator (n dependent adds at ~11 cycles each, recomputed by each of the hs / 16 workgroups of a head) and the
+// MFMA-fed weighted V sum (n / 4 dependent 16x16x4 steps of ~40 cycles): 87 us per 8B layer at depth 4096, 312 us at 16384
+// (profiles/r05_tg_depth.md).  Same arithmetic, same order, different evaluation:
+//   attn_softmax_kernel  one workgroup per query head: max; (float)exp((double)(s - max)); the strictly sequential f32 sum of
+//       the n non-negative numerators evaluated EXACTLY in parallel, 4096 at a time, each chunk continued from the exact running
+//       value of the previous one (gl3_seqsum.h, as the samplers do over the vocabulary); a_t = e_t / sum back into att[].
+//   attn_pv_kernel       one workgroup per (kv head, 16 output columns) serving four query heads of the group
+//       from one pass over V: lane (g, col) of the chain wavefront owns the chain xb[g][col] = a_t * v[t][col] + xb[g][col],
+//       t ascending, and does nothing but `acc = p + acc` on products the eight helper wavefronts rounded for it (one v_mul_f32
+//       each, straight from global operands) and parked in LDS in the chain's read order: one ds_read_b128 + four v_add_f32 per
+//       four timesteps = 5 issue slots per 4 steps for the wavefront everything waits for.  (A lone wavefront issues one
+//       instruction per 4 cycles, so computing the products itself would cost 8 cycles per timestep, through LDS-staged operands
+//       10; every product crosses LDS twice, 64 KB per 128-timestep tile = 80 % of what LDS moves in the chain's 640 cycles.)
+//       Workgroup ids are dealt so that the slabs of one kv head share an XCD (blockIdx % kv_heads = kv head): a V line is
+//       fetched into one L2, once.
+constexpr int PVT = 128;                   // timesteps per product tile
+constexpr int PV_G = 4, PV_COLS16 = 16;    // a workgroup serves PV_G query heads of one kv head x 16 output columns: 64 chains = one wavefront
+constexpr int PV_HELPERS = 8, PV_RING = 4;  // helper wavefronts (wavefront 0 is the chain); tiles their operands are requested ahead
+constexpr int PV_WAVES = 11;               // wavefronts per workgroup: chain, 8 helpers, and wavefronts 4 and 8 — the chain's SIMD neighbours — which retire at once
+constexpr int PV_QP = 64 * 4 + 4;          // floats per timestep quad in LDS: 64 lanes x 4 steps + 4 (the helpers' scattered 4-byte stores hit 64 different banks)
+__host__ __device__ constexpr size_t attn_pv_smem() { return (size_t)2 * (PVT / 4) * PV_QP * 4; }
+__host__ __device__ inline int attn_pv_hq(int kvmul) { return (kvmul + PV_G - 1) / PV_G; }       // groups of PV_G query heads per kv head
+// floats of the transposed weight buffer att_t[kv head][head quad][t][PV_G] (written by attn_softmax_kernel, read by attn_pv_kernel)
+__host__ __device__ inline size_t attn_att_t_floats(int kv_heads, int kvmul, int att_stride) { return (size_t)kv_heads * attn_pv_hq(kvmul) * att_stride * PV_G + (size_t)PVT * PV_G; }
+
+// Workgroup barrier for LDS hand-overs: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also waits for vmcnt(0) — every global load
+// a wavefront has in flight — which turns a prefetch issued in front of it into a full memory round trip per barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct LdsBarrier { __device__ __forceinline__ void operator()() const { lds_barrier(); } };      // Sync functor of exact_seqsum_lds
+
+constexpr int SMX_CHUNK = 4096;
+__host__ __device__ constexpr size_t attn_sum_smem() { return (size_t)(SMX_CHUNK + 32) * 4 + ss_scratch_bytes(SMX_CHUNK); }
+constexpr int EXP_ROW = 1024;              // scores per attn_exp_kernel workgroup
+
+// e_t = (float)exp((double)(s_t - max)) for EXP_ROW scores of one head: grid = (ceil(ctx / EXP_ROW), heads), 256 threads.  The double-precision
+// exp is ~250 instructions; one workgroup per head (the first form of this path) needed 7 us per 4096 scores for it alone — the VALU of one
+// CU — so it is spread over the chip.  max = fold of the per-tile maxima attn_scores_kernel left in tmax.  The numerators go to att_t in
+// attn_pv_kernel's operand order [kv head][head quad][t][PV_G] (the PV_G heads of a timestep are one 16-byte load there).
+static __global__ __launch_bounds__(256) void attn_exp_kernel(const AttnArgs a, int n_tiles_max) {
+    __shared__ float red_s[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int h = blockIdx.y, n = a.dyn[1] + 1;
+    const int i0 = blockIdx.x * EXP_ROW;
+    if (i0 >= n) return;
+    const int ntile = (n + ATT_TT - 1) / ATT_TT;
+    float mx = -INFINITY;
+    for (int i = t; i < ntile; i += 256) mx = fmaxf(mx, a.tmax[(size_t)h * n_tiles_max + i]);
+    mx = wave_max(mx);
+    if (lane == 0) red_s[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));
+    const int kvmul = a.n_heads / a.n_kv_heads, kvh = h / kvmul, gq = h % kvmul;
+    const float* sc = a.att + (size_t)h * a.att_stride;
+    float* at = a.att_t + (size_t)(kvh * attn_pv_hq(kvmul) + gq / PV_G) * a.att_stride * PV_G + (gq % PV_G);
+#pragma unroll
+    for (int u = 0; u < EXP_ROW / 256; ++u) {
+        const int i = i0 + t + 256 * u;
+        if (i < n) at[(size_t)i * PV_G] = (float)exp((double)(sc[i] - mx));
+    }
+}
+
+// The softmax denominator of one head: the strictly sequential f32 sum of its n numerators (FloatTensor.sum, J/tensor/standard/FloatTensor.java
+// :211-219), evaluated exactly in parallel 4096 at a time, each chunk continued from the exact running value of the previous one
+// (gl3_seqsum.h).  grid = heads, 256 threads.  The division e_t / sum happens where the weights are used (attn_pv_kernel's helpers).
+static __global__ __launch_bounds__(256) void attn_sum_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smx[];
+    float* xf = reinterpret_cast<float*>(smx);                        // [SMX_CHUNK + 32]
+    uint8_t* scratch = smx + (size_t)(SMX_CHUNK + 32) * 4;
+    __shared__ float run_s;
+    const int t = threadIdx.x;
+    const int h = blockIdx.x, n = a.dyn[1] + 1;
+    const int kvmul = a.n_heads / a.n_kv_heads, kvh = h / kvmul, gq = h % kvmul;
+    const float* at = a.att_t + (size_t)(kvh * attn_pv_hq(kvmul) + gq / PV_G) * a.att_stride * PV_G + (gq % PV_G);
+    if (t == 0) run_s = 0.f;
+    if (t < 32) xf[SMX_CHUNK + t] = 0.f;                              // zero padding behind the chunk (exact_seqsum_lds reads past the end)
+    // the chunk's numerators travel global -> registers -> LDS; the NEXT chunk's loads are in flight while this one is summed
+    // (unconditional loads, clamped index: elements past the end are zeroed on their way to LDS)
+    constexpr int PT = SMX_CHUNK / 256;
+    float cur[PT];
+#pragma unroll
+    for (int u = 0; u < PT; ++u) cur[u] = at[(size_t)min(t + 256 * u, n - 1) * PV_G];
+    for (int base = 0; base < n; base += SMX_CHUNK) {
+        const int len = min(SMX_CHUNK, n - base);
+#pragma unroll
+        for (int u = 0; u < PT; ++u) xf[t + 256 * u] = t + 256 * u < len ? cur[u] : 0.f;
+        const int nb = base + SMX_CHUNK;
+#pragma unroll
+        for (int u = 0; u < PT; ++u) cur[u] = at[(size_t)min(nb + t + 256 * u, n - 1) * PV_G];
+        lds_barrier();
+        float run = run_s;
+        const int n4 = len & ~3;
+        if (n4 >= 1024) {
+            LdsBarrier bb;
+            run = exact_seqsum_lds<false>(xf, n4, scratch, t, bb, run);
+            if (n4 < len && t < 64) run = naive_sumsq_lds<false>(xf, n4, len, run);      // at most 3 trailing elements
+        } else if (t < 64) {
+            run = seq_sum_lds_ring(xf, len, run);
+        }
+        lds_barrier();
+        if (t == 0) run_s = run;
+        lds_barrier();
+    }
+    if (t == 0) a.sums[h] = run_s;
+}
+
+// attn_pv_kernel: grid = kv heads x head quads x (head_size / 16) slabs, block = 64 x (1 + PV_HELPERS).
+//   chain (wavefront 0): lane (g, col) = (lane >> 4, lane & 15) owns xb[head quad * 4 + g][slab * 16 + col]; per 128-timestep tile
+//       32 ds_read_b128 (four consecutive timesteps of its chain) + 128 dependent v_add_f32.
+//   helpers: every helper wavefront prepares 16 rows of every tile.  Loads are shaped for the memory pipe, not for the chain: lane
+//       (r, c4) = (lane >> 2, lane & 3) takes v[row r][4 c4 .. 4 c4 + 3] and the PV_G numerators of that row with ONE 16-byte load
+//       each — 16 wave-level loads per tile instead of 192 (the first version of this kernel loaded per (chain lane, timestep): the
+//       texture addresser needs ~16 cycles per 64-lane instruction and the whole workgroup waited for it: 12.9 cycles per
+//       timestep, profiles/r05_tg_depth.md) — divides by the heads' denominators, multiplies out (16 products, each one rounding) and
+//       scatters them with 4-byte LDS stores into the chain's order.
+static __global__ __launch_bounds__(64 * PV_WAVES) void attn_pv_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float pbuf[];              // [2][PVT / 4][PV_QP]
+    const int hs = a.hs, kvmul = a.n_heads / a.n_kv_heads, hq_n = attn_pv_hq(kvmul);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int kvh = blockIdx.x % a.n_kv_heads, rest = blockIdx.x / a.n_kv_heads, hq = rest % hq_n, slab = rest / hq_n;
+    const int n = a.dyn[1] + 1;
+    const int ntiles = (n + PVT - 1) / PVT;
+    constexpr int QPT = PVT / 4;                                             // timestep quads per tile
+    if (wave == 0) {
+        // ------------------------------------------------------------------ chain: acc = p_t + acc, t ascending
+        __builtin_amdgcn_s_setprio(3);
+        const int g = hq * PV_G + (lane >> 4), col = lane & 15;
+        float acc = 0.f;
+        PV_T(long long tw_ = 0; const long long ts_ = clock64();)
+        for (int k = 0; k < ntiles; ++k) {
+            PV_T(const long long b0_ = clock64();)
+            lds_barrier();                                                 // tile k is complete (and tile k - 1 may be overwritten)
+            PV_T(tw_ += clock64() - b0_;)
+            const float* pb = pbuf + (size_t)(k & 1) * QPT * PV_QP + 4 * lane;
+            // eight quads per group, the next group's reads in flight under this group's 32 dependent adds
+            float4 ra[8], rb[8];
+#define PV_RD8(R_, Q0_) do { _Pragma("unroll") for (int u = 0; u < 8; ++u) R_[u] = *reinterpret_cast<const float4*>(pb + ((Q0_) + u) * PV_QP); } while (0)
+            // sixteen adds as ONE asm statement: the compiler then waits once for the four quads (s_waitcnt lgkmcnt(n) in front of the
+            // statement) instead of once per quad — every s_waitcnt is an issue slot of the wavefront the whole workgroup waits for
+#define PV_ADD4Q(A_, B_, C_, D_) asm volatile( \
+                "v_add_f32 %0, %1, %0\n\tv_add_f32 %0, %2, %0\n\tv_add_f32 %0, %3, %0\n\tv_add_f32 %0, %4, %0\n\t" \
+                "v_add_f32 %0, %5, %0\n\tv_add_f32 %0, %6, %0\n\tv_add_f32 %0, %7, %0\n\tv_add_f32 %0, %8, %0\n\t" \
+                "v_add_f32 %0, %9, %0\n\tv_add_f32 %0, %10, %0\n\tv_add_f32 %0, %11, %0\n\tv_add_f32 %0, %12, %0\n\t" \
+                "v_add_f32 %0, %13, %0\n\tv_add_f32 %0, %14, %0\n\tv_add_f32 %0, %15, %0\n\tv_add_f32 %0, %16, %0" \
+                : "+v"(acc) : "v"((A_).x), "v"((A_).y), "v"((A_).z), "v"((A_).w), "v"((B_).x), "v"((B_).y), "v"((B_).z), "v"((B_).w), \
+                              "v"((C_).x), "v"((C_).y), "v"((C_).z), "v"((C_).w), "v"((D_).x), "v"((D_).y), "v"((D_).z), "v"((D_).w))
+#define PV_ADD8(R_) do { PV_ADD4Q(R_[0], R_[1], R_[2], R_[3]); PV_ADD4Q(R_[4], R_[5], R_[6], R_[7]); } while (0)
+            PV_RD8(ra, 0);
+            PV_RD8(rb, 8);
+            __builtin_amdgcn_sched_barrier(0);
+            PV_ADD8(ra);
+            __builtin_amdgcn_sched_barrier(0);
+            PV_RD8(ra, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            PV_ADD8(rb);
+            __builtin_amdgcn_sched_barrier(0);
+            PV_RD8(rb, 24);
+            __builtin_amdgcn_sched_barrier(0);
+            PV_ADD8(ra);
+            __builtin_amdgcn_sched_barrier(0);
+            PV_ADD8(rb);
+#undef PV_ADD4Q
+#undef PV_ADD8
+#undef PV_RD8
+        }
+        if (g < kvmul) a.xb[(size_t)(kvh * kvmul + g) * hs + slab * PV_COLS16 + col] = acc;
+        PV_T(if (blockIdx.x == 0 && lane == 0) { gl3_mv_stamp[0] = tw_; gl3_mv_stamp[1] = clock64() - ts_; })
+        return;
+    }
+    // ---------------------------------------------------------------------- helpers
+    // Helper wavefront hw prepares the 16 rows hw 16 .. hw 16 + 15 of EVERY tile: two 16-byte loads (v, the PV_G numerators) requested
+    // PV_RING tiles ahead into a ring of named registers, then per tile 4 divisions (a = e / sum: FloatTensor.divideInPlace of the
+    // softmax), 16 products and 16 scattered LDS stores — short enough to hide behind the chain's tile.
+    // Wavefronts are dealt to the four SIMDs of a CU in turn: 4 and 8 would share the chain's SIMD and its issue slots — they retire
+    // (a finished wavefront no longer counts at s_barrier), so the chain has its SIMD to itself.
+    if (wave == 4 || wave == 8) return;
+    const int hw = wave - 1 - (wave > 4) - (wave > 8);
+    static_assert(PV_HELPERS * 16 == PVT && PV_WAVES == PV_HELPERS + 3, "one 16-row group per helper wavefront and tile");
+    const int r = lane >> 2, c4 = lane & 3;
+    // wave-uniform bases (scalar registers) + one 32-bit lane offset per stream
+    const float* vbase = a.vcache + (size_t)kvh * hs + slab * PV_COLS16 + (size_t)(hw * 16) * a.kv_dim;
+    const float* abase = a.att_t + ((size_t)(kvh * hq_n + hq) * a.att_stride + hw * 16) * PV_G;
+    const unsigned vlane = (unsigned)r * a.kv_dim + 4 * c4;
+    // LDS: row (in tile) rt = hw 16 + r -> quad rt >> 2, step rt & 3; product (g, 4 c4 + jj) -> chain lane g 16 + 4 c4 + jj
+    float* pst = pbuf + (size_t)((hw * 16 + r) >> 2) * PV_QP + (r & 3) + 16 * c4;
+    // Lane (r, c4) divides ONE numerator per tile — head c4 of row r: the 16 rows x PV_G heads of the wavefront are exactly its 64 lanes —
+    // and reads the other three heads' weights of its row from its quad neighbours as DPP operands of the multiplies (quad = the four
+    // lanes of a row).  (Four divisions per lane, each repeated by the row's four lanes, were a third of the helpers' instructions; with
+    // three helper wavefronts on a SIMD their instruction count, not the chain, set the tile time: profiles/r05_tg_depth.md.)
+    const float smq = a.sums[kvh * kvmul + min(hq * PV_G + c4, kvmul - 1)];   // denominator of head c4 (heads past kvMul: clamped, unused)
+    float4 v0, v1, v2, v3;                                                   // the ring (named: an array carried across the barriers would live in scratch)
+    float e0, e1, e2, e3;
+    // The last tile's loads run up to PVT - 1 rows past position n - 1: vcache and att_t are allocated with that much slack, and what
+    // they return is masked in PVH_STORE.  Loads are unconditional (tile index clamped): a load under a branch is waited for at its end.
+#define PVH_LOAD(S_, K_) do { \
+        const int kc_ = min((K_), ntiles - 1); \
+        v##S_ = *reinterpret_cast<const float4*>(vbase + (size_t)kc_ * PVT * a.kv_dim + vlane); \
+        e##S_ = (abase + (size_t)kc_ * PVT * PV_G)[(unsigned)lane]; \
+    } while (0)
+#define PVH_QUAD(X_, G_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, X_), 0x55 * (G_), 0xf, 0xf, false))      /* lane G_ of my quad */
+#define PVH_STORE_G(P_, A_, V_, G_) do { const float ag_ = PVH_QUAD(A_, G_); \
+        (P_)[64 * (G_) + 0] = ag_ * (V_).x; (P_)[64 * (G_) + 4] = ag_ * (V_).y; (P_)[64 * (G_) + 8] = ag_ * (V_).z; (P_)[64 * (G_) + 12] = ag_ * (V_).w; } while (0)
+#define PVH_STORE(S_, K_) do { \
+        float* pb_ = pst + (size_t)((K_) & 1) * QPT * PV_QP; \
+        float4 v_ = v##S_; \
+        float a_ = e##S_ / smq;                             /* softmaxInPlace's divideInPlace(sum) */ \
+        if ((K_) == ntiles - 1) {                           /* +0 pads the timesteps past the end: acc + 0 = acc (acc is never -0) */ \
+            const bool in_ = (K_) * PVT + hw * 16 + r < n; \
+            a_ = in_ ? a_ : 0.f; \
+            v_.x = in_ ? v_.x : 0.f; v_.y = in_ ? v_.y : 0.f; v_.z = in_ ? v_.z : 0.f; v_.w = in_ ? v_.w : 0.f; \
+        } \
+        PVH_STORE_G(pb_, a_, v_, 0); PVH_STORE_G(pb_, a_, v_, 1); PVH_STORE_G(pb_, a_, v_, 2); PVH_STORE_G(pb_, a_, v_, 3); \
+    } while (0)
+#define PVH_STEP(S_, K_) do { \
+        if ((K_) < ntiles) {                                /* wave-uniform; the chain runs exactly ntiles barriers */ \
+            PV_T(const long long s0_ = clock64();) \
+            PVH_STORE(S_, (K_));                            /* buffer K & 1: the chain finished tile K - 2 before the last barrier */ \
+            PV_T(const long long b0_ = clock64(); tst_ += b0_ - s0_;) \
+            lds_barrier(); \
+            PV_T(tw_ += clock64() - b0_;) \
+        } \
+        PVH_LOAD(S_, (K_) + PV_RING);                       /* behind the barrier, PV_RING tiles ahead */ \
+    } while (0)
+    PV_T(long long tw_ = 0, tst_ = 0; const long long ts_ = clock64();)
+    PVH_LOAD(0, 0); PVH_LOAD(1, 1); PVH_LOAD(2, 2); PVH_LOAD(3, 3);
+    for (int k = 0; k < ntiles; k += PV_RING) {
+        PVH_STEP(0, k); PVH_STEP(1, k + 1); PVH_STEP(2, k + 2); PVH_STEP(3, k + 3);
+    }
+    PV_T(if (blockIdx.x == 0 && hw == 0 && lane == 0) { gl3_mv_stamp[2] = tw_; gl3_mv_stamp[3] = tst_; gl3_mv_stamp[4] = clock64() - ts_; })
+#undef PVH_LOAD
+#undef PVH_STORE
+#undef PVH_STORE_G
+#undef PVH_QUAD
+#undef PVH_STEP
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 5, call 7: whole GPU suite with the three attention regimes; bench at depth (final form) + its kernel statistics
+set -u
+O=gpurun_out/r5_call7; mkdir -p $O
+export TMPDIR=/tmp
+( timeout 1500 python -m pytest tests -m gpu -x -q --timeout 600 2>&1 | tail -6 ) > $O/pytest.log 2>&1; echo "== pytest"; tail -3 $O/pytest.log
+( timeout 600 python bench.py --steps 3 --warmup 1 --depth 256,512,1024,4096,16384 --no-pp 2> $O/bench_depth.err | tail -1 ) > $O/bench_depth.json; echo "== bench depth"; python - <<PY
+import json
+try:
+    d = json.load(open("$O/bench_depth.json"))
+    print("tg128", d["value"])
+    for r in d.get("depth_rows", []): print({k: r[k] for k in ("test", "tok_s", "attention_us_per_layer", "kv_read_us_per_layer_at_hbm_peak") if k in r} or r)
+except Exception as e:
+    print("no json:", e); print(open("$O/bench_depth.err").read()[-2000:])
+PY

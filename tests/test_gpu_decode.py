@@ -150,7 +150,8 @@ def test_graph_and_eager_launches_agree_bitwise(pkg, orc, planmod):
 @pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "mid-qwen2", "mha-llama", "mid-granite", "phi3-hs96"])   # head sizes 64 / 128 / 96, kvMul 4 / 6 / 1
 def test_fused_short_context_attention_and_the_handover_at_128(pkg, orc, planmod, cfg):
     """Positions < 128 run attn_head_kernel (one launch per layer, one workgroup per query head), later ones the scores +
-    softmax/PV pair; both must reproduce the oracle bit for bit, also across the handover, and agree with each other."""
+    softmax/PV pair (positions < 768) or — `deep`, with GL3_ATTN_MID=0 right behind 128 — the four-launch long-context path (scores,
+    exp, exact parallel sum, chain-wavefront PV: r5); all must reproduce the oracle bit for bit, also across the handover."""
     plan_mod, hip = planmod
     base = pkg.synth.CONFIGS[cfg]
     m = pkg.synth.make_numpy(pkg.synth.ModelConfig(**{**base.__dict__, "ctx": 160}), seed=29)
@@ -160,23 +161,31 @@ def test_fused_short_context_attention_and_the_handover_at_128(pkg, orc, planmod
         plain = plan_mod.HipMasterPlan(m)
     finally:
         os.environ.pop("GL3_NO_FUSED_ATTN", None)
+    os.environ["GL3_ATTN_MID"] = "0"
+    try:
+        deep = plan_mod.HipMasterPlan(m)
+    finally:
+        os.environ.pop("GL3_ATTN_MID", None)
     o = orc.COracle(m)
     toks = pkg.javarand.bench_tokens(m.cfg.vocab, 134)
     for pos in range(122):
         plan.forward_decode(toks[pos], pos, copy=False)
         plain.forward_decode(toks[pos], pos, copy=False)
+        deep.forward_decode(toks[pos], pos, copy=False)
     o.prefill(toks[:122], 0)
     for pos in range(122, 134):
         ref = o.forward(toks[pos], pos)
         got = plan.forward_decode(toks[pos], pos)
         assert np.array_equal(got, ref), (pos, rel(got, ref))
         assert np.array_equal(plain.forward_decode(toks[pos], pos), ref), pos
+        got = deep.forward_decode(toks[pos], pos)
+        assert np.array_equal(got, ref), ("long-context path", pos, rel(got, ref))
     for l in range(m.cfg.n_layers):
         for p in (0, 60, 127, 128, 133):
             k, v = plan.kv(l, p)
             ko, vo = o.kv(l, p)
             assert np.array_equal(k, ko) and np.array_equal(v, vo)
-    plan.freeTornadoExecutionPlan(); plain.freeTornadoExecutionPlan()
+    plan.freeTornadoExecutionPlan(); plain.freeTornadoExecutionPlan(); deep.freeTornadoExecutionPlan()
 
 
 def test_sequential_prefill_then_decode(pkg, orc, planmod):
@@ -375,21 +384,37 @@ def test_native_gguf_loader_builds_the_same_plan(pkg, orc, planmod, tmp_path, cf
 
 
 def test_native_bench_host_over_the_c_abi(pkg, orc, planmod, tmp_path):
-    """tools/gl3_bench (plain C++, links only the C-ABI): loads a GGUF natively, runs the LlamaBench protocol and must produce
-    the same greedy ids as the Python host for the java.util.Random(42) token stream."""
+    """tools/gl3_bench (plain C++, links only the C-ABI): loads a GGUF natively, runs the LlamaBench protocol (test names, -b, -d, -pg,
+    output formats of J/bench/LlamaBench.java:52-59,99-109,309-372) and must produce the same greedy ids as the CPU oracle for the
+    java.util.Random(42) token stream — at depth 0 and behind an untimed prefill of -d positions (ids indexed by absolute position)."""
+    import json
     import subprocess
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], seed=23)
-    path = str(tmp_path / "m.gguf")
+    path = str(tmp_path / "tiny.gguf")
     m.write_gguf(path)
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gl3_bench")
     out = subprocess.run([exe, "-m", path, "-p", "16", "-n", "12", "-b", "8", "-r", "1", "--ids"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    assert "| tiny-llama-random | pp16 -b 8 |" in out.stdout and "| tiny-llama-random | tg12 |" in out.stdout
-    ids = [int(x) for x in out.stdout.split("greedy ids:")[1].split()]
+    assert "| tiny | Q8_0 |" in out.stdout and "| pp16 b8 |" in out.stdout and "| tg12 b8 |" in out.stdout
+    ids = [int(x) for x in out.stderr.split("greedy ids:")[1].split("\n")[0].split()]
     o = orc.COracle(pkg.synth.SynthModel.from_gguf(path))
-    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 16)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 40)
     assert ids == [orc.argmax(o.forward(toks[i], i)) for i in range(12)]          # greedy ids of the CPU oracle on the same file
+    # -d 20: 20 positions prefilled untimed (chunks of 8), then tg at positions 20 ..; -pg; json output with one row per test
+    out = subprocess.run([exe, "-m", path, "-n", "6", "-pg", "8,4", "-d", "0,20", "-b", "8", "-r", "2", "-o", "json", "--ids"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rows = json.loads(out.stdout)
+    assert [r["test"] for r in rows] == ["tg6 b8", "pp8+tg4 b8", "tg6@d20 b8", "pp8+tg4@d20 b8"]
+    assert all(r["model"] == "tiny" and r["quant"] == "Q8_0" and len(r["samples_ts"]) == 2 and r["avg_ts"] > 0 for r in rows)
+    id_lines = [[int(x) for x in l.split(":")[1].split()] for l in out.stderr.splitlines() if l.startswith("greedy ids:")]
+    o2 = orc.COracle(pkg.synth.SynthModel.from_gguf(path))
+    o2.prefill(toks[:20], 0)
+    assert id_lines[2] == [orc.argmax(o2.forward(toks[20 + i], 20 + i)) for i in range(6)]      # tg6@d20
+    for fmt, needle in (("csv", "model,quant,size_gib,params_b,backend,test,avg_ts,stddev_ts,samples"), ("sql", "INSERT INTO llama_bench VALUES ('tiny', 'Q8_0',"),
+                        ("jsonl", '{"model": "tiny", "quant": "Q8_0",')):
+        out = subprocess.run([exe, "-m", path, "-p", "8", "-n", "0", "-r", "1", "--no-warmup", "-o", fmt], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and needle in out.stdout, (fmt, out.stdout, out.stderr)
 
 
 @pytest.mark.parametrize("cfg,window", [("tiny-llama", None), ("tiny-qwen3", None), ("tiny-llama", 1024), ("phi3-hs96", 1024)])
