@@ -94,7 +94,11 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
                     if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_STORE, true, VL_RMS_WAVES>), rg, rb, rs, s, v); \
                     else hipLaunchKernelGGL((matvec_vl_kernel<WT_, EPI_SWIGLU, true, VL_RMS_WAVES>), rg, rb, rs, s, v); \
                 } while (0)
-                if (w.fmt == GL3_TYPE_F16) GL3_VLR(WT_F16); else if (w.fmt == GL3_FMT_Q8V) GL3_VLR(WT_Q8_0); else GL3_VLR(WT_Q4_0);
+                if (w.fmt == GL3_TYPE_F16 && (ctx->d.flags & GL3_FLAG_VECTOR_512)) {          // 16 accumulator lanes (FP16FloatTensor.vectorDot on a 512-bit species)
+                    if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_vl_kernel<WT_F16, EPI_STORE, true, VL_RMS_WAVES, 512>), rg, rb, rs, s, v);
+                    else hipLaunchKernelGGL((matvec_vl_kernel<WT_F16, EPI_SWIGLU, true, VL_RMS_WAVES, 512>), rg, rb, rs, s, v);
+                }
+                else if (w.fmt == GL3_TYPE_F16) GL3_VLR(WT_F16); else if (w.fmt == GL3_FMT_Q8V) GL3_VLR(WT_Q8_0); else GL3_VLR(WT_Q4_0);
 #undef GL3_VLR
                 return;
             }
@@ -119,7 +123,12 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
                 const dim3 qg(ngroups), qb(64 * nw); \
                 if (nw == 16) GL3_VLQ_E(WT_, 16); else GL3_VLQ_E(WT_, 8); \
             } while (0)
-            if (w.fmt == GL3_TYPE_F16) GL3_VL(WT_F16);
+            if (w.fmt == GL3_TYPE_F16 && (ctx->d.flags & GL3_FLAG_VECTOR_512)) {
+                if (epi == EPI_STORE) hipLaunchKernelGGL((matvec_vl_kernel<WT_F16, EPI_STORE, false, VL_WAVES, 512>), vg, vb, vs, s, v);
+                else if (epi == EPI_RESID) hipLaunchKernelGGL((matvec_vl_kernel<WT_F16, EPI_RESID, false, VL_WAVES, 512>), vg, vb, vs, s, v);
+                else hipLaunchKernelGGL((matvec_vl_kernel<WT_F16, EPI_SWIGLU, false, VL_WAVES, 512>), vg, vb, vs, s, v);
+            }
+            else if (w.fmt == GL3_TYPE_F16) GL3_VL(WT_F16);
             else if (w.fmt == GL3_FMT_Q8V) { if (ksplit) GL3_VLQ(WT_Q8_0); else GL3_VL(WT_Q8_0); }
             else { if (ksplit) GL3_VLQ(WT_Q4_0); else GL3_VL(WT_Q4_0); }
 #undef GL3_VLQ
@@ -476,6 +485,19 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     if (d.weight_type != GL3_TYPE_Q8_0 && d.weight_type != GL3_TYPE_F16 && d.weight_type != GL3_TYPE_Q4_0)
         return bail(GL3_E_UNSUPPORTED, "matrix weight type must be Q8_0, F16 or Q4_0");
     const bool q8v = d.weight_type == GL3_TYPE_Q8_0 && (d.flags & GL3_FLAG_F32_ACTIVATION);
+    {   // the Vector-API species (-Dllama.VectorBitSize; include/gpullama3_hip.h): 256 by default, 512 for F16 decode, the rest refused
+        const bool species_type = d.weight_type == GL3_TYPE_F16 || d.weight_type == GL3_TYPE_Q4_0 || q8v;
+        if ((d.flags & GL3_FLAG_VECTOR_512) && (d.flags & GL3_FLAG_VECTOR_128)) return bail(GL3_E_ARG, "GL3_FLAG_VECTOR_512 and GL3_FLAG_VECTOR_128 exclude each other");
+        if ((d.flags & (GL3_FLAG_VECTOR_512 | GL3_FLAG_VECTOR_128)) && (d.flags & GL3_FLAG_SCALAR_DOT))
+            return bail(GL3_E_ARG, "a vector species and GL3_FLAG_SCALAR_DOT (-Dllama.VectorBitSize=0) exclude each other");
+        if ((d.flags & GL3_FLAG_VECTOR_128) && species_type)
+            return bail(GL3_E_UNSUPPORTED, "the 128-bit Vector-API species (4 accumulator lanes) is restated in the oracles only; run the JVM with -Dllama.VectorBitSize=256");
+        if ((d.flags & GL3_FLAG_VECTOR_512) && species_type && d.weight_type != GL3_TYPE_F16)
+            return bail(GL3_E_UNSUPPORTED, "Q4_0 / Q8_0 (f32 activation) have no 512-bit vector dot: the reference throws UnsupportedOperationException (Q4_0FloatTensor.java:118-120, "
+                                           "Q8_0FloatTensor.java:165-167); run the JVM with -Dllama.VectorBitSize=256");
+        if ((d.flags & GL3_FLAG_VECTOR_512) && d.weight_type == GL3_TYPE_F16 && d.tp_size > 1)
+            return bail(GL3_E_UNSUPPORTED, "the 512-bit F16 species is built for one rank");
+    }
     if ((d.flags & GL3_FLAG_F32_ACTIVATION) && d.weight_type != GL3_TYPE_Q8_0)
         return bail(GL3_E_ARG, "GL3_FLAG_F32_ACTIVATION applies to Q8_0 matrices");
     if (q8v && (d.flags & GL3_FLAG_SCALAR_DOT))
@@ -632,7 +654,8 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     // (GL3_FLAG_SCALAR_DOT) prefills token by token.
     {
         const bool int8_path = d.weight_type == GL3_TYPE_Q8_0 && !(d.flags & GL3_FLAG_F32_ACTIVATION);
-        const bool vl_path = !int8_path && !(d.flags & GL3_FLAG_SCALAR_DOT);      // r4: tensor-parallel ranks too (rank-chunked activations)
+        // (the 512-bit F16 species has decode kernels only: its prefill chunks run token by token, like the scalar order)
+        const bool vl_path = !int8_path && !(d.flags & GL3_FLAG_SCALAR_DOT) && !(d.flags & GL3_FLAG_VECTOR_512);      // r4: tensor-parallel ranks too (rank-chunked activations)
         if (d.max_batch > 1 && (int8_path || vl_path) && !moe) TRY(gl3_prefill_alloc(ctx));
     }
     if (getenv("GL3_DEBUG_ALLOC")) {

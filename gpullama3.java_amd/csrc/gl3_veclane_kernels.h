@@ -169,10 +169,15 @@ __device__ __forceinline__ float q4_mul(float x, const Q4Planes& pl, float negze
 // RMS = true (qkv, gate / up, logits): InferenceCore.rmsnorm (:39-48) runs in the prologue — every workgroup computes the exact
 // in-order sum of squares of the residual stream itself (gl3_seqsum.h, 256 threads) while its first weight chunks are in flight,
 // instead of a one-workgroup rmsnorm_f32_kernel launch in front of the matvec (9.3 us + a launch boundary, twice per layer).
-template <int WT, int EPI, bool RMS = false, int VW = VL_WAVES>
+// SPECIES = 512 (F16 only, GL3_FLAG_VECTOR_512): FP16FloatTensor.vectorDot is species-generic — on an AVX-512 host it keeps 16 accumulator
+// lanes, lane j = elements j, j + 16, ....  The VL layout gives lane l of a row the elements l + 8 kk of every 64-element chunk: even kk
+// are accumulator lane l of the 16, odd kk lane l + 8, each in ascending element order — so the same loads feed TWO chains per thread,
+// and reduceLanes adds the eight even chains in lane order, then the eight odd ones.
+template <int WT, int EPI, bool RMS = false, int VW = VL_WAVES, int SPECIES = 256>
 static __global__ __launch_bounds__(64 * VW, WT == WT_F16 ? 1 : 2) void matvec_vl_kernel(const VlArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xT[];
     static_assert(!RMS || VW == 4, "exact_sumsq_lds: 256 threads");
+    static_assert(SPECIES == 256 || (SPECIES == 512 && WT == WT_F16), "the Q8_0 / Q4_0 vector dots have no 512-bit form (the reference throws)");
     constexpr int VL_WAVES = VW;
     constexpr int NM = EPI == EPI_SWIGLU ? 2 : 1;
     // Chunks in flight per wavefront (4 or 8 VGPRs each; 16 KB / 9 KB of the weight stream per wavefront and matrix)
@@ -268,9 +273,9 @@ static __global__ __launch_bounds__(64 * VW, WT == WT_F16 ? 1 : 2) void matvec_v
     __syncthreads();
     if (!live) return;
 
-    float acc[NM];
+    float acc[NM], acc2[NM];                          // acc2: accumulator lanes 8..15 of a 512-bit species
 #pragma unroll
-    for (int m = 0; m < NM; ++m) acc[m] = 0.f;
+    for (int m = 0; m < NM; ++m) { acc[m] = 0.f; acc2[m] = 0.f; }
     const Q4Consts qc = q4_consts();
     // One chunk of the 8 accumulator chains.  The chunk's activation operands (xa) were fetched from LDS while the previous
     // chunk was computed; this call fetches the next chunk's (xb).
@@ -287,8 +292,11 @@ static __global__ __launch_bounds__(64 * VW, WT == WT_F16 ? 1 : 2) void matvec_v
             for (int m = 0; m < NM; ++m) {
                 const uint32_t wd[4] = {(uint32_t)wq[m][u].x, (uint32_t)wq[m][u].y, (uint32_t)wq[m][u].z, (uint32_t)wq[m][u].w};
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk)       // thizVector.fma(thatVector, val); the conversion flushes subnormals (MODE)
-                    acc[m] = __builtin_fmaf((kk & 1) ? cvt_hi(wd[kk >> 1]) : cvt_lo(wd[kk >> 1]), xs[kk], acc[m]);
+                for (int kk = 0; kk < 8; ++kk) {     // thizVector.fma(thatVector, val); the conversion flushes subnormals (MODE)
+                    const float wv = (kk & 1) ? cvt_hi(wd[kk >> 1]) : cvt_lo(wd[kk >> 1]);
+                    if (SPECIES == 512 && (kk & 1)) acc2[m] = __builtin_fmaf(wv, xs[kk], acc2[m]);
+                    else acc[m] = __builtin_fmaf(wv, xs[kk], acc[m]);
+                }
             }
         } else if (WT == WT_Q8_0) {
 #pragma unroll
@@ -361,6 +369,10 @@ static __global__ __launch_bounds__(64 * VW, WT == WT_F16 ? 1 : 2) void matvec_v
         float r = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) r = r + __shfl(acc[m], (lane & ~7) + j, 64);
+        if (SPECIES == 512) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r = r + __shfl(acc2[m], (lane & ~7) + j, 64);
+        }
         res[m] = r;
     }
     const int row = g * 8 + rr;

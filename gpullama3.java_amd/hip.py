@@ -17,6 +17,7 @@ E_ARG, E_UNSUPPORTED, E_OOM, E_HIP, E_RCCL, E_STATE = -1, -2, -3, -4, -5, -6
 ERR_NAMES = {0: "GL3_OK", -1: "GL3_E_ARG", -2: "GL3_E_UNSUPPORTED", -3: "GL3_E_OOM", -4: "GL3_E_HIP", -5: "GL3_E_RCCL",
              -6: "GL3_E_STATE"}
 FLAG_NO_GRAPH, FLAG_LAYER_TAPS, FLAG_FORCE_RCCL, FLAG_SCALAR_DOT, FLAG_F32_ACTIVATION = 1, 2, 4, 8, 16
+FLAG_VECTOR_512, FLAG_VECTOR_128 = 32, 64      # -Dllama.VectorBitSize (default 256): see include/gpullama3_hip.h
 K_NAMES = ["matvec_qkv", "matvec_wo", "matvec_gateup", "matvec_down", "matvec_logits", "attention", "other", "collective"]
 
 T_IDS = {"token_embd.weight": 0, "output_norm.weight": 1, "output.weight": 2, "attn_norm.weight": 3,

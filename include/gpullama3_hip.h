@@ -114,6 +114,15 @@ enum {
                                      not affected: dotQ8Activation is scalar in both modes. */
 #define GL3_FLAG_F32_ACTIVATION 0x10u /* Q8_0 matrices: -Dllama.quantizeActivation=false — f32 activation x dequantised weights in the
                                        * Vector-API order of Q8_0FloatTensor.vectorDot (256-bit species) instead of the int8 activation */
+/* The species of the Vector-API order = -Dllama.VectorBitSize, default VectorShape.preferredShape() of the JVM's host
+ * (J/tensor/standard/FloatTensor.java:21): 256 on an AVX2 host (this library's default), 512 on AVX-512 (e.g. the EPYC 9575F of an
+ * MI355X node), 128 on SSE / NEON.  Only F16 / Q4_0 matrices and Q8_0 with GL3_FLAG_F32_ACTIVATION depend on it (the Q8_0 int8 path is
+ * scalar).  GL3_FLAG_VECTOR_512: F16 matrices in the 16-accumulator order of FP16FloatTensor.vectorDot (decode kernels; a prefill chunk
+ * runs token by token); Q4_0 / Q8_0-f32act plans are refused with GL3_E_UNSUPPORTED — the reference throws UnsupportedOperationException
+ * for them (Q4_0FloatTensor.java:118-120, Q8_0FloatTensor.java:165-167; run such a JVM with -Dllama.VectorBitSize=256).
+ * GL3_FLAG_VECTOR_128 (4 accumulators; two fmas per block for Q8_0 / Q4_0): restated in the oracles, refused here (GL3_E_UNSUPPORTED). */
+#define GL3_FLAG_VECTOR_512 0x20u
+#define GL3_FLAG_VECTOR_128 0x40u
 
 /* Configuration (J/model/Configuration.java via LlamaModelLoader.java:47-63 / Qwen3ModelLoader.java:48-74)
  * plus the plan-selection knobs the reference reads from system properties

@@ -71,7 +71,8 @@ typedef struct { const void* p; int type; } orc_tensor;
 
 typedef struct {
     orc_config c;
-    int vector_bits;                      /* 0: scalar dots (-Dllama.VectorBitSize=0); 256: the Vector-API dots of F16 / Q4_0 (and Q8_0 with f32 activation) */
+    int vector_bits;                      /* 0: scalar dots (-Dllama.VectorBitSize=0); 128 / 256 / 512: the Vector-API dots of F16 / Q4_0 (and Q8_0 with f32 activation) of that species */
+    int species_error;                    /* set by a matmul the reference throws UnsupportedOperationException for (Q4_0 / Q8_0-f32act on a 512-bit species) */
     int f32_activation;                   /* 1: -Dllama.quantizeActivation=false — Q8_0 matrices take the f32 activation (vectorDot / scalarDot) */
     orc_tensor global[3];
     orc_tensor* layer[ORC_T_COUNT];       /* per-layer tensors, [id][layer] */
@@ -201,40 +202,52 @@ static inline float f16_to_f32_daz(uint16_t h) {
     float f; memcpy(&f, &bits, 4); return f;
 }
 
-static inline float reduce_lanes8(const float* v) {
+static inline float reduce_lanes(const float* v, int L) {
     float r = 0.f;
-    for (int l = 0; l < 8; l++) r = r + v[l];
+    for (int l = 0; l < L; l++) r = r + v[l];
     return r;
 }
 
-static float dot_f16_v256(const uint8_t* wrow, const float* x, int n) {
-    float val[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int ub = n & ~7;
-    for (int i = 0; i < ub; i += 8)
-        for (int l = 0; l < 8; l++) val[l] = fmaf(f16_to_f32_daz(rd16(wrow + 2 * (i + l))), x[i + l], val[l]);     /* thizVector.fma(thatVector, val) */
-    float result = reduce_lanes8(val);
+/* Species: FloatTensor.java:21 takes VectorShape.preferredShape() — 256 bits on an AVX2 host, 512 on AVX-512 (the GPU box's EPYC 9575F),
+ * 128 on NEON / SSE — unless -Dllama.VectorBitSize says otherwise; L = bits / 32 float lanes.  FP16FloatTensor.vectorDot is
+ * species-generic; the Q8_0 / Q4_0 vector dots have a 256-bit and a 128-bit branch and THROW for anything else
+ * (Q8_0FloatTensor.java:165-167, Q4_0FloatTensor.java:118-120): restated as ORC_E_SPECIES from the forward calls.                      */
+static float dot_f16_vec(const uint8_t* wrow, const float* x, int n, int L) {
+    float val[16] = {0};
+    int ub = n / L * L;
+    for (int i = 0; i < ub; i += L)
+        for (int l = 0; l < L; l++) val[l] = fmaf(f16_to_f32_daz(rd16(wrow + 2 * (i + l))), x[i + l], val[l]);     /* thizVector.fma(thatVector, val) */
+    float result = reduce_lanes(val, L);
     if (ub < n) { float t = 0.f; for (int j = ub; j < n; j++) t += orc_f16_to_f32(rd16(wrow + 2 * j)) * x[j]; result += t; }
     return result;
 }
 
-/* Q4_0FloatTensor.vectorDot  J/tensor/standard/Q4_0FloatTensor.java:82-133, the 256-bit branch :101-106:
- * val = sum0.add(sum1).add(sum2).add(sum3).fma(wScale, val), sum_i = x-vector * (nibbles - 8) as floats                */
-static float dot_q4_0_v256(const uint8_t* wrow, const float* x, int n) {
+/* One block of the Q8_0 / Q4_0 vector dots, q[32] = the block's dequantised integers in ELEMENT order (Q4_0: lo nibbles = elements
+ * 0..15, hi nibbles = 16..31).  256 bits (:145-152 / :101-106): val = sum0.add(sum1).add(sum2).add(sum3).fma(wScale, val) with
+ * sum_i = x[8 i .. 8 i + 7] * q[8 i .. 8 i + 7].  128 bits (:154-163 / :107-117): the same with 4-lane vectors over elements 0..15,
+ * then again over 16..31 — two fmas per block.                                                                                         */
+static inline void block_vec(const float* x, const float* q, float ws, float* val, int L) {
+    for (int h = 0; h < 32; h += 4 * L)
+        for (int l = 0; l < L; l++) {
+            float sum0 = x[h + l] * q[h + l], sum1 = x[h + L + l] * q[h + L + l];
+            float sum2 = x[h + 2 * L + l] * q[h + 2 * L + l], sum3 = x[h + 3 * L + l] * q[h + 3 * L + l];
+            float s = ((sum0 + sum1) + sum2) + sum3;
+            val[l] = fmaf(s, ws, val[l]);
+        }
+}
+
+/* Q4_0FloatTensor.vectorDot  J/tensor/standard/Q4_0FloatTensor.java:82-133 */
+static float dot_q4_0_vec(const uint8_t* wrow, const float* x, int n, int L) {
     float val[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int ub = n / 32 * 32;
     for (int j = 0; j < ub; j += 32) {
         const uint8_t* blk = wrow + (j / 32) * 18;
-        float ws = orc_f16_to_f32(rd16(blk));
-        for (int l = 0; l < 8; l++) {
-            float lo0 = (float)(int8_t)((blk[2 + l] & 0x0F) - 8), lo1 = (float)(int8_t)((blk[2 + 8 + l] & 0x0F) - 8);
-            float hi0 = (float)(int8_t)((blk[2 + l] >> 4) - 8), hi1 = (float)(int8_t)((blk[2 + 8 + l] >> 4) - 8);
-            float sum0 = x[j + l] * lo0, sum1 = x[j + 8 + l] * lo1, sum2 = x[j + 16 + l] * hi0, sum3 = x[j + 24 + l] * hi1;
-            float s = ((sum0 + sum1) + sum2) + sum3;
-            val[l] = fmaf(s, ws, val[l]);
-        }
+        float ws = orc_f16_to_f32(rd16(blk)), q[32];
+        for (int e = 0; e < 16; e++) { q[e] = (float)(int8_t)((blk[2 + e] & 0x0F) - 8); q[16 + e] = (float)(int8_t)((blk[2 + e] >> 4) - 8); }
+        block_vec(x + j, q, ws, val, L);
     }
     float result = 0.f;
-    result += reduce_lanes8(val);
+    result += reduce_lanes(val, L);
     if (ub < n) {
         orc_tensor t = {wrow, ORC_Q4_0};
         float tl = 0.f;
@@ -244,25 +257,20 @@ static float dot_q4_0_v256(const uint8_t* wrow, const float* x, int n) {
     return result;
 }
 
-/* Q8_0FloatTensor.vectorDot  J/tensor/standard/Q8_0FloatTensor.java:125-175, the 256-bit branch :145-152 (taken by dot() when
- * llama.quantizeActivation=false and the Vector API is on):  val = sum0.add(sum1).add(sum2).add(sum3).fma(wScale, val),
- * sum_i = x-vector i of the block * (int8 quants 8i .. 8i+7 cast to float); scalar tail for n % 32 (never taken: K % 32 == 0) */
-static float dot_q8_0_v256(const uint8_t* wrow, const float* x, int n) {
+/* Q8_0FloatTensor.vectorDot  J/tensor/standard/Q8_0FloatTensor.java:125-175 (taken by dot() when llama.quantizeActivation=false and the
+ * Vector API is on); scalar tail for n % 32 (never taken: K % 32 == 0) */
+static float dot_q8_0_vec(const uint8_t* wrow, const float* x, int n, int L) {
     float val[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int ub = n / 32 * 32;
     for (int j = 0; j < ub; j += 32) {
         const uint8_t* blk = wrow + (j / 32) * 34;
-        float ws = orc_f16_to_f32(rd16(blk));
-        const int8_t* q = (const int8_t*)(blk + 2);
-        for (int l = 0; l < 8; l++) {
-            float sum0 = x[j + l] * (float)q[l], sum1 = x[j + 8 + l] * (float)q[8 + l];
-            float sum2 = x[j + 16 + l] * (float)q[16 + l], sum3 = x[j + 24 + l] * (float)q[24 + l];
-            float s = ((sum0 + sum1) + sum2) + sum3;
-            val[l] = fmaf(s, ws, val[l]);
-        }
+        float ws = orc_f16_to_f32(rd16(blk)), q[32];
+        const int8_t* qi = (const int8_t*)(blk + 2);
+        for (int e = 0; e < 32; e++) q[e] = (float)qi[e];
+        block_vec(x + j, q, ws, val, L);
     }
     float result = 0.f;
-    result += reduce_lanes8(val);
+    result += reduce_lanes(val, L);
     if (ub < n) {
         orc_tensor t = {wrow, ORC_Q8_0};
         float tl = 0.f;
@@ -274,19 +282,22 @@ static float dot_q8_0_v256(const uint8_t* wrow, const float* x, int n) {
 
 /* FloatTensor.matmul  J/tensor/standard/FloatTensor.java:98-100 (rows in parallel) */
 static void matmul(orc_ctx* o, const orc_tensor* w, const float* x, float* out, int d0, int d1) {
-    if (o->vector_bits == 256 && (w->type == ORC_F16 || w->type == ORC_Q4_0)) {
+    const int L = o->vector_bits / 32;
+    if (o->vector_bits && (w->type == ORC_F16 || w->type == ORC_Q4_0)) {
         const uint8_t* base = (const uint8_t*)w->p;
         size_t rb = w->type == ORC_F16 ? (size_t)d1 * 2 : (size_t)(d1 / 32) * 18;
+        if (w->type == ORC_Q4_0 && L > 8) { o->species_error = 1; return; }         /* throw new UnsupportedOperationException(F_SPECIES.toString()) */
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < d0; i++)
-            out[i] = w->type == ORC_F16 ? dot_f16_v256(base + (size_t)i * rb, x, d1) : dot_q4_0_v256(base + (size_t)i * rb, x, d1);
+            out[i] = w->type == ORC_F16 ? dot_f16_vec(base + (size_t)i * rb, x, d1, L) : dot_q4_0_vec(base + (size_t)i * rb, x, d1, L);
         return;
     }
-    if (w->type == ORC_Q8_0 && o->f32_activation && o->vector_bits == 256) {     /* Q8_0FloatTensor.dot :73-83 with QUANTIZE_ACTIVATION = false */
+    if (w->type == ORC_Q8_0 && o->f32_activation && o->vector_bits) {     /* Q8_0FloatTensor.dot :73-83 with QUANTIZE_ACTIVATION = false */
         const uint8_t* base = (const uint8_t*)w->p;
         size_t rb = (size_t)(d1 / 32) * 34;
+        if (L > 8) { o->species_error = 1; return; }
 #pragma omp parallel for schedule(static)
-        for (int i = 0; i < d0; i++) out[i] = dot_q8_0_v256(base + (size_t)i * rb, x, d1);
+        for (int i = 0; i < d0; i++) out[i] = dot_q8_0_vec(base + (size_t)i * rb, x, d1, L);
         return;
     }
     if (w->type == ORC_Q8_0 && !o->f32_activation) {
@@ -687,16 +698,24 @@ ORC_API int orc_sample(const float* logits, int n, float temperature, float topp
     return result;
 }
 
-/* 0 = scalar dots (the default of this oracle, -Dllama.VectorBitSize=0), 256 = Vector-API dots for F16 / Q4_0 matrices */
+/* 0 = scalar dots (the default of this oracle, -Dllama.VectorBitSize=0); 128 / 256 / 512 = Vector-API dots of that species for F16 / Q4_0
+ * matrices (and Q8_0 with the f32 activation) */
 ORC_API int orc_set_vector_bits(orc_ctx* o, int bits) {
-    if (bits != 0 && bits != 256) return -1;
+    if (bits != 0 && bits != 128 && bits != 256 && bits != 512) return -1;
     o->vector_bits = bits;
+    o->species_error = 0;
     return 0;
 }
-ORC_API float orc_dot_v256(const void* wrow, int type, const float* x, int n) {
-    return type == ORC_F16 ? dot_f16_v256((const uint8_t*)wrow, x, n) : type == ORC_Q8_0 ? dot_q8_0_v256((const uint8_t*)wrow, x, n)
-                                                                                        : dot_q4_0_v256((const uint8_t*)wrow, x, n);
+/* 1 after a forward / prefill whose matmul the reference refuses for this species (UnsupportedOperationException); reading clears it */
+ORC_API int orc_species_error(orc_ctx* o) { const int e = o->species_error; o->species_error = 0; return e; }
+/* one row's Vector-API dot of a `bits`-wide species (KAT entry point); NaN for the combinations the reference throws for */
+ORC_API float orc_dot_vec(const void* wrow, int type, const float* x, int n, int bits) {
+    const int L = bits / 32;
+    if (type == ORC_F16) return dot_f16_vec((const uint8_t*)wrow, x, n, L);
+    if (L > 8) return NAN;
+    return type == ORC_Q8_0 ? dot_q8_0_vec((const uint8_t*)wrow, x, n, L) : dot_q4_0_vec((const uint8_t*)wrow, x, n, L);
 }
+ORC_API float orc_dot_v256(const void* wrow, int type, const float* x, int n) { return orc_dot_vec(wrow, type, x, n, 256); }
 /* 1 = -Dllama.quantizeActivation=false: Q8_0 matrices multiply the f32 activation (vector_bits 256: vectorDot, 0: scalarDot) */
 ORC_API int orc_set_f32_activation(orc_ctx* o, int on) { o->f32_activation = on ? 1 : 0; return 0; }
 /* thread pool size of the following forwards (tiny test models run faster on a few threads than on every logical CPU); returns the old value */

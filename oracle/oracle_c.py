@@ -81,6 +81,9 @@ def lib():
         L.orc_set_f32_activation.argtypes = [C.c_void_p, C.c_int]
         L.orc_dot_v256.restype = C.c_float
         L.orc_dot_v256.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_dot_vec.restype = C.c_float
+        L.orc_dot_vec.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_species_error.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -89,14 +92,20 @@ def _p(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class UnsupportedSpecies(Exception):
+    """The reference's UnsupportedOperationException(F_SPECIES.toString()): Q8_0FloatTensor.java:165-167, Q4_0FloatTensor.java:118-120 —
+    the Q8_0 (f32 activation) / Q4_0 vector dots exist for 128- and 256-bit species only."""
+
+
 class COracle:
     """Same call surface as the HIP plan: forward(token, pos) -> logits, prefill(tokens, start)."""
 
     def __init__(self, model, vector_bits: int = 0, f32_activation: bool = False):
         """model: gpullama3.java_amd synth.SynthModel-like (cfg, tensors name->(raw, type, ...), rope).
-        vector_bits: 0 = scalar dots everywhere (-Dllama.VectorBitSize=0), 256 = the Vector-API dots for F16 / Q4_0 matrices.
-        f32_activation: -Dllama.quantizeActivation=false — Q8_0 matrices take the f32 activation (with vector_bits 256:
-        Q8_0FloatTensor.vectorDot)."""
+        vector_bits: 0 = scalar dots everywhere (-Dllama.VectorBitSize=0); 128 / 256 / 512 = the Vector-API dots of that species for
+        F16 / Q4_0 matrices (VectorShape.preferredShape(): 256 on an AVX2 host, 512 on AVX-512 such as the GPU box's EPYC 9575F).
+        f32_activation: -Dllama.quantizeActivation=false — Q8_0 matrices take the f32 activation (with vector_bits != 0:
+        Q8_0FloatTensor.vectorDot).  Q4_0 / Q8_0-f32act with 512 raise UnsupportedSpecies from forward / prefill, as the reference throws."""
         L = lib()
         c = model.cfg
         self.cfg = c
@@ -137,12 +146,18 @@ class COracle:
         logits = np.empty(c.vocab, np.float32)
         lx = np.empty((c.n_layers, c.dim), np.float32) if layer_x else None
         lib().orc_forward(self._h, token, pos, _p(logits), _p(lx) if layer_x else None)
+        self._check_species()
         return (logits, lx) if layer_x else logits
+
+    def _check_species(self):
+        if lib().orc_species_error(self._h):
+            raise UnsupportedSpecies("Q8_0 (f32 activation) / Q4_0 vector dots: 128- and 256-bit species only")
 
     def prefill(self, tokens, start_pos: int):
         self._pool()
         t = np.ascontiguousarray(tokens, np.int32)
         lib().orc_prefill(self._h, _p(t), len(t), start_pos)
+        self._check_species()
 
     def moe_routing(self):
         """(expert ids, routing weights, shared-expert gate) of the last layer of the last step."""

@@ -106,48 +106,65 @@ def f16_to_f32_daz(h: np.ndarray) -> np.ndarray:
     return bits.astype(np.uint32).view(F32)
 
 
-def matmul_v256(w_raw, ggml_type: int, x: np.ndarray, d0: int, d1: int) -> np.ndarray:
-    """FloatTensor.matmul with the Vector-API dots of a 256-bit species (8 float lanes):
-    FP16FloatTensor.vectorDot (FP16FloatTensor.java:63-110) / Q4_0FloatTensor.vectorDot, 256-bit branch
-    (Q4_0FloatTensor.java:82-133).  reduceLanes(ADD) in lane order from 0."""
+class UnsupportedSpecies(Exception):
+    """The reference throws UnsupportedOperationException(F_SPECIES.toString()) — Q8_0FloatTensor.java:165-167, Q4_0FloatTensor.java:118-120:
+    the Q8_0 / Q4_0 vector dots exist for 128- and 256-bit species only (a 512-bit host, e.g. AVX-512, needs -Dllama.VectorBitSize=256)."""
+
+
+def matmul_vec(w_raw, ggml_type: int, x: np.ndarray, d0: int, d1: int, bits: int = 256) -> np.ndarray:
+    """FloatTensor.matmul with the Vector-API dots of a `bits`-wide species, L = bits / 32 float lanes (FloatTensor.java:21-47):
+      F16   FP16FloatTensor.vectorDot (FP16FloatTensor.java:63-110) is species-generic: val[l] = fma(w[i + l], x[i + l], val[l]), i += L;
+      Q8_0  (f32 activation) Q8_0FloatTensor.vectorDot :125-175 — 256: one fma per block over four 8-lane products; 128: TWO fmas per
+            block (bytes 0..15, then 16..31), each over four 4-lane products (:154-163); 512: throws (:165-167);
+      Q4_0  Q4_0FloatTensor.vectorDot :82-133 — 256: lo nibbles = elements 0..15, hi = 16..31, four 8-lane products, one fma; 128: two
+            fmas per block (lo bytes, then hi bytes), each over four 4-lane products (:107-117); 512: throws (:118-120).
+    reduceLanes(ADD) in lane order from 0.  Sizes here are multiples of the block / lane count: the scalar tails are empty."""
+    if bits not in (128, 256, 512):
+        raise ValueError(bits)
+    L = bits // 32
     x = np.asarray(x, dtype=F32)
     raw = w_raw.view(np.uint8).reshape(-1)
-    val = np.zeros((d0, 8), F32)
+    val = np.zeros((d0, L), F32)
     if ggml_type == GGML_F16:
-        w = f16_to_f32_daz(raw[: 2 * d0 * d1].view(np.uint16)).reshape(d0, d1 // 8, 8)
-        xv = x.reshape(d1 // 8, 8)
-        for i in range(d1 // 8):
+        assert d1 % L == 0
+        w = f16_to_f32_daz(raw[: 2 * d0 * d1].view(np.uint16)).reshape(d0, d1 // L, L)
+        xv = x.reshape(d1 // L, L)
+        for i in range(d1 // L):
             val = fma32(w[:, i, :], xv[i][None, :], val)
-    elif ggml_type == GGML_Q4_0:
-        nb = d1 // 32
+        return seq_sum(val, axis=1)
+    if bits == 512:
+        raise UnsupportedSpecies("Species[float, 16, S_512_BIT]")
+    nb = d1 // 32
+    if ggml_type == GGML_Q4_0:
         blk = raw[: d0 * nb * 18].reshape(d0, nb, 18)
         ws = blk[:, :, :2].copy().view(np.float16).astype(F32).reshape(d0, nb)
-        lo = ((blk[:, :, 2:] & 0x0F).astype(np.int8) - 8).astype(F32)          # [d0, nb, 16]
-        hi = ((blk[:, :, 2:] >> 4).astype(np.int8) - 8).astype(F32)
-        xb = x.reshape(nb, 4, 8)
-        for b in range(nb):
-            sum0 = xb[b, 0][None, :] * lo[:, b, 0:8]
-            sum1 = xb[b, 1][None, :] * lo[:, b, 8:16]
-            sum2 = xb[b, 2][None, :] * hi[:, b, 0:8]
-            sum3 = xb[b, 3][None, :] * hi[:, b, 8:16]
-            sm = ((sum0 + sum1) + sum2) + sum3
-            val = fma32(sm, ws[:, b][:, None], val)
-    elif ggml_type == GGML_Q8_0:                          # Q8_0FloatTensor.vectorDot, 256-bit branch (Q8_0FloatTensor.java:125-175)
-        nb = d1 // 32
+        lo = ((blk[:, :, 2:] & 0x0F).astype(np.int8) - 8).astype(F32)          # [d0, nb, 16]: elements 0..15
+        hi = ((blk[:, :, 2:] >> 4).astype(np.int8) - 8).astype(F32)            # elements 16..31
+        q = np.concatenate([lo, hi], axis=2)                                   # [d0, nb, 32] in element order
+    elif ggml_type == GGML_Q8_0:
         blk = raw[: d0 * nb * 34].reshape(d0, nb, 34)
         ws = blk[:, :, :2].copy().view(np.float16).astype(F32).reshape(d0, nb)
-        q = blk[:, :, 2:].view(np.int8).astype(F32)      # [d0, nb, 32]
-        xb = x.reshape(nb, 4, 8)
-        for b in range(nb):
-            sum0 = xb[b, 0][None, :] * q[:, b, 0:8]
-            sum1 = xb[b, 1][None, :] * q[:, b, 8:16]
-            sum2 = xb[b, 2][None, :] * q[:, b, 16:24]
-            sum3 = xb[b, 3][None, :] * q[:, b, 24:32]
-            sm = ((sum0 + sum1) + sum2) + sum3
-            val = fma32(sm, ws[:, b][:, None], val)
+        q = blk[:, :, 2:].view(np.int8).astype(F32)                            # [d0, nb, 32]
     else:
         raise ValueError(ggml_type)
+    # both types: element e of a block multiplies x[32 b + e]; one fma per group of 4 L elements (256: the block; 128: its halves),
+    # sum_i = products of elements [i L, (i + 1) L) of the group, ((sum0 + sum1) + sum2) + sum3
+    G = 4 * L
+    xb = x.reshape(nb, 32 // G, 4, L)
+    qg = q.reshape(d0, nb, 32 // G, 4, L)
+    for b in range(nb):
+        for h in range(32 // G):
+            s0 = xb[b, h, 0][None, :] * qg[:, b, h, 0]
+            s1 = xb[b, h, 1][None, :] * qg[:, b, h, 1]
+            s2 = xb[b, h, 2][None, :] * qg[:, b, h, 2]
+            s3 = xb[b, h, 3][None, :] * qg[:, b, h, 3]
+            sm = ((s0 + s1) + s2) + s3
+            val = fma32(sm, ws[:, b][:, None], val)
     return seq_sum(val, axis=1)
+
+
+def matmul_v256(w_raw, ggml_type: int, x: np.ndarray, d0: int, d1: int) -> np.ndarray:
+    return matmul_vec(w_raw, ggml_type, x, d0, d1, 256)
 
 
 def rmsnorm(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
@@ -209,9 +226,11 @@ class NpOracle:
     """Holds config, raw GGUF-layout tensors and the State arrays (LlamaState.java:28-81)."""
 
     def __init__(self, cfg: dict, tensors: dict, rope, vector_bits: int = 0, f32_activation: bool = False):
-        """vector_bits: 0 = scalar dots (-Dllama.VectorBitSize=0); 256 = Vector-API dots for F16 / Q4_0 matrices.
-        f32_activation: -Dllama.quantizeActivation=false (Q8_0 matrices x f32 activation; needs vector_bits 256 here)."""
-        assert vector_bits in (0, 256)
+        """vector_bits: 0 = scalar dots (-Dllama.VectorBitSize=0); 128 / 256 / 512 = Vector-API dots of that species for F16 / Q4_0 matrices
+        (and Q8_0 with the f32 activation) — VectorShape.preferredShape() of the host: 256 on AVX2, 512 on AVX-512 (FloatTensor.java:21).
+        f32_activation: -Dllama.quantizeActivation=false (Q8_0 matrices x f32 activation).  Q4_0 / Q8_0-f32act with 512 raise
+        UnsupportedSpecies at the first matmul, as the reference throws."""
+        assert vector_bits in (0, 128, 256, 512)
         self.vector_bits = vector_bits
         self.f32_activation = f32_activation
         self.c = cfg
@@ -225,8 +244,8 @@ class NpOracle:
 
     def _mm(self, name, x, d0, d1):
         raw, ty = self.t[name]
-        if self.vector_bits == 256 and (ty in (GGML_F16, GGML_Q4_0) or (ty == GGML_Q8_0 and self.f32_activation)):
-            return matmul_v256(raw, ty, x, d0, d1)
+        if self.vector_bits and (ty in (GGML_F16, GGML_Q4_0) or (ty == GGML_Q8_0 and self.f32_activation)):
+            return matmul_vec(raw, ty, x, d0, d1, self.vector_bits)
         return matmul(raw, ty, x, d0, d1)
 
     def _f32(self, name, n):
@@ -239,8 +258,8 @@ class NpOracle:
         bs, ts = BLOCK[ty]
         rb = d1 // bs * ts
         sub = raw.view(np.uint8).reshape(-1)[row0 * rb:(row0 + d0) * rb]
-        if self.vector_bits == 256 and (ty in (GGML_F16, GGML_Q4_0) or (ty == GGML_Q8_0 and self.f32_activation)):
-            return matmul_v256(sub, ty, x, d0, d1)
+        if self.vector_bits and (ty in (GGML_F16, GGML_Q4_0) or (ty == GGML_Q8_0 and self.f32_activation)):
+            return matmul_vec(sub, ty, x, d0, d1, self.vector_bits)
         return matmul(sub, ty, x, d0, d1)
 
     def _moe_ffn(self, p, x, xb):

@@ -106,6 +106,57 @@ def test_f16_and_q4_0_decode_match_c_oracle_live(pkg, orc, planmod, cfg, wtype, 
     plan.freeTornadoExecutionPlan()
 
 
+@pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "tiny-llama-tied", "mid-qwen2", "mid-phi3", "1b-layer"])
+def test_f16_on_a_512_bit_species_matches_c_oracle_live(pkg, orc, planmod, cfg):
+    """FloatTensor.java:21 takes VectorShape.preferredShape(): on the GPU box's own EPYC 9575F (AVX-512) the reference's F16 dot keeps 16
+    accumulator lanes (FP16FloatTensor.vectorDot :63-110 is species-generic) — BASELINE configs[0]'s arithmetic on this node.
+    GL3_FLAG_VECTOR_512: logits, per-layer x, device argmax and the KV cache after a (token-by-token) prefill chunk equal the oracle's
+    vector_bits = 512 mode bit for bit, and differ from the 256-bit order."""
+    plan_mod, hip = planmod
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=1, seed=19)
+    plan = plan_mod.HipMasterPlan(m, prefill_batch_size=16, flags=hip.FLAG_LAYER_TAPS | hip.FLAG_VECTOR_512)
+    o, o256 = orc.COracle(m, vector_bits=512), orc.COracle(m, vector_bits=256)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 12)
+    plan.prefill(toks[:6], 0)
+    o.prefill(toks[:6], 0); o256.prefill(toks[:6], 0)
+    differs = False
+    for pos in range(6, 12):
+        ref, lx = o.forward(toks[pos], pos, layer_x=True)
+        got = plan.tornadoVMForwardDecode(toks[pos], pos)
+        assert np.array_equal(got, ref), (pos, rel(got, ref))
+        differs |= not np.array_equal(got, o256.forward(toks[pos], pos))
+        for l in range(m.cfg.n_layers):
+            assert np.array_equal(plan.layer_x(l), lx[l])
+        assert plan.forward_decode_argmax(toks[pos], pos) == orc.argmax(ref)
+    assert differs
+    for l in range(m.cfg.n_layers):
+        k, v = plan.kv(l, 3)
+        ko, vo = o.kv(l, 3)
+        assert np.array_equal(k, ko) and np.array_equal(v, vo)
+    plan.freeTornadoExecutionPlan()
+
+
+def test_vector_species_the_reference_cannot_run_are_refused(pkg, planmod):
+    """Q4_0FloatTensor.vectorDot / Q8_0FloatTensor.vectorDot throw UnsupportedOperationException on a 512-bit species (:118-120, :165-167):
+    gl3_create answers GL3_E_UNSUPPORTED (-2) for such a plan; the 128-bit species exists in the oracles only and is refused for every
+    species-dependent type; the headline Q8_0 int8 path does not depend on the species and accepts the flag."""
+    plan_mod, hip = planmod
+    for wt, flags in [(2, hip.FLAG_VECTOR_512), (8, hip.FLAG_VECTOR_512 | hip.FLAG_F32_ACTIVATION), (1, hip.FLAG_VECTOR_128), (2, hip.FLAG_VECTOR_128),
+                      (8, hip.FLAG_VECTOR_128 | hip.FLAG_F32_ACTIVATION)]:
+        m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama-tied" if wt == 2 else "mid-llama"], wtype=wt, seed=3)
+        with pytest.raises(hip.Gl3Error) as e:
+            plan_mod.HipMasterPlan(m, flags=flags)
+        assert e.value.code == -2, (wt, flags)
+    with pytest.raises(hip.Gl3Error) as e:
+        plan_mod.HipMasterPlan(pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], wtype=1, seed=3), flags=hip.FLAG_VECTOR_512 | hip.FLAG_SCALAR_DOT)
+    assert e.value.code == -1
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], wtype=8, seed=3)
+    plan = plan_mod.HipMasterPlan(m, flags=hip.FLAG_VECTOR_512)                 # dotQ8Activation is scalar: nothing changes
+    ref = plan_mod.HipMasterPlan(m)
+    assert np.array_equal(plan.forward_decode(5, 0), ref.forward_decode(5, 0))
+    plan.freeTornadoExecutionPlan(); ref.freeTornadoExecutionPlan()
+
+
 @pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "tiny-llama-tied", "mid-qwen2", "mid-granite", "mid-phi3"])
 def test_q8_0_with_f32_activation_matches_c_oracle_live(pkg, orc, planmod, cfg):
     """SURVEY 8 a4': Q8_0 matrices with -Dllama.quantizeActivation=false (GL3_FLAG_F32_ACTIVATION) = Q8_0FloatTensor.vectorDot on

@@ -126,6 +126,33 @@ def test_q8_0_f32_activation_vector_dot_numpy_and_c_agree(pkg, orc):
             assert float(np.max(np.abs(a - c)) / np.max(np.abs(c))) < 5e-2
 
 
+@pytest.mark.parametrize("bits", [128, 512])
+def test_other_vector_species_numpy_and_c_agree(pkg, orc, bits):
+    """FloatTensor.java:21 takes VectorShape.preferredShape(): 512 bits on an AVX-512 host (the GPU box's EPYC 9575F), 128 on SSE / NEON.
+    FP16FloatTensor.vectorDot is species-generic (L = bits / 32 accumulator lanes); the Q8_0 / Q4_0 vector dots have a 128-bit branch
+    (two fmas per block over 4-lane vectors, Q8_0FloatTensor.java:154-163, Q4_0FloatTensor.java:107-117) and THROW for 512
+    (:165-167, :118-120).  Both restatements agree bit for bit in every mode the reference can run, differ from the 256-bit order, and
+    raise where it throws."""
+    cases = [("tiny-llama", 1, False), ("tiny-qwen3", 1, False), ("tiny-llama-tied", 2, False), ("tiny-llama", 8, True), ("tiny-phi3", 2, False)]
+    for cfg, wt, f32act in cases:
+        m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wt, seed=1357)
+        cv = orc.COracle(m, vector_bits=bits, f32_activation=f32act)
+        c256 = orc.COracle(m, vector_bits=256, f32_activation=f32act)
+        nv = oracle_np.NpOracle(m.oracle_cfg(), m.oracle_tensors(), m.rope, vector_bits=bits, f32_activation=f32act)
+        toks = pkg.javarand.bench_tokens(m.cfg.vocab, 3, seed=9)
+        if bits == 512 and wt != 1:
+            with pytest.raises(orc.UnsupportedSpecies):
+                cv.forward(toks[0], 0)
+            with pytest.raises(oracle_np.UnsupportedSpecies):
+                nv.forward(toks[0], 0)
+            continue
+        for pos, t in enumerate(toks):
+            a, b, c = cv.forward(t, pos), nv.forward(t, pos), c256.forward(t, pos)
+            assert np.array_equal(a, b), (cfg, bits, pos)
+            assert not np.array_equal(a, c), (cfg, bits, pos)                  # another accumulator count = another rounding order
+            assert float(np.max(np.abs(a - c)) / np.max(np.abs(c))) < 1e-3
+
+
 def test_fma32_emulation_is_correctly_rounded():
     """oracle_np.fma32 (float64 product + round-to-odd sum) against exact rational arithmetic."""
     from fractions import Fraction

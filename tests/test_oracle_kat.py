@@ -4,6 +4,7 @@ import ctypes as C
 import struct
 
 import numpy as np
+import pytest
 
 from oracle import oracle_np
 
@@ -174,3 +175,46 @@ def test_qwen2_bias_is_added_before_rope_kat(pkg, orc):
         exp[h * hs:h * hs + half] = v0 * fcr - v1 * fci
         exp[h * hs + half:(h + 1) * hs] = v0 * fci + v1 * fcr
     assert np.array_equal(k, exp)
+
+
+def test_vector_species_lane_order_kat(orc):
+    """Hand-derived answers that depend on WHICH accumulator lane an element lands in (FloatTensor.java:21-47: L = VectorBitSize / 32
+    lanes; FP16FloatTensor.vectorDot :63-110 — lane l accumulates elements l, l + L, ... by fma, reduceLanes adds the lanes from 0).
+    All weights 1.0; x has 2^24 at 0 and one +1, one -2^24 elsewhere: 2^24 + 1 rounds back to 2^24 (tie to even), so the +1 survives only
+    if it sits in a lane (or, for Q8_0 / Q4_0, a product group) of its own, AND is added after the big values cancelled.
+       A: +1 at 4, -2^24 at 8    L = 4: lane 0 sees 2^24, +1, -2^24 -> 0.   L = 8: lane 0: 2^24 - 2^24 = 0, lane 4: 1 -> 1.
+                                 L = 16: lanes 0, 4, 8 hold 2^24, 1, -2^24; reduce in lane order: (2^24 + 1) - 2^24 -> 0.
+       B: +1 at 8, -2^24 at 16   L = 4 and L = 8: all three in lane 0 -> 0.   L = 16: lane 0: 2^24 - 2^24 = 0, lane 8: 1 -> 1."""
+    import ctypes as C
+    from oracle import oracle_np
+    L = orc.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = 32
+    w16 = np.full(n, 0x3C00, np.uint16)                       # f16 1.0
+    big = np.float32(2.0 ** 24)
+    for name, one_at, neg_at, want in (("A", 4, 8, {128: 0.0, 256: 1.0, 512: 0.0}), ("B", 8, 16, {128: 0.0, 256: 0.0, 512: 1.0})):
+        x = np.zeros(n, np.float32)
+        x[0], x[one_at], x[neg_at] = big, 1.0, -big
+        for bits, exp in want.items():
+            assert L.orc_dot_vec(p(w16), 1, p(x), n, bits) == exp, (name, bits)
+            assert float(oracle_np.matmul_vec(w16.view(np.uint8), 1, x, 1, n, bits)[0]) == exp, (name, bits)
+    # Q8_0 (f32 activation) and Q4_0, one block, scale 1.0, every quant = 1 (Q4_0: nibble 9 - 8), x = pattern A:
+    #   256 bits (Q8_0FloatTensor.java:145-152): lane l multiplies elements l, 8 + l, 16 + l, 24 + l, ONE fma: lane 0: (2^24 + -2^24) = 0, lane 4: 1 -> 1
+    #   128 bits (:154-163): lane l, first fma over elements l, 4 + l, 8 + l, 12 + l: ((2^24 + 1) + -2^24) + 0 = 0 -> 0
+    #   512 bits: the reference throws (:165-167) -> NaN from orc_dot_vec, UnsupportedSpecies from the NumPy statement
+    x = np.zeros(n, np.float32)
+    x[0], x[4], x[8] = big, 1.0, -big
+    q8 = np.concatenate([np.array([0x00, 0x3C], np.uint8), np.ones(32, np.uint8)])
+    q4 = np.concatenate([np.array([0x00, 0x3C], np.uint8), np.full(16, 0x99, np.uint8)])
+    for ty, blk in ((8, q8), (2, q4)):
+        assert L.orc_dot_vec(p(blk), ty, p(x), n, 256) == 1.0 and L.orc_dot_vec(p(blk), ty, p(x), n, 128) == 0.0, ty
+        assert float(oracle_np.matmul_vec(blk, ty, x, 1, n, 256)[0]) == 1.0 and float(oracle_np.matmul_vec(blk, ty, x, 1, n, 128)[0]) == 0.0, ty
+        assert np.isnan(L.orc_dot_vec(p(blk), ty, p(x), n, 512))
+        with pytest.raises(oracle_np.UnsupportedSpecies):
+            oracle_np.matmul_vec(blk, ty, x, 1, n, 512)
+    # Q4_0's second half: elements 16..31 are the HIGH nibbles of bytes 0..15 (Q4_0FloatTensor.java:96-97); +1 at element 20 (hi nibble of byte 4)
+    # shares 128-bit group 2 with nothing -> survives in both species
+    x = np.zeros(n, np.float32)
+    x[20] = 3.0
+    for bits in (128, 256):
+        assert L.orc_dot_vec(p(q4), 2, p(x), n, bits) == 3.0

@@ -49,11 +49,22 @@ def write_dump(path, d):
 
 def oracle_modes(d):
     """Oracle mode of a dump: the int8-activation Q8_0 dot is scalar whatever the species (Q8_0FloatTensor.java:90-123); the F16 /
-    Q4_0 / f32-activation dots follow llama.VectorBitSize, and only 0 and 256 have a counterpart here."""
-    if d["vector_bits"] not in (0, 256):
-        pytest.skip("dump made with a %d-bit vector species: the oracle restates the scalar and the 256-bit orders only "
-                    "(re-run GoldenDump with -Dllama.VectorBitSize=256 or 0)" % d["vector_bits"])
+    Q4_0 / f32-activation dots follow llama.VectorBitSize — r5: every species a JVM can report (0, 128, 256, 512) has a counterpart in
+    both oracles (a dump of Q4_0 / Q8_0-f32act at 512 cannot exist: the reference throws there)."""
+    assert d["vector_bits"] in (0, 128, 256, 512), d["vector_bits"]
     return dict(vector_bits=d["vector_bits"], f32_activation=not d["quantize_activation"])
+
+
+def hip_flags(hip, modes, wt):
+    """Plan flags of a dump's mode, or None when the library refuses the mode (128-bit species of a species-dependent type)."""
+    species_type = wt in (1, 2) or modes["f32_activation"]
+    vb = modes["vector_bits"]
+    if vb == 128 and species_type:
+        return None
+    flags = hip.FLAG_F32_ACTIVATION if modes["f32_activation"] else 0
+    if species_type:
+        flags |= hip.FLAG_SCALAR_DOT if vb == 0 else hip.FLAG_VECTOR_512 if vb == 512 else 0
+    return flags
 
 
 def cases():
@@ -104,7 +115,9 @@ def test_hip_path_matches_the_reference_dump(pkg, stem, wt, seed):
     d, m = load_case(pkg, stem, wt, seed)
     modes = oracle_modes(d)
     plan_mod, hip = import_module(ge.PKG_NAME + ".plan"), import_module(ge.PKG_NAME + ".hip")
-    flags = (hip.FLAG_SCALAR_DOT if modes["vector_bits"] == 0 else 0) | (hip.FLAG_F32_ACTIVATION if modes["f32_activation"] else 0)
+    flags = hip_flags(hip, modes, wt)
+    if flags is None:
+        pytest.skip("dump made with the 128-bit species: restated in the oracles, refused by the library (GL3_FLAG_VECTOR_128)")
     plan = plan_mod.HipMasterPlan(m, flags=flags)
     for pos in range(d["steps"]):
         lg = plan.tornadoVMForwardDecode(int(d["tokens"][pos]), pos)

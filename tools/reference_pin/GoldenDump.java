@@ -20,9 +20,9 @@
 //         -d /tmp/pin /path/to/repo/tools/reference_pin/GoldenDump.java
 //   java  --enable-preview --add-modules jdk.incubator.vector -cp /tmp/pin:target/classes:$TORNADO_API_JARS \
 //         GoldenDump pin_ggufs/tiny_llama_q8_0.gguf /path/to/repo/tests/golden/reference/tiny_llama_q8_0.bin 6 24
-// Modes: the dump records -Dllama.VectorBitSize (0 = scalar dots; 256 = the species width the *_v256 fixtures assume; unset =
-// the host's preferred species, which on an AVX-512 host is 512 and has NO counterpart in this repo's oracle) and
-// -Dllama.quantizeActivation (default true); the test picks the oracle mode from the header.
+// Modes: the dump records -Dllama.VectorBitSize (0 = scalar dots; 128 / 256 / 512 = the species; unset = the host's preferred species:
+// 256 on AVX2, 512 on AVX-512 — every one of them has a counterpart in both oracles since round 5) and -Dllama.quantizeActivation
+// (default true); the test picks the oracle mode — and the plan flags of the HIP path — from the header.
 import java.io.DataOutputStream;
 import java.io.FileOutputStream;
 import java.nio.ByteBuffer;

@@ -28,6 +28,11 @@ PIN_CASES = [
     ("pin_llama_f16_scalar", 1, 7, 4, 4, "-Dllama.VectorBitSize=0"),
     ("pin_llama_f16_v256", 1, 7, 4, 4, "-Dllama.VectorBitSize=256"),
     ("pin_llama_q8_0_f32act_v256", 8, 7, 4, 4, "-Dllama.VectorBitSize=256 -Dllama.quantizeActivation=false"),
+    # r5: the other species a JVM can report (FloatTensor.java:21) — 512 is what an AVX-512 host such as the GPU box's EPYC 9575F picks by
+    # default; F16 is species-generic, the Q8_0 vector dot has a 128-bit branch (and throws at 512: no dump can exist)
+    ("pin_llama_f16_v512", 1, 7, 4, 4, "-Dllama.VectorBitSize=512"),
+    ("pin_llama_f16_v128", 1, 7, 4, 4, "-Dllama.VectorBitSize=128"),
+    ("pin_llama_q8_0_f32act_v128", 8, 7, 4, 4, "-Dllama.VectorBitSize=128 -Dllama.quantizeActivation=false"),
 ]
 
 
