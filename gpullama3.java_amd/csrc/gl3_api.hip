@@ -975,6 +975,12 @@ int32_t gl3_forward_decode_sample(gl3_ctx* ctx, int32_t token, int32_t pos, floa
     return gl3_tp_check(ctx);
 }
 
+int32_t gl3_get_topp_counts(gl3_ctx* ctx, int64_t* on_device, int64_t* on_host) {
+    if (!ctx || !on_device || !on_host) return GL3_E_ARG;
+    *on_device = ctx->topp_device; *on_host = ctx->topp_host;
+    return GL3_OK;
+}
+
 int32_t gl3_get_sample_probs(gl3_ctx* ctx, float* out) {
     if (!ctx || !out) return GL3_E_ARG;
     GL3_HIP(hipSetDevice(ctx->d.device));

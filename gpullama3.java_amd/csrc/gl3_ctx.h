@@ -165,6 +165,8 @@ struct gl3_ctx {
     float* h_logits = nullptr;                    // pinned f32[vocab]
     int* h_argmax = nullptr;
     float *sm_probs = nullptr, *sm_aux = nullptr, *h_probs = nullptr;   // sampling (gl3_sample.hip): probabilities, scratch, pinned copy
+    int64_t topp_device = 0, topp_host = 0;       // top-p draws answered on the device / by the host heap (gl3_get_topp_counts)
+    void* sm_sort = nullptr;                      // top-p on the device: (key, index) x 2, radix histogram, result words
     std::vector<int> topp_indices;
     std::vector<std::pair<void*, size_t>> pinned;     // caller buffers registered with gl3_pin_host_buffer (logits land there directly)
     // upload staging

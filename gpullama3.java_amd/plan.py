@@ -222,6 +222,12 @@ class HipMasterPlan:
         for off in range(0, len(tokens), b):
             self.tornadoVMForwardBatchPrefill(tokens[off:off + b], start_pos + off)
 
+    def topp_counts(self):
+        """(top-p draws answered on the device, draws answered by the host heap after a tie at the sampled rank)."""
+        a, b = C.c_int64(), C.c_int64()
+        hip.check(hip.lib().gl3_get_topp_counts(self._ctx, C.byref(a), C.byref(b)), self._ctx)
+        return a.value, b.value
+
     def x(self):
         out = np.empty(self.cfg.dim, np.float32)
         hip.check(hip.lib().gl3_get_x(self._ctx, _p(out)), self._ctx)

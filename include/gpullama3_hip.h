@@ -225,6 +225,9 @@ GL3_API int32_t gl3_forward_decode_sample(gl3_ctx* ctx, int32_t token, int32_t p
                                           float coin, int32_t* token_out);
 /* Parity tap: the probabilities (f32[vocab]) the last gl3_forward_decode_sample sampled from. */
 GL3_API int32_t gl3_get_sample_probs(gl3_ctx* ctx, float* out);
+/* Parity / measurement tap: top-p draws of this plan answered by the device path (8 bytes back) and by the host heap (a tie between equal
+ * probabilities at the sampled rank: the reference's heap order decides, gl3_sample.hip). */
+GL3_API int32_t gl3_get_topp_counts(gl3_ctx* ctx, int64_t* on_device, int64_t* on_host);
 
 /* Optional: page-lock a caller-owned host buffer (e.g. the MemorySegment the Java shim passes as logits_out on every step) so
  * that gl3_forward_decode copies the logits straight into it instead of going through the plan's pinned staging buffer and a

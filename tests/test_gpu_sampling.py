@@ -56,3 +56,30 @@ def test_full_vocabulary_softmax_and_sampling(pkg, orc, planmod):
         assert np.array_equal(plan.sample_probs(), probs), (temperature, topp)
         assert got == want, (temperature, topp, coin)
     plan.freeTornadoExecutionPlan()
+
+
+def test_top_p_runs_on_the_device_and_ties_fall_back_to_the_heap(pkg, orc, planmod):
+    """r5: ToppSampler on the device (radix sort of the candidates + exact chunked prefix sums, gl3_sample.hip) — 8 bytes come back instead
+    of vocab x 4.  200 draws over the 128256-entry vocabulary at peaked, medium and nearly flat temperatures: every id equals the oracle's
+    heap selection; most draws are answered on the device, the rest (a tie between equal probabilities at the sampled rank, where only the
+    reference's heap history names the token) by the host heap — both counted by gl3_get_topp_counts."""
+    plan_mod, hip = planmod
+    import torch
+    cfg = pkg.synth.CONFIGS["8b-vocab"]
+    m = pkg.synth.make_torch(cfg, seed=71, device="cuda" if torch.cuda.is_available() else "cpu")
+    plan = plan_mod.HipMasterPlan(m)
+    o = orc.COracle(m)
+    logits = o.forward(128000, 0)
+    rng = pkg.javarand.L32X64MixRandom(99)
+    n = 0
+    for temperature in (0.02, 0.1, 0.7, 1.0, 3.0):
+        for topp in (0.5, 0.9, 0.95, 0.999):
+            for _ in range(10):
+                coin = rng.next_float()
+                want = orc.sample(logits, temperature, topp, coin)
+                got = plan.forward_decode_sample(128000, 0, temperature, topp, coin)
+                assert got == want, (temperature, topp, coin)
+                n += 1
+    dev, host = plan.topp_counts()
+    assert dev + host == n and dev >= 0.8 * n, (dev, host)
+    plan.freeTornadoExecutionPlan()
