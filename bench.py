@@ -338,17 +338,27 @@ def main():
             roofline_pp["matrix_pipe_floor_us"] = round(mfma_floor_us, 1)
             roofline_pp["frac_of_matrix_pipe_floor"] = round(mfma_floor_us / g["avg_us"], 4)
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read in-process, so `traffic` stays null in this line.  The figure of
-    # the round's SEPARATE rocprofv3 --pmc FETCH_SIZE pass over this same command (profiles/rNN_pmc_fetch_summary.csv, x2 gfx950
-    # correction) is attached under a key that says so.
+    # HBM traffic of the dominant kernel: PMC counters cannot be read in-process (--pmc needs its own rocprofv3 pass).  The round's
+    # separate FETCH_SIZE pass over this same command is committed as profiles/rNN_pmc_fetch_summary.csv (x2 gfx950 correction) together
+    # with a .meta.json naming the SHA-256 of the kernel source it profiled.  When that hash equals the source of THIS build the counter
+    # figure IS this kernel's traffic and fills `traffic` (the method string says where it comes from); otherwise `traffic` stays null and
+    # the stale figure rides under a key that says so.
     try:
         import csv
         import glob
+        import hashlib
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_summary.csv")))[-1]
+        src_sha = hashlib.sha256(open(os.path.join(ROOT, "gpullama3.java_amd", "csrc", "gl3_decode_kernels.h"), "rb").read()).hexdigest()
+        meta_path = f.replace(".csv", ".meta.json")
+        meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
         for r in csv.reader(open(f)):
             if "matvec_q8t_kernel<0, 2" in r[0] and world == 1 and args.model == "llama-3-8b" and args.wtype == "q8_0":
-                roofline["traffic_not_measured_in_this_run"] = dict(bytes_per_launch=int(r[-1]), source=os.path.relpath(f, ROOT) +
-                                                                   " (FETCH_SIZE x 2, separate rocprofv3 --pmc pass of this command)")
+                src = os.path.relpath(f, ROOT) + " (FETCH_SIZE x 2, separate rocprofv3 --pmc pass of this command)"
+                if meta.get("gl3_decode_kernels_sha256") == src_sha:
+                    roofline["traffic"] = int(r[-1])
+                    roofline["method"] += "; traffic: not measured in this run — " + src + ", taken on this build's kernel source (sha256 " + src_sha[:12] + ")"
+                else:
+                    roofline["traffic_not_measured_in_this_run"] = dict(bytes_per_launch=int(r[-1]), source=src + "; kernel source changed since")
     except Exception:
         pass
 

@@ -321,7 +321,15 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
         attn_head_dispatch(d.head_size, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ctx->heads_l), dim3(256), attn_head_smem(d.head_size), ctx->stream, aa); });
         return;
     }
-    if (which != 2) hipLaunchKernelGGL(attn_scores_kernel, dim3(ctx->n_tsplit, ctx->kv_heads_l), dim3(64 * kvmul), sm1, ctx->stream, aa);
+    // GL3_ATTN_SCORES_LOOP=0: the one-tile-per-workgroup scores kernel at every depth (A/B switch)
+    static const bool scores_loop = env_flag("GL3_ATTN_SCORES_LOOP", true);
+    if (which != 2 && amode == ATT_LONG && scores_loop && kvmul <= 4 && (d.head_size == 128 || d.head_size == 64)) {
+        const dim3 sg(ctx->n_tsplit < SCL_WGS ? ctx->n_tsplit : SCL_WGS, ctx->kv_heads_l), sb(64 * (kvmul + SCL_LOADERS));
+        const size_t sml = ((size_t)kvmul * d.head_size + 2 * (size_t)ATT_TT * (d.head_size + 4) + 2 * d.head_size) * 4;
+        if (d.head_size == 128) hipLaunchKernelGGL(attn_scores_loop_kernel<128>, sg, sb, sml, ctx->stream, aa, ctx->n_tsplit);
+        else hipLaunchKernelGGL(attn_scores_loop_kernel<64>, sg, sb, sml, ctx->stream, aa, ctx->n_tsplit);
+    }
+    else if (which != 2) hipLaunchKernelGGL(attn_scores_kernel, dim3(ctx->n_tsplit, ctx->kv_heads_l), dim3(64 * kvmul), sm1, ctx->stream, aa);
     if (which != 1 && amode == ATT_LONG) {
         hipLaunchKernelGGL(attn_exp_kernel, dim3((d.ctx + EXP_ROW - 1) / EXP_ROW, ctx->heads_l), dim3(256), 0, ctx->stream, aa, ctx->n_tsplit);
         hipLaunchKernelGGL(attn_sum_kernel, dim3(ctx->heads_l), dim3(256), attn_sum_smem(), ctx->stream, aa);
@@ -627,6 +635,8 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
 #undef GL3_RL_LDS
     TRYHIP(hipFuncSetAttribute((const void*)rmsnorm_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     TRYHIP(hipFuncSetAttribute((const void*)attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    TRYHIP(hipFuncSetAttribute((const void*)attn_scores_loop_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    TRYHIP(hipFuncSetAttribute((const void*)attn_scores_loop_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     TRYHIP(hipFuncSetAttribute((const void*)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     TRYHIP(hipFuncSetAttribute((const void*)attn_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_sum_smem()));
     TRYHIP(hipFuncSetAttribute((const void*)attn_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_pv_smem()));

@@ -88,6 +88,12 @@ struct MoeSlots {
     float* sh_out;
 };
 
+// Workgroup barrier for LDS hand-overs: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also waits for vmcnt(0) — every global load
+// a wavefront has in flight — which turns a prefetch issued in front of it into a full memory round trip per barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct LdsBarrier { __device__ __forceinline__ void operator()() const { lds_barrier(); } };      // Sync functor of exact_seqsum_lds
+
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -641,6 +647,154 @@ static __global__ void attn_scores_kernel(const AttnArgs a) {
     }
 }
 
+// Long-context form of attn_scores_kernel (r5, positions >= attn_mid; head_size 64 / 128, kvMul <= 4): grid = (SCL_WGS, n_kv_heads), every
+// workgroup LOOPS over the score tiles w, w + SCL_WGS, ... of its kv head, with two kinds of wavefronts:
+//   chain wavefronts (one per query head of the group, lane = timestep of the tile): q (broadcast) and the lane's K row come from LDS
+//       in groups of four 16-byte quads, the next group's reads pinned in flight under the current group's 16 multiply-add pairs;
+//   loader wavefronts (4): K rows of the tile THREE trips ahead are requested into named registers (rows of 512 / 256 bytes, fully
+//       coalesced), the tile one trip ahead is written into the other half of a double-buffered LDS image.
+// The one-tile-per-workgroup kernel above pays, per tile, an exposed HBM round trip for K, the q staging and RoPE (2064 workgroups at
+// depth 16384, each redoing them) and chains that read q AND k from LDS right in front of their use (~130 cycles per element when a CU
+// holds only four wavefronts; it gets by on 16 resident wavefronts per CU): 27.9 us per 8B layer for 67 MB of K.  Same arithmetic, same order.
+constexpr int SCL_WGS = 32, SCL_LOADERS = 4;
+template <int HS>
+static __global__ __launch_bounds__(64 * (4 + SCL_LOADERS), 1) void attn_scores_loop_kernel(const AttnArgs a, int n_tiles_max) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int hs = HS, half = HS / 2, pitch = HS + 4, q4 = HS / 4;
+    const int kvmul = a.n_heads / a.n_kv_heads;
+    float* q_s = sm;                               // [kvmul][hs]
+    float* kt = q_s + kvmul * hs;                  // [2][ATT_TT][hs + 4]
+    float* krow_s = kt + 2 * ATT_TT * pitch;       // [hs] this position's rotated key (owner workgroup)
+    float* cr_s = krow_s + hs;                     // [hs/2]
+    float* ci_s = cr_s + half;                     // [hs/2]
+    const int t = threadIdx.x, nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int w = blockIdx.x, kvh = blockIdx.y;
+    const int pos = a.dyn[1];
+    const int ntile = pos / ATT_TT + 1;
+    if (w >= ntile) return;
+    const int cnt = (ntile - w + SCL_WGS - 1) / SCL_WGS;             // my tiles: w + i SCL_WGS, i < cnt
+    const bool owner = ((ntile - 1) % SCL_WGS) == w;                 // the tile that holds `pos` is mine
+    // ---- once per workgroup: q of the group's heads (+ bias), the RoPE row of `pos`, per-head RMSNorm (qwen3), RoPE; the owner also
+    // rotates this position's key and writes the KV row (InferenceCore.java:75-93)
+    for (int i = t; i < kvmul * hs; i += nthr) q_s[i] = a.bq ? a.qkv[(kvh * kvmul) * hs + i] + a.bq[(kvh * kvmul) * hs + i] : a.qkv[(kvh * kvmul) * hs + i];
+    for (int i = t; i < half; i += nthr) { cr_s[i] = a.rope_cr[(size_t)pos * half + i]; ci_s[i] = a.rope_ci[(size_t)pos * half + i]; }
+    float vraw = 0.f;
+    if (owner && t < hs) {
+        krow_s[t] = a.bk ? a.qkv[a.q_dim + kvh * hs + t] + a.bk[kvh * hs + t] : a.qkv[a.q_dim + kvh * hs + t];
+        vraw = a.bv ? a.qkv[a.q_dim + a.kv_dim + kvh * hs + t] + a.bv[kvh * hs + t] : a.qkv[a.q_dim + a.kv_dim + kvh * hs + t];
+    }
+    __syncthreads();
+    if (a.arch == 1) {
+        const int nvec = kvmul + (owner ? 1 : 0);
+        for (int vec = wave; vec < nvec; vec += nthr >> 6) head_rmsnorm_wave(vec < kvmul ? q_s + vec * hs : krow_s, vec < kvmul ? a.qnorm : a.knorm, hs, a.eps, t & 63);
+        __syncthreads();
+    }
+    for (int h = 0; h < kvmul; ++h) rope_head(q_s + h * hs, hs, cr_s, ci_s, a.arch, t, nthr);
+    if (owner) rope_head(krow_s, hs, cr_s, ci_s, a.arch, t, nthr);
+    __syncthreads();
+    if (owner && t < hs) {
+        a.kcache[(size_t)pos * a.kv_dim + kvh * hs + t] = krow_s[t];
+        a.vcache[(size_t)pos * a.kv_dim + kvh * hs + t] = vraw;
+    }
+    if (wave >= kvmul) {
+        // ------------------------------------------------------------------ loaders
+        if (wave >= kvmul + SCL_LOADERS) return;                   // (blocks are launched with kvmul + SCL_LOADERS wavefronts: none)
+        const int lt = t - 64 * kvmul;                              // 0 .. 255
+        constexpr int PER = ATT_TT * q4 / (64 * SCL_LOADERS);      // float4 pieces of a tile per loader thread: 8 (hs 128) / 4 (hs 64)
+        // three tiles in flight in NAMED registers (an array carried across the barriers of a loop is kept in scratch by hipcc)
+#define SCL_DECL(S_) float4 S_##0 = {0.f, 0.f, 0.f, 0.f}, S_##1 = S_##0, S_##2 = S_##0, S_##3 = S_##0, S_##4 = S_##0, S_##5 = S_##0, S_##6 = S_##0, S_##7 = S_##0
+        SCL_DECL(k0_); SCL_DECL(k1_); SCL_DECL(k2_);
+#undef SCL_DECL
+        const float* kb = a.kcache + (size_t)kvh * hs;
+        // rows past pos - 1 do not exist in the cache yet: clamped (row pos is taken from krow_s, later rows are never stored as scores)
+#define SCL_LOAD1(S_, U_, T0_) do { if ((U_) < PER) { const int p_ = lt + 256 * (U_), row_ = max(min((T0_) + p_ / q4, pos - 1), 0); \
+            S_##U_ = *reinterpret_cast<const float4*>(kb + (size_t)row_ * a.kv_dim + 4 * (p_ % q4)); } } while (0)
+#define SCL_LOAD(S_, I_) do { \
+            const int t0_ = (w + min((I_), cnt - 1) * SCL_WGS) * ATT_TT; \
+            SCL_LOAD1(S_, 0, t0_); SCL_LOAD1(S_, 1, t0_); SCL_LOAD1(S_, 2, t0_); SCL_LOAD1(S_, 3, t0_); \
+            SCL_LOAD1(S_, 4, t0_); SCL_LOAD1(S_, 5, t0_); SCL_LOAD1(S_, 6, t0_); SCL_LOAD1(S_, 7, t0_); \
+        } while (0)
+        // (only rows that exist in the cache are written: in the tile that holds pos another wavefront writes row pos from krow_s, and a
+        // clamped copy of row pos - 1 landing there afterwards was a write-write race — position 130 = row 2 of its tile failed, 128 / 129 not)
+#define SCL_STORE1(S_, U_, KD_) do { if ((U_) < PER) { const int p_ = lt + 256 * (U_); \
+            if (st0_ + p_ / q4 < pos) *reinterpret_cast<float4*>((KD_) + (p_ / q4) * pitch + 4 * (p_ % q4)) = S_##U_; } } while (0)
+#define SCL_STORE(S_, I_) do { \
+            float* kd_ = kt + ((I_) & 1) * ATT_TT * pitch; \
+            const int st0_ = (w + (I_) * SCL_WGS) * ATT_TT; \
+            SCL_STORE1(S_, 0, kd_); SCL_STORE1(S_, 1, kd_); SCL_STORE1(S_, 2, kd_); SCL_STORE1(S_, 3, kd_); \
+            SCL_STORE1(S_, 4, kd_); SCL_STORE1(S_, 5, kd_); SCL_STORE1(S_, 6, kd_); SCL_STORE1(S_, 7, kd_); \
+            if (owner && (I_) == cnt - 1 && lt < q4)        /* the tile that holds pos: its row is this step's own key */ \
+                *reinterpret_cast<float4*>(kd_ + (pos & (ATT_TT - 1)) * pitch + 4 * lt) = *reinterpret_cast<const float4*>(krow_s + 4 * lt); \
+        } while (0)
+#define SCL_STEP(S_, I_) do { \
+            if ((I_) < cnt) {                               /* workgroup-uniform: every wavefront runs exactly cnt barriers */ \
+                PV_T(const long long s0_ = clock64();) \
+                SCL_STORE(S_, (I_)); \
+                PV_T(const long long b0_ = clock64(); lst_ += b0_ - s0_;) \
+                lds_barrier(); \
+                PV_T(lbw_ += clock64() - b0_;) \
+            } \
+            SCL_LOAD(S_, (I_) + 3);                         /* unconditional (clamped): no wait at the end of a branch */ \
+        } while (0)
+        PV_T(long long lst_ = 0, lbw_ = 0; const long long lts_ = clock64();)
+        SCL_LOAD(k0_, 0); SCL_LOAD(k1_, 1); SCL_LOAD(k2_, 2);
+        for (int i = 0; i < cnt; i += 3) { SCL_STEP(k0_, i); SCL_STEP(k1_, i + 1); SCL_STEP(k2_, i + 2); }
+        PV_T(if (blockIdx.x == 0 && blockIdx.y == 0 && lt == 0) { gl3_mv_stamp[8] = lst_; gl3_mv_stamp[9] = lbw_; gl3_mv_stamp[10] = clock64() - lts_; })
+#undef SCL_LOAD
+#undef SCL_LOAD1
+#undef SCL_STORE
+#undef SCL_STORE1
+#undef SCL_STEP
+        return;
+    }
+    // ---------------------------------------------------------------------- chains: wavefront = query head, lane = timestep of the tile
+    const int hq = wave, r = t & 63;
+    const float sqrt_hs = (float)sqrt((double)hs);
+    const float4* q4p = reinterpret_cast<const float4*>(q_s + hq * hs);      // wave-uniform addresses: LDS broadcast reads
+    PV_T(long long cbw_ = 0; const long long cts_ = clock64();)
+    for (int i = 0; i < cnt; ++i) {
+        const int sp = w + i * SCL_WGS, t0 = sp * ATT_TT, t1 = min(pos + 1, t0 + ATT_TT);
+        PV_T(const long long cb0_ = clock64();)
+        lds_barrier();                                      // tile i is in buffer i & 1 (and buffer (i + 1) & 1 may be overwritten)
+        PV_T(cbw_ += clock64() - cb0_;)
+        // every lane runs the chain (rows past the tile's end read stale LDS and are not stored): no divergence around the pinned reads
+        const float4* kk4 = reinterpret_cast<const float4*>(kt + (i & 1) * ATT_TT * pitch + r * pitch);
+        float score = 0.f;                                  // strict j order, mul then add (FloatTensor.scalarDot)
+        // four quads of q and of k a group, the next group's eight reads in flight under the current group's 16 multiply-add pairs; the
+        // sched_barriers keep that order (left alone the scheduler sinks every read next to its use and the chain waits an LDS round
+        // trip per quad).  (q in HS registers instead of LDS reads needs more than the 256 registers of two wavefronts per SIMD: the
+        // spilled part was re-read from scratch every tile, 44 cycles per element.)
+        float4 qa[4], ka[4], qb[4], kb[4];
+#define SCL_RD(Q_, K_, Q0_) do { _Pragma("unroll") for (int u = 0; u < 4; ++u) { Q_[u] = q4p[(Q0_) + u]; K_[u] = kk4[(Q0_) + u]; } } while (0)
+#define SCL_USE(Q_, K_) do { _Pragma("unroll") for (int u = 0; u < 4; ++u) { \
+            score = score + mul_f32_scalar(Q_[u].x, K_[u].x); score = score + mul_f32_scalar(Q_[u].y, K_[u].y); \
+            score = score + mul_f32_scalar(Q_[u].z, K_[u].z); score = score + mul_f32_scalar(Q_[u].w, K_[u].w); } } while (0)
+        SCL_RD(qa, ka, 0);
+#pragma unroll
+        for (int g = 0; g < HS / 16; g += 2) {
+            SCL_RD(qb, kb, 4 * (g + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            SCL_USE(qa, ka);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < HS / 16) SCL_RD(qa, ka, 4 * (g + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            SCL_USE(qb, kb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef SCL_RD
+#undef SCL_USE
+        float my_score = -INFINITY;
+        if (t0 + r < t1) {
+            my_score = a.att_mul != 0.f ? score * a.att_mul : score / sqrt_hs;
+            a.att[(size_t)(kvh * kvmul + hq) * a.att_stride + t0 + r] = my_score;
+        }
+        const float m = wave_max(my_score);                 // the tile's maximum per head (attn_exp_kernel folds the tiles)
+        if (r == 0) a.tmax[(size_t)(kvh * kvmul + hq) * n_tiles_max + sp] = m;
+    }
+    PV_T(if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) { gl3_mv_stamp[5] = cbw_; gl3_mv_stamp[6] = clock64() - cts_; gl3_mv_stamp[7] = cnt; })
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Short-context decode attention in ONE launch (positions < AF_MAXN): RoPE + KV write + scores + softmax + weighted V
 // sum.  Same arithmetic and order as the two-kernel path above/below; what it saves is a launch, two kernel boundaries
@@ -1020,11 +1174,6 @@ __host__ __device__ inline int attn_pv_hq(int kvmul) { return (kvmul + PV_G - 1)
 // floats of the transposed weight buffer att_t[kv head][head quad][t][PV_G] (written by attn_softmax_kernel, read by attn_pv_kernel)
 __host__ __device__ inline size_t attn_att_t_floats(int kv_heads, int kvmul, int att_stride) { return (size_t)kv_heads * attn_pv_hq(kvmul) * att_stride * PV_G + (size_t)PVT * PV_G; }
 
-// Workgroup barrier for LDS hand-overs: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also waits for vmcnt(0) — every global load
-// a wavefront has in flight — which turns a prefetch issued in front of it into a full memory round trip per barrier.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-struct LdsBarrier { __device__ __forceinline__ void operator()() const { lds_barrier(); } };      // Sync functor of exact_seqsum_lds
 
 constexpr int SMX_CHUNK = 4096;
 __host__ __device__ constexpr size_t attn_sum_smem() { return (size_t)(SMX_CHUNK + 32) * 4 + ss_scratch_bytes(SMX_CHUNK); }
@@ -1131,7 +1280,7 @@ static __global__ __launch_bounds__(64 * PV_WAVES) void attn_pv_kernel(const Att
             PV_T(tw_ += clock64() - b0_;)
             const float* pb = pbuf + (size_t)(k & 1) * QPT * PV_QP + 4 * lane;
             // eight quads per group, the next group's reads in flight under this group's 32 dependent adds
-            float4 ra[8], rb[8];
+            float4 ra[8], rb[8], rc[8];
 #define PV_RD8(R_, Q0_) do { _Pragma("unroll") for (int u = 0; u < 8; ++u) R_[u] = *reinterpret_cast<const float4*>(pb + ((Q0_) + u) * PV_QP); } while (0)
             // sixteen adds as ONE asm statement: the compiler then waits once for the four quads (s_waitcnt lgkmcnt(n) in front of the
             // statement) instead of once per quad — every s_waitcnt is an issue slot of the wavefront the whole workgroup waits for
@@ -1143,20 +1292,20 @@ static __global__ __launch_bounds__(64 * PV_WAVES) void attn_pv_kernel(const Att
                 : "+v"(acc) : "v"((A_).x), "v"((A_).y), "v"((A_).z), "v"((A_).w), "v"((B_).x), "v"((B_).y), "v"((B_).z), "v"((B_).w), \
                               "v"((C_).x), "v"((C_).y), "v"((C_).z), "v"((C_).w), "v"((D_).x), "v"((D_).y), "v"((D_).z), "v"((D_).w))
 #define PV_ADD8(R_) do { PV_ADD4Q(R_[0], R_[1], R_[2], R_[3]); PV_ADD4Q(R_[4], R_[5], R_[6], R_[7]); } while (0)
+            // three groups of eight quads: two groups (the helpers' stores share the LDS with these reads) are in flight under a group's adds
             PV_RD8(ra, 0);
             PV_RD8(rb, 8);
+            PV_RD8(rc, 16);
             __builtin_amdgcn_sched_barrier(0);
             PV_ADD8(ra);
             __builtin_amdgcn_sched_barrier(0);
-            PV_RD8(ra, 16);
+            PV_RD8(ra, 24);
             __builtin_amdgcn_sched_barrier(0);
             PV_ADD8(rb);
             __builtin_amdgcn_sched_barrier(0);
-            PV_RD8(rb, 24);
+            PV_ADD8(rc);
             __builtin_amdgcn_sched_barrier(0);
             PV_ADD8(ra);
-            __builtin_amdgcn_sched_barrier(0);
-            PV_ADD8(rb);
 #undef PV_ADD4Q
 #undef PV_ADD8
 #undef PV_RD8
@@ -1209,10 +1358,15 @@ static __global__ __launch_bounds__(64 * PV_WAVES) void attn_pv_kernel(const Att
         } \
         PVH_STORE_G(pb_, a_, v_, 0); PVH_STORE_G(pb_, a_, v_, 1); PVH_STORE_G(pb_, a_, v_, 2); PVH_STORE_G(pb_, a_, v_, 3); \
     } while (0)
+#ifdef PV_NO_STORE                 /* probe build: chain speed without the helpers' LDS traffic (wrong results) */
+#define PVH_STORE_X(S_, K_) do {} while (0)
+#else
+#define PVH_STORE_X(S_, K_) PVH_STORE(S_, K_)
+#endif
 #define PVH_STEP(S_, K_) do { \
         if ((K_) < ntiles) {                                /* wave-uniform; the chain runs exactly ntiles barriers */ \
             PV_T(const long long s0_ = clock64();) \
-            PVH_STORE(S_, (K_));                            /* buffer K & 1: the chain finished tile K - 2 before the last barrier */ \
+            PVH_STORE_X(S_, (K_));                          /* buffer K & 1: the chain finished tile K - 2 before the last barrier */ \
             PV_T(const long long b0_ = clock64(); tst_ += b0_ - s0_;) \
             lds_barrier(); \
             PV_T(tw_ += clock64() - b0_;) \
@@ -1228,6 +1382,7 @@ static __global__ __launch_bounds__(64 * PV_WAVES) void attn_pv_kernel(const Att
 #undef PVH_LOAD
 #undef PVH_STORE
 #undef PVH_STORE_G
+#undef PVH_STORE_X
 #undef PVH_QUAD
 #undef PVH_STEP
 }

@@ -28,6 +28,35 @@ int main() {
         float *dtm, *dsum; hipMalloc(&dtm, tm.size() * 4); hipMalloc(&dsum, H * 4); hipMemcpy(dtm, tm.data(), tm.size() * 4, hipMemcpyHostToDevice); a.tmax = dtm; a.sums = dsum;
         hipFuncSetAttribute((const void*)attn_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_sum_smem());
         hipFuncSetAttribute((const void*)attn_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_pv_smem());
+        // scores: random K cache / q of the 8B shape (RoPE table of ones and zeros: the rotation is not what is timed)
+        std::vector<float> kc((size_t)(ctx + PVT) * kvd), qkvh((size_t)H * hs + 2 * kvd), cr((size_t)ctx * hs / 2, 1.f), ci((size_t)ctx * hs / 2, 0.f);
+        for (auto& x : kc) x = rand() / (float)RAND_MAX - 0.5f;
+        for (auto& x : qkvh) x = rand() / (float)RAND_MAX - 0.5f;
+        float *dk, *dqkv, *dcr, *dci;
+        hipMalloc(&dk, kc.size() * 4); hipMalloc(&dqkv, qkvh.size() * 4); hipMalloc(&dcr, cr.size() * 4); hipMalloc(&dci, ci.size() * 4);
+        hipMemcpy(dk, kc.data(), kc.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dqkv, qkvh.data(), qkvh.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dcr, cr.data(), cr.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dci, ci.data(), ci.size() * 4, hipMemcpyHostToDevice);
+        a.kcache = dk; a.qkv = dqkv; a.rope_cr = dcr; a.rope_ci = dci; a.q_dim = H * hs; a.eps = 1e-5f;
+        {
+            const int kvmul = H / KVH;
+            const size_t sml = ((size_t)kvmul * hs + 2 * (size_t)ATT_TT * (hs + 4) + 2 * hs) * 4, sm1 = ((size_t)kvmul * hs + (size_t)ATT_TT * (hs + 4) + hs) * 4;
+            hipFuncSetAttribute((const void*)attn_scores_loop_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            hipFuncSetAttribute((const void*)attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            hipEvent_t s0, s1, s2; hipEventCreate(&s0); hipEventCreate(&s1); hipEventCreate(&s2);
+            float ml = 0, mo = 0;
+            for (int i = 0; i < 12; ++i) {
+                hipEventRecord(s0);
+                attn_scores_loop_kernel<128><<<dim3(nts < SCL_WGS ? nts : SCL_WGS, KVH), 64 * (kvmul + SCL_LOADERS), sml>>>(a, nts);
+                hipEventRecord(s1);
+                attn_scores_kernel<<<dim3(nts, KVH), 64 * kvmul, sm1>>>(a);
+                hipEventRecord(s2); hipEventSynchronize(s2);
+                float m1, m2; hipEventElapsedTime(&m1, s0, s1); hipEventElapsedTime(&m2, s1, s2);
+                if (i >= 2) { ml += m1; mo += m2; }
+            }
+            long long st[32]; hipMemcpyFromSymbol(st, HIP_SYMBOL(gl3::gl3_mv_stamp), sizeof(st));
+            printf("n %5d: scores loop kernel %.2f us (one-tile kernel %.2f us) | chain wave 0 of workgroup (0, 0): %lld tiles, %lld cycles, %lld waiting at barriers | loader thread 0: "
+                   "%lld cycles, storing %lld, waiting at barriers %lld\n", n, ml * 100, mo * 100, st[7], st[6], st[5], st[10], st[8], st[9]);
+        }
         hipEvent_t e0, e1, e2, e3; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3);
         float ms_s = 0, ms_p = 0, ms_e = 0;
         const int reps = 10;
@@ -48,7 +77,7 @@ int main() {
         printf("n %5d: exp %.2f us, sum %.2f us, pv %.2f us (%d workgroups of %d threads, cols %d) | chain wave: %lld cycles total = %.1f per timestep, %lld waiting at barriers (%.0f per tile)"
                " | helper wave 0: total %lld, barrier wait %lld, store+load issue %lld\n", n, ms_e * 1e3 / reps, ms_s * 1e3 / reps, ms_p * 1e3 / reps, KVH * attn_pv_hq(H / KVH) * (hs / PV_COLS16), 64 * PV_WAVES,
                PV_COLS16, st[1], (double)st[1] / n, st[0], (double)st[0] / ntiles, st[4], st[2], st[3]);
-        hipFree(dtm); hipFree(dsum); hipFree(datt_t); hipFree(datt); hipFree(datt0); hipFree(dv); hipFree(dxb); hipFree(ddyn);
+        hipFree(dk); hipFree(dqkv); hipFree(dcr); hipFree(dci); hipFree(dtm); hipFree(dsum); hipFree(datt_t); hipFree(datt); hipFree(datt0); hipFree(dv); hipFree(dxb); hipFree(ddyn);
     }
     return 0;
 }

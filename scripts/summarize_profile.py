@@ -35,6 +35,13 @@ if os.path.isdir(pmc_dir):
         for k, v in sorted(acc.items()):
             mean = sum(v) / len(v)
             w.writerow(list(k) + [len(v), round(mean, 3), int(mean * 1024 * 2)])
+    # which kernel source the counters belong to: bench.py fills roofline.traffic from this table only while the hash still matches
+    import hashlib
+    import json
+    hdr = os.path.join(os.path.dirname(out), "gpullama3.java_amd", "csrc", "gl3_decode_kernels.h")
+    json.dump({"gl3_decode_kernels_sha256": hashlib.sha256(open(hdr, "rb").read()).hexdigest(),
+               "command": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 1 --no-pp --no-cpu-baseline"},
+              open(os.path.join(out, tag + "_pmc_fetch_summary.meta.json"), "w"))
 print("wrote", [x for x in os.listdir(out) if x.startswith(tag)])
 
 # ---- round 3 additions: SQ / matrix-pipe counters of the batched-prefill kernels, their FETCH_SIZE, further kernel statistics

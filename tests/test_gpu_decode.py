@@ -501,12 +501,13 @@ def test_long_context_prefill_and_decode(pkg, orc, planmod, cfg, window, monkeyp
 
 
 @pytest.mark.gpu
-def test_context_beyond_20k_positions(pkg, orc, planmod):
+@pytest.mark.parametrize("cfg", ["tiny-llama", "tiny-qwen3", "mid-qwen3"])      # head sizes 32 (one-tile scores kernel), 64 and 128 (looping scores kernel, ~10 tiles per workgroup)
+def test_context_beyond_20k_positions(pkg, orc, planmod, cfg):
     """Round 2 rejected contexts above ~20 k positions (the decode attention kept a ctx-long softmax row in LDS); the reference has
     no such cap (InferenceCore.java:98-137 is O(pos)).  A decode step at position 20 600 of a 21 000-position context, on a KV cache
     that holds one prefilled chunk and zeros elsewhere (both sides zero-initialise it), is bit-identical to the oracle."""
     plan_mod, hip = planmod
-    base = pkg.synth.CONFIGS["tiny-llama"]
+    base = pkg.synth.CONFIGS[cfg]
     m = pkg.synth.make_numpy(pkg.synth.ModelConfig(**{**base.__dict__, "ctx": 21000}), seed=5)
     plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=64)
     o = orc.COracle(m)
