@@ -50,6 +50,7 @@ static void launch_mv(gl3_ctx* ctx, K kernel, int wgs, int threads, size_t smem,
 
 template <int PRO, int EPI>
 static void launch_matvec_t(gl3_ctx* ctx, const MatvecArgs& a, int wgs, size_t smem, bool nt) {
+    if (a.tp) { launch_mv(ctx, matvec_q8t_kernel<PRO, EPI, true, 4, false, true>, wgs, mv_threads(4), smem, a); return; }   // folded gathers
     if (nt) launch_mv(ctx, matvec_q8t_kernel<PRO, EPI, true>, wgs, mv_threads(4), smem, a);
     else launch_mv(ctx, matvec_q8t_kernel<PRO, EPI, false>, wgs, mv_threads(4), smem, a);
 }
@@ -58,12 +59,14 @@ template <int PRO, int EPI>
 static hipError_t allow_big_lds() {
     hipError_t e = hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO, EPI, true, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)matvec_q8t_kernel<PRO, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 }
 
 // rows_valid / out / resid_in may address a slice (tensor parallel row split); w holds exactly that slice.
 static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const Q8Mat* w2, const float* x,
-                          const float* norm_w, float* out, const float* resid_in, float out_scale = 1.0f) {
+                          const float* norm_w, float* out, const float* resid_in, float out_scale = 1.0f, const TpRec* tp = nullptr) {
     if (w.fmt != GL3_TYPE_Q8_0) {      // F16 / Q4_0: element-wise chains, one output row per lane (gl3_rowlane_kernels.h)
         hipStream_t s = ctx->stream;
         // Vector-order kernels normalise in their own prologue (matvec_vl_kernel<.., RMS>); GL3_VL_RMS=0: separate rmsnorm launch
@@ -155,12 +158,15 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
     MatvecArgs a{};
     a.w = w.w; a.w2 = w2 ? w2->w : nullptr; a.rows = w.rows; a.k = w.k; a.ng = w.ng; a.nstrips = w.nstrips;
     a.x = x; a.norm_w = norm_w; a.eps = ctx->d.rms_eps; a.out = out; a.resid_in = resid_in; a.out_scale = out_scale;
+    a.tp = tp;
     const int wgs = w.nstrips < max_wgs ? w.nstrips : max_wgs;
     const size_t smem = matvec_smem(pro, epi, w);
     if (pro == PRO_RMS && epi == EPI_STORE) launch_matvec_t<PRO_RMS, EPI_STORE>(ctx, a, wgs, smem, nt);
     else if (pro == PRO_QUANT && epi == EPI_RESID) {
         static const int wide_max = getenv("GL3_WIDE_STRIPS") ? atoi(getenv("GL3_WIDE_STRIPS")) : 256;
-        if (w.nstrips <= wide_max && nt)      // one workgroup per CU: 8 producer wavefronts
+        if (w.nstrips <= wide_max && nt && tp)
+            launch_mv(ctx, matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 8, false, true>, wgs, mv_threads(8), smem, a);
+        else if (w.nstrips <= wide_max && nt)      // one workgroup per CU: 8 producer wavefronts
             launch_mv(ctx, matvec_q8t_kernel<PRO_QUANT, EPI_RESID, true, 8>, wgs, mv_threads(8), smem, a);
         else launch_matvec_t<PRO_QUANT, EPI_RESID>(ctx, a, wgs, smem, nt);
     }
@@ -282,6 +288,75 @@ static void enqueue_moe_ffn(gl3_ctx* ctx, int l, Prof& pr) {
     pr.end();
 }
 
+// ---- folded gathers (TpRec, gl3_decode_kernels.h; protocol notes in gl3_tp.hip).  Records per layer + embedding + logits, built
+// once the peers' arenas are known (gl3_finalize).  ctx->tp_fold: 0 = gather kernels (every type but the Q8_0 int8 path, RCCL
+// transport, GL3_TP_FOLD=0), 1 = producers push; the consumer side is a one-wavefront wait launch (GL3_TP_FOLD=1) or the consumer's
+// own prologue (GL3_TP_FOLD=2: no launch is left between producer and consumer; ranks must not share a GPU once the models are
+// large enough for a polling consumer to fill it), per consumer kind in ctx->tp_fold_mask.
+enum { TR_ATTN = 0, TR_WO, TR_GATEUP, TR_DOWN, TR_QKV, TR_WAIT_XB, TR_WAIT_HB, TR_WAIT_X, TR_PER_LAYER };
+enum { TF_WO = 1, TF_DOWN = 2, TF_QKV = 4, TF_LOGITS = 8, TF_EMBED = 16 };
+static int32_t tp_fold_setup(gl3_ctx* ctx) {
+    const gl3_model_desc& d = ctx->d;
+    ctx->tp_fold = 0;
+    const int mode = getenv("GL3_TP_FOLD") ? atoi(getenv("GL3_TP_FOLD")) : 1;
+    if (!ctx->use_rccl || ctx->transport != GL3_TP_P2P || d.tp_size < 2 || mode <= 0) return GL3_OK;
+    if (ctx->emb.fmt != GL3_TYPE_Q8_0 || !ctx->wo_replicated || d.arch == GL3_ARCH_QWEN2MOE || env_flag("GL3_TP_DEBUG", false)) return GL3_OK;
+    const int L = d.n_layers, tp = d.tp_size, me = d.tp_rank;
+    // which consumers wait in their own prologue (the others get a wait launch in front): GL3_TP_FOLD=2 all, GL3_TP_FOLD_MASK picks
+    int mask = mode >= 2 ? (TF_WO | TF_DOWN | TF_QKV | TF_LOGITS | TF_EMBED) : 0;
+    if (getenv("GL3_TP_FOLD_MASK")) mask = atoi(getenv("GL3_TP_FOLD_MASK"));
+    uint8_t* own = ctx->arena.base;
+    static const unsigned limit = getenv("GL3_TP_SPIN_LIMIT") ? (unsigned)atol(getenv("GL3_TP_SPIN_LIMIT")) : 20000000u;
+    uint32_t* step = reinterpret_cast<uint32_t*>(own + GL3_ARENA_STEP);
+    auto flags_of = [&](uint8_t* base, int buf) { return reinterpret_cast<uint32_t*>(base + GL3_ARENA_FOLD + (size_t)buf * GL3_MAX_TP * 4); };
+    auto mk_wait = [&](int buf, int add) {
+        TpWait w{};
+        w.flags = flags_of(own, buf); w.step = step; w.err = ctx->h_tp_err; w.mul = L; w.add = add; w.tp = tp; w.me = me; w.spin_limit = limit;
+        return w;
+    };
+    auto mk_push = [&](int buf, int add) {
+        TpPush p{};
+        p.ticket = reinterpret_cast<uint32_t*>(own + GL3_ARENA_FOLD_TICKET) + buf; p.step = step; p.mul = L; p.add = add; p.npeers = tp - 1;
+        for (int j = 0; j < tp - 1; ++j) {
+            uint8_t* peer = ctx->peer_base[(me + 1 + j) % tp];
+            p.delta[j] = (long)(peer - own);
+            p.flag[j] = flags_of(peer, buf) + me;
+        }
+        return p;
+    };
+    std::vector<TpRec> h((size_t)L * TR_PER_LAYER + 2);
+    for (int l = 0; l < L; ++l) {
+        TpRec* r = h.data() + (size_t)l * TR_PER_LAYER;
+        r[TR_ATTN].p = mk_push(GB_XB, l + 1);
+        r[TR_GATEUP].p = mk_push(GB_HB, l + 1);
+        r[TR_DOWN].p = mk_push(GB_X, l + 1);
+        if (mask & TF_WO) r[TR_WO].w = mk_wait(GB_XB, l + 1);
+        if (mask & TF_DOWN) r[TR_DOWN].w = mk_wait(GB_HB, l + 1);
+        if ((mask & TF_QKV) && l > 0) r[TR_QKV].w = mk_wait(GB_X, l);
+        r[TR_WAIT_XB].w = mk_wait(GB_XB, l + 1); r[TR_WAIT_HB].w = mk_wait(GB_HB, l + 1); r[TR_WAIT_X].w = mk_wait(GB_X, l + 1);
+    }
+    h[(size_t)L * TR_PER_LAYER].w = mk_wait(GB_X, 0);          // embedding: the previous step's last pushes into x
+    if (mask & TF_LOGITS) h[(size_t)L * TR_PER_LAYER + 1].w = mk_wait(GB_X, L);
+    GL3_HIP(hipMalloc((void**)&ctx->tp_recs, h.size() * sizeof(TpRec)));
+    GL3_HIP(hipMemcpy(ctx->tp_recs, h.data(), h.size() * sizeof(TpRec), hipMemcpyHostToDevice));
+    ctx->tp_fold = 1; ctx->tp_fold_mask = mask;
+    return GL3_OK;
+}
+static const TpRec* tp_rec(const gl3_ctx* ctx, int l, int which) {
+    return ctx->tp_fold ? reinterpret_cast<const TpRec*>(ctx->tp_recs) + (size_t)l * TR_PER_LAYER + which : nullptr;
+}
+// mode 1: the consumer side of a folded gather as its own one-wavefront launch
+static void fold_wait(gl3_ctx* ctx, int l, int which, Prof& pr) {
+    const int m = ctx->tp_fold_mask, last = l == ctx->d.n_layers - 1;
+    if (which == TR_WAIT_XB && (m & TF_WO)) return;
+    if (which == TR_WAIT_HB && (m & TF_DOWN)) return;
+    if (which == TR_WAIT_X && !last && (m & TF_QKV)) return;
+    if (which == TR_WAIT_X && last && (m & TF_LOGITS) && (m & TF_EMBED)) return;
+    pr.begin(GL3_K_COLLECTIVE, 0);
+    hipLaunchKernelGGL(tp_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, tp_rec(ctx, l, which));
+    pr.end();
+}
+
 static int32_t all_gather(gl3_ctx* ctx, int which, int count_per_rank, Prof& pr) {
     if (!ctx->use_rccl) return GL3_OK;
     pr.begin(GL3_K_COLLECTIVE, 0);
@@ -316,6 +391,7 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
     aa.win = ctx->attn_win;
     aa.att_stride = (d.ctx + 3) & ~3;
     aa.att_t = ctx->att_t; aa.tmax = ctx->att_tmax; aa.sums = ctx->att_sums;
+    aa.tp = tp_rec(ctx, l, TR_ATTN);
     const size_t sm2 = ((size_t)ctx->attn_win + (size_t)pv_rows * PV_COLS) * 4;
     if (which == 0 && amode == ATT_SHORT && ctx->fused_attn_ok) {      // positions < AF_MAXN: one launch
         attn_head_dispatch(d.head_size, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ctx->heads_l), dim3(256), attn_head_smem(d.head_size), ctx->stream, aa); });
@@ -349,7 +425,11 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
     Gl3Range step_range("gl3 decode step");
 
     pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
-    if (ctx->emb.fmt == GL3_TYPE_Q8_0) hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
+    const int fold = ctx->tp_fold, fmask = fold ? ctx->tp_fold_mask : 0, L_ = d.n_layers;
+    if (ctx->emb.fmt == GL3_TYPE_Q8_0)
+        hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale,
+                           (fmask & TF_EMBED) ? tp_rec(ctx, L_, 0) : (const TpRec*)nullptr,
+                           fold ? reinterpret_cast<uint32_t*>(ctx->arena.base + GL3_ARENA_STEP) : (uint32_t*)nullptr);
     else if (ctx->emb.vl && ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_vl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
     else if (ctx->emb.vl && ctx->emb.fmt == GL3_FMT_Q8V) hipLaunchKernelGGL((embed_vl_kernel<WT_Q8_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
     else if (ctx->emb.vl) hipLaunchKernelGGL((embed_vl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
@@ -361,18 +441,20 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
         gl3_layer& L = ctx->layers[l];
         Gl3Range layer_range("layer", l);
         pr.begin(GL3_K_MATVEC_QKV, mv_bytes(L.wqkv) + d.dim * 4, q8);
-        { Gl3Range g("rmsnorm + qkv"); launch_matvec(ctx, PRO_RMS, EPI_STORE, L.wqkv, nullptr, ctx->x, L.attn_norm, ctx->qkv, nullptr); }
+        { Gl3Range g("rmsnorm + qkv"); launch_matvec(ctx, PRO_RMS, EPI_STORE, L.wqkv, nullptr, ctx->x, L.attn_norm, ctx->qkv, nullptr, 1.0f, (fmask & TF_QKV) && l > 0 ? tp_rec(ctx, l, TR_QKV) : nullptr); }
         pr.end();
 
         pr.begin(GL3_K_ATTENTION, 0);
         { Gl3Range g("rope + kv write + attention"); launch_attention(ctx, l, 0, amode); }
         pr.end();
-        if ((r = all_gather(ctx, GB_XB, ctx->q_dim_l, pr)) != GL3_OK) return r;
+        if (fold) fold_wait(ctx, l, TR_WAIT_XB, pr);
+        else if ((r = all_gather(ctx, GB_XB, ctx->q_dim_l, pr)) != GL3_OK) return r;
 
         // x[rows of this rank] += Wo[rows, :] . xb — all rows on every rank when Wo is replicated (no gather behind it)
         const size_t wo_off = ctx->wo_replicated ? 0 : (size_t)rank * ctx->dim_l;
         pr.begin(GL3_K_MATVEC_WO, mv_bytes(L.wo), q8);
-        { Gl3Range g("wo + residual"); launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->x + wo_off, ctx->x + wo_off, ctx->resid_scale); }
+        { Gl3Range g("wo + residual"); launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.wo, nullptr, ctx->xb, nullptr, ctx->x + wo_off, ctx->x + wo_off, ctx->resid_scale,
+                                                        (fmask & TF_WO) ? tp_rec(ctx, l, TR_WO) : nullptr); }
         pr.end();
         if (!ctx->wo_replicated && (r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
 
@@ -382,23 +464,26 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
             continue;
         }
         pr.begin(GL3_K_MATVEC_GATEUP, mv_bytes(L.w1) + L.w3.algo_bytes() + d.dim * 4, q8);
-        { Gl3Range g("rmsnorm + gate/up + swiglu"); launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr); }
+        { Gl3Range g("rmsnorm + gate/up + swiglu"); launch_matvec(ctx, PRO_RMS, EPI_SWIGLU, L.w1, &L.w3, ctx->x, L.ffn_norm, ctx->hb + (size_t)rank * ctx->hidden_l, nullptr, 1.0f,
+                                                                  tp_rec(ctx, l, TR_GATEUP)); }
         pr.end();
-        if ((r = all_gather(ctx, GB_HB, ctx->hidden_l, pr)) != GL3_OK) return r;
+        if (fold) fold_wait(ctx, l, TR_WAIT_HB, pr);
+        else if ((r = all_gather(ctx, GB_HB, ctx->hidden_l, pr)) != GL3_OK) return r;
 
         pr.begin(GL3_K_MATVEC_DOWN, mv_bytes(L.w2), q8);
         { Gl3Range g("down + residual");
           launch_matvec(ctx, PRO_QUANT, EPI_RESID, L.w2, nullptr, ctx->hb, nullptr, ctx->x + (size_t)rank * ctx->dim_l,
-                        ctx->x + (size_t)rank * ctx->dim_l, ctx->resid_scale); }
+                        ctx->x + (size_t)rank * ctx->dim_l, ctx->resid_scale, tp_rec(ctx, l, TR_DOWN)); }
         pr.end();
-        if ((r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
+        if (fold) fold_wait(ctx, l, TR_WAIT_X, pr);
+        else if ((r = all_gather(ctx, GB_X, ctx->dim_l, pr)) != GL3_OK) return r;
         if (ctx->taps) hipMemcpyAsync(ctx->taps + (size_t)l * d.dim, ctx->x, sizeof(float) * d.dim, hipMemcpyDeviceToDevice, s);
     }
     if (want_logits) {
         pr.begin(GL3_K_MATVEC_LOGITS, mv_bytes(ctx->wcls) + d.dim * 4, q8);
         { Gl3Range g("final rmsnorm + logits");
           launch_matvec(ctx, PRO_RMS, EPI_STORE, ctx->wcls, nullptr, ctx->x, ctx->out_norm,
-                        ctx->logits + (size_t)rank * ctx->vocab_l, nullptr, ctx->logit_scale); }
+                        ctx->logits + (size_t)rank * ctx->vocab_l, nullptr, ctx->logit_scale, (fmask & TF_LOGITS) ? tp_rec(ctx, L_, 1) : nullptr); }
         pr.end();
         if ((r = all_gather(ctx, GB_LOGITS, ctx->vocab_l, pr)) != GL3_OK) return r;
     }
@@ -707,7 +792,7 @@ void gl3_destroy(gl3_ctx* ctx) {
         f(L.attn_norm); f(L.ffn_norm); f(L.qnorm); f(L.knorm); f(L.bq); f(L.bk); f(L.bv);
         f(L.gate_exps.w); f(L.up_exps.w); f(L.down_exps.w); f(L.gate_inp); f(L.gate_inp_shexp);
     }
-    f(ctx->moe_logits); f(ctx->moe_w); f(ctx->moe_sel); f(ctx->moe_hb); f(ctx->moe_y); f(ctx->moe_slots);
+    f(ctx->moe_logits); f(ctx->moe_w); f(ctx->moe_sel); f(ctx->moe_hb); f(ctx->moe_y); f(ctx->moe_slots); f(ctx->tp_recs);
     f(ctx->out_norm); f(ctx->rope_cr); f(ctx->rope_ci); f(ctx->kcache); f(ctx->vcache); f(ctx->xn); f(ctx->qkv);
     if (!ctx->arena.base) { f(ctx->x); f(ctx->xb); f(ctx->hb); f(ctx->logits); }
     gl3_tp_arena_free(ctx);
@@ -900,6 +985,7 @@ int32_t gl3_finalize(gl3_ctx* ctx) {
     if (ctx->use_rccl && ctx->transport == GL3_TP_NONE)
         GL3_FAIL(GL3_E_STATE, "tensor parallel plan without gl3_tp_p2p_attach / gl3_tp_init / gl3_tp_attach_local");
     { int32_t r = gl3_tp_local_resolve(ctx); if (r != GL3_OK) return r; }
+    { int32_t r = tp_fold_setup(ctx); if (r != GL3_OK) return r; }
     if (!(ctx->have_global & (1u << GL3_T_OUTPUT))) {   // tied: wcls = this rank's vocab rows of token_embd
         ctx->wcls = ctx->emb;
         ctx->wcls.rows = ctx->vocab_l;
@@ -983,6 +1069,13 @@ int32_t gl3_forward_decode_sample(gl3_ctx* ctx, int32_t token, int32_t pos, floa
     else if ((r = enqueue_decode(ctx, true, nullptr, amode)) != GL3_OK) return r;
     if ((r = gl3_sample_run(ctx, ctx->logits, temperature, topp, coin, token_out)) != GL3_OK) return r;
     return gl3_tp_check(ctx);
+}
+
+int32_t gl3_tp_fold_mode(gl3_ctx* ctx, int32_t* mode, int32_t* consumer_mask) {
+    if (!ctx || !mode || !consumer_mask) return GL3_E_ARG;
+    if (!ctx->finalized) GL3_FAIL(GL3_E_STATE, "gl3_tp_fold_mode before gl3_finalize");
+    *mode = ctx->tp_fold; *consumer_mask = ctx->tp_fold ? ctx->tp_fold_mask : 0;
+    return GL3_OK;
 }
 
 int32_t gl3_get_topp_counts(gl3_ctx* ctx, int64_t* on_device, int64_t* on_host) {

@@ -121,6 +121,9 @@ struct gl3_tp_arena {
     bool pooled = false;                          // base goes back to the process-wide arena pool, not to hipFree (gl3_tp.hip)
 };
 constexpr size_t GL3_ARENA_HDR = 1024, GL3_ARENA_SEQ = 64, GL3_ARENA_ARRIVE = 68;      // bytes 256..511: checksums of GL3_TP_DEBUG (gl3_tp.hip)
+// folded gathers (decode, Q8_0 int8 path): u32 flags[3][GL3_MAX_TP] per buffer GB_XB / GB_X / GB_HB (flags[b][p] = gathers of buffer b
+// rank p has completed into this arena), u32 ticket[3] (finished producer wavefronts of the running launch), u32 step (decode steps)
+constexpr size_t GL3_ARENA_FOLD = 512, GL3_ARENA_FOLD_TICKET = 704, GL3_ARENA_STEP = 720;
 
 struct gl3_ctx {
     gl3_model_desc d{};
@@ -191,6 +194,9 @@ struct gl3_ctx {
     gl3_tp_arena arena;
     uint8_t* peer_base[GL3_MAX_TP] = {};          // arena of every rank as mapped into this process (peer_base[tp_rank] = arena.base)
     void* ipc_opened[GL3_MAX_TP] = {};            // mappings to close (hipIpcCloseMemHandle)
+    int tp_fold_mask = 0;                         // TF_* consumers that wait in their own prologue
+    int tp_fold = 0;                              // decode gathers folded into producers / consumers (gl3_api.hip tp_fold_setup): 0, 1, 2
+    void* tp_recs = nullptr;                      // device TpRec[n_layers * 8 + 2]
     uint32_t* h_tp_err = nullptr;                 // pinned, device-visible: set by a gather kernel whose peers never arrived
     size_t tp_dbg_prev_off = 0, tp_dbg_prev_n4 = 0;   // GL3_TP_DEBUG: the previous gather of this forward call (re-checked by the next one)
     std::vector<hipEvent_t> ev;

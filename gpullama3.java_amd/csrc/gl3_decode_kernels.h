@@ -55,6 +55,71 @@ __device__ long long gl3_mv_stamp[32];
 #define ATT_STAMP(i)
 #endif
 
+// ---------------------------------------------------------------------------------------------------
+// Tensor-parallel hand-over folded into the kernels that produce / consume a gathered buffer (protocol: gl3_tp.hip, "folded
+// gathers").  A producer (attention -> xb, gate/up -> hb, down -> x) stores every result element into its own arena AND into each
+// peer's arena (the same arena offset: own address + delta[j]); the wavefront that finishes last publishes "gather k of this buffer
+// from rank me is complete" into every peer's flag word.  A consumer waits until every peer's flag for the buffer has reached k —
+// in a one-wavefront wait kernel in front of it, or in its own prologue (TpRec.w inside matvec_q8t_kernel<.., TPF = true>).
+// k = (step - 1) * mul + add: step = decode steps taken by this plan (device word, bumped by the embedding kernel), mul = gathers of
+// the buffer per step, add = index of this gather inside the step: nothing of it is baked into a captured graph.
+constexpr int TPF_MAX_PEERS = 15;
+struct TpWait {
+    const uint32_t* flags;       // own arena: flags[rank] of the awaited buffer; NULL = nothing to wait for
+    const uint32_t* step;
+    uint32_t* err;               // host-pinned word: set to 1 on a timeout
+    int mul, add, tp, me;
+    unsigned spin_limit;
+};
+struct TpPush {
+    uint32_t* ticket;            // own arena: wavefronts of the producing launch that have finished
+    const uint32_t* step;
+    int mul, add, npeers;        // npeers = 0: nothing to push
+    long delta[TPF_MAX_PEERS];   // peer arena base - own arena base (bytes), peers in rotated order (me + 1, me + 2, ...)
+    uint32_t* flag[TPF_MAX_PEERS];   // peer j's flags[me] of the buffer
+};
+struct TpRec { TpWait w; TpPush p; };
+
+// every lane of the calling wavefront returns once all peers have published gather k (lane p polls the flag of rank p)
+__device__ __forceinline__ void tp_wait(const TpWait& w) {
+    const uint32_t need = (__hip_atomic_load(w.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u) * (uint32_t)w.mul + (uint32_t)w.add;
+    const int lane = threadIdx.x & 63;
+    const bool mine = lane < w.tp && lane != w.me;
+    unsigned spins = 0;
+    for (;;) {
+        // signed distance: a peer may already be a step ahead
+        const bool ok = !mine || (int32_t)(__hip_atomic_load(w.flags + (mine ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - need) >= 0;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > w.spin_limit) { if (lane == 0) __hip_atomic_store(w.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: nothing read before the peers' data landed survives
+}
+// one result element into every peer's copy of the buffer
+__device__ __forceinline__ void tp_push_store(const TpPush& p, float* own, float v) {
+    for (int j = 0; j < p.npeers; ++j)
+        *reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(own) + p.delta[j]) = v;
+}
+// called by every storing wavefront of the launch after its last tp_push_store (all lanes); total = such wavefronts in the launch
+__device__ __forceinline__ void tp_publish(const TpPush& p, unsigned total) {
+    // This wavefront's stores have been acknowledged by the peers' memory: the arenas are uncached on both sides, so a completed
+    // store is a visible one and no cache needs writing back here.  (A system-scope fence per wavefront — hundreds per launch, each
+    // an L2 write-back — made the folded decode step 20 % slower than the gather kernels between two ranks on one GPU.)  The one
+    // wavefront that publishes fences once.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) != 0) return;
+    const unsigned ticket = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket != total - 1) return;
+    __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t k = (__hip_atomic_load(p.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u) * (uint32_t)p.mul + (uint32_t)p.add;
+    __threadfence_system();
+    for (int j = 0; j < p.npeers; ++j) __hip_atomic_store(p.flag[j], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The wait as its own launch (one wavefront): the default consumer side — it cannot starve a peer rank's producer of compute units
+// when ranks share one GPU (CI), which a consumer that fills the chip while it polls can.
+static __global__ __launch_bounds__(64) void tp_wait_kernel(const TpRec* r) { tp_wait(r->w); }
+
 struct MatvecArgs {
     const uint8_t* w;        // Q8T tiles
     const uint8_t* w2;       // second matrix (EPI_SWIGLU: w = gate W1, w2 = up W3)
@@ -70,6 +135,7 @@ struct MatvecArgs {
     float out_scale;         // EPI_STORE / EPI_RESID: the row result is multiplied by this first (1 except Granite: residualScale after wo /
                              // down, logitScale on the logits — InferenceCore.forwardGranite :893-894, :911-912, :921; x * 1.0f is exact)
     const struct MoeSlots* moe;   // SEL instantiations only (Qwen2-MoE): what each blockIdx.y slot of the launch works on
+    const TpRec* tp;         // tensor parallel, folded gathers: what this launch pushes to the peers / waits for (NULL: nothing)
 };
 
 // Qwen2-MoE launches of matvec_q8t_kernel<.., SEL = true> (InferenceCore.matmulExpert :430-432): blockIdx.y = slot.  Slots j < n_sel
@@ -239,7 +305,10 @@ __device__ __forceinline__ uint16_t ld2(const uint8_t* p) {
 //       the epilogue while the producers already stream the next strip.
 // Register pressure is the maximum of the roles, not their sum (wave-uniform branches).
 //   LDS: xq[ng*128] | xs[ng*4] f32 | xf[k + 32] f32 (PRO_RMS) | pbuf[2][NM][ng*64] f32 | red[4] | sync[4]
-template <int PRO, int EPI, bool NT, int NPW = 4, bool SEL = false>
+// TPF (tensor parallel, folded gathers): the aux wavefronts wait for the peers' slices of x before they read it (after the barrier
+// that releases the producers: the weight stream starts while the wait polls), and the chain wavefront stores every result into
+// the peers' arenas as well and publishes the gather (TpRec above).
+template <int PRO, int EPI, bool NT, int NPW = 4, bool SEL = false, bool TPF = false>
 __global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_kernel(const MatvecArgs a_in) {
     MatvecArgs a = a_in;
     if (SEL) {                                          // wave-uniform: one scalar load of the expert id
@@ -347,13 +416,20 @@ __global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_
     // UNCONDITIONAL loads with clamped indices (quads past the end re-read the last one: an L1 hit that is never used).  With a
     // lane-predicated `if (qd < nquads) xv[i] = load`, and even with a wave-uniform condition, the compiler waited
     // (s_waitcnt vmcnt(0)) after every single load: 10 to 14 serial L2 round trips in front of every matvec (seen in the ISA).
+    if (!TPF) {
 #pragma unroll
-    for (int i = 0; i < NXV; ++i) xv[i] = *reinterpret_cast<const float4*>(a.x + 4 * min(ta + 256 * i, nquads - 1));
+        for (int i = 0; i < NXV; ++i) xv[i] = *reinterpret_cast<const float4*>(a.x + 4 * min(ta + 256 * i, nquads - 1));
+    }
     if (PRO == PRO_RMS) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) nwv[i] = *reinterpret_cast<const float4*>(a.norm_w + 4 * min(ta + 256 * i, nquads - 1));
     }
     __syncthreads();                                     // activation loads are queued ahead of the weight stream
+    if (TPF) {
+        if (a.tp->w.flags) tp_wait(a.tp->w);
+#pragma unroll
+        for (int i = 0; i < NXV; ++i) xv[i] = *reinterpret_cast<const float4*>(a.x + 4 * min(ta + 256 * i, nquads - 1));
+    }
     SubBarrier aux_sync{&sync_w[0], MV_AUX, 0};
     if (PRO == PRO_RMS) {
         if (nquads <= NXV * 256) {
@@ -450,23 +526,48 @@ __global__ __launch_bounds__(mv_threads(NPW), NPW == 4 ? 4 : 2) void matvec_q8t_
             const int row = strip * 16 + 4 * (lane >> 4) + r;
             if (row < a.rows) {
                 const float v0 = r == 0 ? acc[0][0] : r == 1 ? acc[0][1] : r == 2 ? acc[0][2] : acc[0][3];
-                if (EPI == EPI_STORE) a.out[row] = v0 * a.out_scale;
-                if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + v0 * a.out_scale : v0 * a.out_scale;
+                float res;
+                if (EPI == EPI_STORE) res = v0 * a.out_scale;
+                if (EPI == EPI_RESID) res = a.resid_in ? a.resid_in[row] + v0 * a.out_scale : v0 * a.out_scale;
                 if (EPI == EPI_SWIGLU) {                  // InferenceCore.java:155-158, exp in double
                     const float v1 = r == 0 ? acc[NM - 1][0] : r == 1 ? acc[NM - 1][1] : r == 2 ? acc[NM - 1][2] : acc[NM - 1][3];
                     const float gte = v0 / (float)(1.0 + exp(-(double)v0));
-                    a.out[row] = gte * v1;
+                    res = gte * v1;
                 }
+                a.out[row] = res;
+                if (TPF) tp_push_store(a.tp->p, a.out + row, res);
             }
         }
     }
+    if (TPF && a.tp->p.npeers) tp_publish(a.tp->p, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Embedding row gather + dequant: x[i] = q * d  (token_embedding_table.copyTo, InferenceCore.java:61;
 // replaces the host row copy of forwardTornadoVM :956-980 + convertQ8_0toFP32).
+// tp (folded gathers): the kernel opens decode step number *step + 1 of the plan — it first waits until the peers' last pushes of
+// the previous step into x have landed (a later arrival would overwrite this step's embedding), then bumps the step word.
 static __global__ __launch_bounds__(256) void embed_q8t_kernel(const uint8_t* __restrict__ emb, int ng, int dim,
-                                                         const int* __restrict__ dyn, float* __restrict__ x, float emb_scale) {
+                                                         const int* __restrict__ dyn, float* __restrict__ x, float emb_scale,
+                                                         const TpRec* tp = nullptr, uint32_t* step = nullptr) {
+    if (step) {
+        const uint32_t s = *step;
+        __syncthreads();
+        if (threadIdx.x == 0) *step = s + 1;
+        if (tp) {                          // as tp_wait with "need" spelled out: the step word is being rewritten
+            TpWait w = tp->w;
+            const uint32_t need = s * (uint32_t)w.mul;
+            const int lane = threadIdx.x & 63;
+            const bool mine = lane < w.tp && lane != w.me;
+            unsigned spins = 0;
+            for (;;) {
+                const bool ok = !mine || (int32_t)(__hip_atomic_load(w.flags + (mine ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - need) >= 0;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > w.spin_limit) { if (lane == 0) __hip_atomic_store(w.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+        }
+    }
     const int token = dyn[0];
     const uint8_t* strip = emb + (size_t)(token >> 4) * ng * TILE_BYTES;
     const int i16 = token & 15;
@@ -518,6 +619,7 @@ struct AttnArgs {
     // attn_head_kernel, static-batched decode on one rank: the output leaves the kernel as the wo projection's int8 operand in the
     // small-batch layout (gl3_bd_gemm.h: XQ2 / XS2, xq_slots token slots) instead of f32 xb; NULL = write xb
     uint8_t* xq_out; float* xs_out; int xq_slots;
+    const TpRec* tp;         // tensor parallel, folded gathers: xb also goes to the peers' arenas (NULL: not folded)
 };
 
 __device__ __forceinline__ void rope_head(float* v, int hs, const float* cr, const float* ci, int arch, int t0, int nthreads) {
@@ -1013,10 +1115,13 @@ static __global__ __launch_bounds__(256, 1) void attn_head_kernel(const AttnArgs
                 *reinterpret_cast<uint32_t*>(a.xq_out + bdq_offset(el >> 2, bt, a.xq_slots)) = (uint32_t)q0 | ((uint32_t)q1 << 8) | ((uint32_t)q2 << 16) | ((uint32_t)q3 << 24);
             if ((lane & 31) == 0) a.xs_out[bds_offset(el >> 5, bt, a.xq_slots)] = (float)(_Float16)qs;
         } else {
-            a.xb[(size_t)bt * a.xb_stride + (size_t)(h0 + g) * hs + j] = acc;
+            float* o = a.xb + (size_t)bt * a.xb_stride + (size_t)(h0 + g) * hs + j;
+            *o = acc;
+            if (a.tp) tp_push_store(a.tp->p, o, acc);
         }
     }
     ATT_STAMP(6);
+    if (a.tp) tp_publish(a.tp->p, gridDim.x * gridDim.y * 4);
 }
 
 // Picks the instantiation for the head size (host side).
@@ -1142,8 +1247,13 @@ static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnA
     // D[row][col]: row = column index of the slab = 4*(lane>>4) + reg; every MFMA column holds the same chain
     if (wave == 0 && (lane & 15) == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.xb[h * hs + j0 + 4 * (lane >> 4) + r] = acc[r];
+        for (int r = 0; r < 4; ++r) {
+            float* o = a.xb + h * hs + j0 + 4 * (lane >> 4) + r;
+            *o = acc[r];
+            if (a.tp) tp_push_store(a.tp->p, o, acc[r]);
+        }
     }
+    if (a.tp && wave == 0) tp_publish(a.tp->p, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1310,7 +1420,12 @@ static __global__ __launch_bounds__(64 * PV_WAVES) void attn_pv_kernel(const Att
 #undef PV_ADD8
 #undef PV_RD8
         }
-        if (g < kvmul) a.xb[(size_t)(kvh * kvmul + g) * hs + slab * PV_COLS16 + col] = acc;
+        if (g < kvmul) {
+            float* o = a.xb + (size_t)(kvh * kvmul + g) * hs + slab * PV_COLS16 + col;
+            *o = acc;
+            if (a.tp) tp_push_store(a.tp->p, o, acc);
+        }
+        if (a.tp) tp_publish(a.tp->p, gridDim.x);
         PV_T(if (blockIdx.x == 0 && lane == 0) { gl3_mv_stamp[0] = tw_; gl3_mv_stamp[1] = clock64() - ts_; })
         return;
     }

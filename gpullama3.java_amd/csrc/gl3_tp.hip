@@ -24,6 +24,28 @@
 // Expected cost: ~1.5 us boundary + ~3-5 us (store round trip over xGMI + flag propagation), 4 per layer + 1 per token.
 // No hardware curve exists until the driver's 8-GPU run (SCALE_rNN.json); in CI the SAME kernel runs between ranks that are
 // host threads of one process on one GPU (gl3_local_group) and between processes sharing one GPU over IPC handles.
+//
+// Folded gathers (decode step of the Q8_0 int8 path; gl3_api.hip tp_fold_setup, device side TpRec in gl3_decode_kernels.h).
+// The three per-layer hand-overs of a decode step need no launch of their own on the producing side: the attention kernels
+// (xb), the gate/up matvec (hb) and the down matvec (x) store every result element into the peers' arenas as they store it
+// into their own, and the launch's last wavefront publishes "gather k of buffer b from rank me" into a per-buffer flag word
+// of every peer (header bytes 512..: flags[3][16], ticket[3], step).  k = (step - 1) * n_layers + layer + 1 with step counted
+// in device memory by the embedding kernel, so a captured graph replays unchanged.  The consumer side is either a
+// one-wavefront wait launch in front of wo / down / the next qkv (default: measured +5 % decode tokens/s over the gather
+// kernels between two processes on ONE GPU, 994 vs 943 tok/s Llama-3.2-1B) or the consumer's own prologue (GL3_TP_FOLD=2:
+// the aux wavefronts of matvec_q8t_kernel<.., TPF> poll while the producer wavefronts already stream weights; nothing is
+// launched between producer and consumer).  A polling consumer holds its compute units: between ranks that share one GPU it
+// can keep a peer's producer from ever being scheduled (four in-process ranks, 2048-row wo: 384 polling workgroups on 256
+// CUs, the fourth rank's attention kernel — whole-SIMD register budget — never starts), so mode 2 is for one rank per GPU
+// and CI runs it with capped grids (GL3_WGS=16); there it is 11 % slower than the wait launches (843 tok/s) for the same reason.
+// Write-after-read safety (no acknowledgements): rank A pushes buffer b of layer l only after it has consumed a flag that the
+// slowest peer B publishes AFTER B's last read of its previous copy of b —
+//   xb(l) is pushed by A's attention(l), behind A's wait for x(l-1) = end of B's down(l-1), which follows B's wo(l-1), the reader;
+//   hb(l) by A's gate/up(l), behind the same wait; B's reader of hb was down(l-1) itself;
+//   x(l)  by A's down(l), behind A's wait for hb(l) = end of B's gate/up(l), the last reader of x in B's layer l;
+//   across steps the embedding kernel (mode 2) / the wait launch behind the last down (mode 1) waits for x(L) of the previous
+//   step before x is overwritten, and the logits gather (a gather kernel in every mode) joins the ranks once per sampled token.
+// The batched paths (prefill, static-batched decode) and the F16 / Q4_0 plans keep the gather kernels.
 #include <cstring>
 #include <tuple>
 

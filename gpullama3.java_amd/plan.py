@@ -222,6 +222,12 @@ class HipMasterPlan:
         for off in range(0, len(tokens), b):
             self.tornadoVMForwardBatchPrefill(tokens[off:off + b], start_pos + off)
 
+    def tp_fold_mode(self):
+        """(mode, consumer mask) of the tensor-parallel hand-over of this plan's decode step (gl3_tp_fold_mode)."""
+        a, b = C.c_int32(), C.c_int32()
+        hip.check(hip.lib().gl3_tp_fold_mode(self._ctx, C.byref(a), C.byref(b)), self._ctx)
+        return a.value, b.value
+
     def topp_counts(self):
         """(top-p draws answered on the device, draws answered by the host heap after a tie at the sampled rank)."""
         a, b = C.c_int64(), C.c_int64()

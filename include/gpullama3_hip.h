@@ -204,6 +204,11 @@ typedef struct gl3_local_group gl3_local_group;
 GL3_API int32_t gl3_local_group_create(int32_t n, gl3_local_group** out);
 GL3_API void gl3_local_group_destroy(gl3_local_group* g);
 GL3_API int32_t gl3_tp_attach_local(gl3_ctx* ctx, gl3_local_group* g);
+/* After gl3_finalize: how this plan's decode step hands the gathered activations over (gl3_api.hip tp_fold_setup).  *mode = 0: one
+ * gather launch per hand-over (every type but the Q8_0 int8 path, the RCCL transport, GL3_TP_FOLD=0); 1: the producing kernels
+ * write their results into the peers' arenas themselves.  *consumer_mask: bit set = that consumer waits for the peers in its own
+ * prologue (1 wo, 2 down, 4 qkv, 8 logits, 16 embedding; GL3_TP_FOLD=2 sets all), clear = a one-wavefront wait launch precedes it. */
+GL3_API int32_t gl3_tp_fold_mode(gl3_ctx* ctx, int32_t* mode, int32_t* consumer_mask);
 
 /* forceCopyInReadOnlyData(): checks that every tensor arrived, ties wcls to token_embd when
  * GL3_T_OUTPUT was not uploaded (AbstractModelLoader.java:194), captures the decode hipGraph. */

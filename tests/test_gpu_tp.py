@@ -51,6 +51,47 @@ def test_row_split_ranks_are_bit_identical_to_the_oracle(pkg, orc, planmod, cfg,
             assert np.array_equal(out[r][p], ref[p]), (r, p)
 
 
+def test_q8_decode_gathers_are_folded_into_the_producers(pkg, orc, planmod):
+    """The default hand-over of the Q8_0 int8 decode step: the attention / gate-up / down kernels write their results into the peers'
+    arenas (mode 1), the F16 / Q4_0 plans keep the gather launches (mode 0).  (Bit-exactness of both: the row-split test above.)"""
+    plan_mod, hip = planmod
+    for wtype, want in ((8, 1), (2, 0)):
+        m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], wtype=wtype, seed=3)
+        grp = plan_mod.make_local_group(2)
+        modes, err = [None, None], [None, None]
+
+        def rank_main(r):
+            try:
+                plan = plan_mod.HipMasterPlan(m, tp_rank=r, tp_size=2, local_group=grp)
+                modes[r] = plan.tp_fold_mode()
+                plan.forward_decode(1, 0)
+                plan.freeTornadoExecutionPlan()
+            except Exception as e:   # noqa: BLE001
+                err[r] = e
+        th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(2)]
+        [t.start() for t in th]; [t.join(timeout=300) for t in th]
+        hip.lib().gl3_local_group_destroy(grp)
+        assert err == [None, None], err
+        assert modes == [(want, 0), (want, 0)], (wtype, modes)
+
+
+@pytest.mark.parametrize("cfg,tp,mask", [("mid-llama", 4, None), ("mid-qwen3", 8, None), ("mid-llama", 2, "5")])
+def test_gathers_folded_into_the_consumer_prologues(cfg, tp, mask):
+    """GL3_TP_FOLD=2: no launch between producer and consumer — wo / down / qkv / logits / the embedding wait for the peers in their own
+    prologue.  A consumer that polls holds its compute units, so ranks that SHARE one GPU (this test) must leave room for each other's
+    producers: GL3_WGS=16 caps every matvec at 16 workgroups (with full grids four ranks' wo launches fill the chip and the laggard's
+    attention kernel never starts — seen as a gather time-out, not a wrong result).  Separate process: the switches are read at plan
+    creation / first launch.  The third case mixes prologue waits (wo, qkv) with wait launches (GL3_TP_FOLD_MASK)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GL3_TP_FOLD="2", GL3_WGS="16", GL3_TP_SPIN_LIMIT="4000000")
+    if mask: env["GL3_TP_FOLD_MASK"] = mask
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "debug_tp_fold.py"), cfg, str(tp), "3"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ("fold mode 1 mask %s" % (mask or "31")) in r.stdout, r.stdout[-1000:]
+
+
 def test_single_rank_rccl_communicator(pkg, orc, planmod):
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], seed=7)
