@@ -1103,6 +1103,10 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
         GL3_HIP(hipFuncSetAttribute((const void*)gemm_vlq_kernel<WT_Q4_0, EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * vlq_stage_floats<WT_Q4_0>() * 4));
         GL3_HIP(hipFuncSetAttribute((const void*)gemm_vlq_kernel<WT_Q8_0, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * vlq_stage_floats<WT_Q8_0>() * 4));
         GL3_HIP(hipFuncSetAttribute((const void*)gemm_vlq_kernel<WT_Q8_0, EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * vlq_stage_floats<WT_Q8_0>() * 4));
+#define GL3_VQM_ATTR(WT_, EPI_, OCC_) GL3_HIP(hipFuncSetAttribute((const void*)gemm_vlq_mfma_kernel<WT_, EPI_, OCC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * VQM_STAGE_FLOATS * 4))
+        GL3_VQM_ATTR(WT_Q4_0, EPI_STORE, 2); GL3_VQM_ATTR(WT_Q4_0, EPI_RESID, 2); GL3_VQM_ATTR(WT_Q4_0, EPI_STORE, 4); GL3_VQM_ATTR(WT_Q4_0, EPI_RESID, 4);
+        GL3_VQM_ATTR(WT_Q8_0, EPI_STORE, 2); GL3_VQM_ATTR(WT_Q8_0, EPI_RESID, 2); GL3_VQM_ATTR(WT_Q8_0, EPI_STORE, 4); GL3_VQM_ATTR(WT_Q8_0, EPI_RESID, 4);
+#undef GL3_VQM_ATTR
         GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1313,6 +1317,8 @@ static void pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
     }
 }
 
+static bool env_flag_cached_vlq_mfma() { static const bool on = env_flag("GL3_VLQ_MFMA", true); return on; }
+
 // Batched matmul of the f32-activation weight types (gl3_prefill_vl.h): out[b][row] (+)= dot(W[row], act[b]) in the Vector-API order
 template <int EPI>
 static void launch_gemm_vl(gl3_ctx* ctx, const Q8Mat& w, int ntok, const float* act, int act_stride, float* out, int out_stride, float out_scale = 1.0f) {
@@ -1322,6 +1328,22 @@ static void launch_gemm_vl(gl3_ctx* ctx, const Q8Mat& w, int ntok, const float* 
     if (w.fmt == GL3_TYPE_F16) {
         a.ntt = (ntok + F16G_TOK - 1) / F16G_TOK;
         hipLaunchKernelGGL((gemm_f16_mfma_kernel<EPI>), dim3(8 * ((a.nrt * a.ntt + 7) / 8)), dim3(256), 2 * F16G_STAGE, ctx->stream, a);
+    } else if (ntok > VLQ_TOK && env_flag_cached_vlq_mfma() && a.nrt * ((ntok + VQM_TOK - 1) / VQM_TOK) >= 192) {
+        // enough 64 x 64 tiles to fill the chip: products on the f32 matrix cores (gemm_vlq_mfma_kernel; 8B Q4_0 pp512 2.53 k -> 3.4 k
+        // tok/s).  Fewer tiles (short chunks, the 4096-row projections at 128 tokens) keep the 16-token VALU kernel; GL3_VLQ_MFMA=0: always.
+        a.ntt = (ntok + VQM_TOK - 1) / VQM_TOK;
+        static const bool by_tokens = env_flag("GL3_VQM_XCD_TOKENS", true);      // A/B switch of the tile mapping (vqm_tile_of)
+        a.xcd_tokens = by_tokens ? 1 : 0;
+        const dim3 g(by_tokens ? vqm_grid(a.nrt, a.ntt) : 8 * ((a.nrt * a.ntt + 7) / 8));
+        const size_t sm = (size_t)2 * VQM_STAGE_FLOATS * 4;
+        static const bool occ2 = env_flag("GL3_VQM_OCC2", false);                // A/B: the 143-register build, one workgroup per CU (5 % slower)
+        if (w.fmt == GL3_TYPE_Q4_0) {
+            if (occ2) hipLaunchKernelGGL((gemm_vlq_mfma_kernel<WT_Q4_0, EPI, 2>), g, dim3(512), sm, ctx->stream, a);
+            else hipLaunchKernelGGL((gemm_vlq_mfma_kernel<WT_Q4_0, EPI, 4>), g, dim3(512), sm, ctx->stream, a);
+        } else {
+            if (occ2) hipLaunchKernelGGL((gemm_vlq_mfma_kernel<WT_Q8_0, EPI, 2>), g, dim3(512), sm, ctx->stream, a);
+            else hipLaunchKernelGGL((gemm_vlq_mfma_kernel<WT_Q8_0, EPI, 4>), g, dim3(512), sm, ctx->stream, a);
+        }
     } else {
         a.ntt = (ntok + VLQ_TOK - 1) / VLQ_TOK;
         const dim3 g(8 * ((a.nrt * a.ntt + 7) / 8));

@@ -35,6 +35,7 @@ struct VlGemmArgs {
     float* out; int out_stride;      // EPI_STORE: out[b][row] = r * out_scale; EPI_RESID: out[b][row] += r * out_scale
     float out_scale;
     int nrt, ntt;                    // row tiles, token tiles (grid = 8 * ceil(nrt * ntt / 8), XCD-aware mapping)
+    int xcd_tokens;                  // gemm_vlq_mfma_kernel: 1 = vqm_tile_of (token tiles pinned to XCDs), 0 = vl_tile_of
 };
 
 // XCD-aware tile mapping shared by both kernels: workgroups are dealt round-robin to the 8 XCDs, so the token tiles that share
@@ -277,6 +278,195 @@ __global__ __launch_bounds__(256, 2) void gemm_vlq_kernel(const VlGemmArgs a) {
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Q4_0 / Q8_0 with f32 activation, round 5: the ROUNDED PRODUCTS on the f32 matrix cores, the ordered adds on the VALU.
+//   s[l] = ((x0*q0 + x1*q1) + x2*q2) + x3*q3 needs every product rounded to f32 on its own, which no k-accumulating MFMA gives —
+//   but a K = 1 MFMA with C = 0 is exactly that: v_mfma_f32_16x16x1_4b_f32 computes four independent 16 x 16 outer products
+//   D_q[i][j] = fma(a_q[i], b_q[j], 0) = fl(a_q[i] * b_q[j]) (one rounding per product, subnormals kept: cdna_hip_programming.md
+//   "f32-input MFMA"; a zero product of either sign plus +0 leaves the sums' and the fma's values unchanged).  With block q = the
+//   four elements 8 q + l of a weight block, A = x of 16 tokens and B = the dequantised quants of 16 rows, ONE instruction delivers
+//   the four product tiles P0..P3 of (16 tokens x 16 rows, block, accumulator lane l); the VALU then does the reference's three
+//   adds and the fma with the row's scale on the 4 registers of the tile (v_pk_add_f32 / v_pk_fma_f32): 2 packed VALU
+//   instructions per MFMA-delivered product quad instead of 4, and the matrix pipe (64 FLOP/clk/SIMD, the f32 VALU's own rate)
+//   runs beside them.  Both pipes are ~balanced: 8 packed VALU instructions per 32-cycle MFMA.
+// Workgroup = 8 wavefronts = 64 rows x 64 tokens; wavefront (rt, th) = 16 rows x 32 tokens (two tiles) for all 8 accumulator
+// lanes (64 accumulator registers).  K advances 64 elements (two blocks) per stage through double-buffered LDS:
+//   XF[64 tokens][68]                 x, natural order (A operand of lane (q, token): 8 consecutive floats = l 0..7)
+//   QF[2 blocks][8 l][4 q][..][row]   dequantised quants as f32, index b * SB + l * SL + q * SQ + row (SL = 68, SQ = 560: the
+//                                     staging thread (row, l) writes and the operand lane (q, row) reads without bank conflicts)
+//   WS[2 blocks][64 rows]             block scales as f32
+// The weights stay in the decode path's VL layout: thread (group, row, l) of the workgroup holds its 16 bytes of a VL chunk
+// (8 / 4 blocks) in registers and dequantises two blocks per stage.
+constexpr int VQM_ROWS = 64, VQM_TOK = 64, VQM_XP = 68, VQM_SL = 68, VQM_SQ = 560, VQM_SB = 4 * VQM_SQ;
+constexpr int VQM_STAGE_FLOATS = VQM_TOK * VQM_XP + 2 * VQM_SB + 2 * VQM_ROWS;
+
+// Tile mapping: the f32 x tile of a workgroup (64 tokens x K x 4 B: 1 MB at K = 4096) is 7x the bytes of its weight tile, so each
+// XCD keeps a FIXED set of token tiles (its x stays in that XCD's 4 MB L2 while the row tiles stream past) and the weights are
+// re-read once per XCD — against vl_tile_of's "token tiles of one row tile share an XCD", which re-reads all of x (8.4 MB at 512
+// tokens: more than one L2) for every row tile: 7 GB of x per 8B layer.  G = token groups (a power of two <= 8), P = 8 / G row
+// parts: XCD x = blockIdx.x & 7 works on token tiles g + G i (g = x % G) and row tiles part + P j (part = x / G), rows fastest.
+__host__ __device__ inline int vqm_groups(int ntt) { return ntt >= 8 ? 8 : ntt >= 4 ? 4 : ntt >= 2 ? 2 : 1; }
+__host__ __device__ inline int vqm_grid(int nrt, int ntt) {
+    const int G = vqm_groups(ntt), P = 8 / G;
+    return 8 * ((nrt + P - 1) / P) * ((ntt + G - 1) / G);
+}
+__device__ __forceinline__ bool vqm_tile_of(const VlGemmArgs& a, int& rt, int& tt) {
+    const int G = vqm_groups(a.ntt), P = 8 / G, x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nrp = (a.nrt + P - 1) / P;
+    rt = (x / G) + P * (slot % nrp);
+    tt = (x % G) + G * (slot / nrp);
+    return rt < a.nrt && tt < a.ntt;
+}
+
+template <int WT, int EPI, int OCC = 2>
+__global__ __launch_bounds__(512, OCC) void gemm_vlq_mfma_kernel(const VlGemmArgs a) {
+    static_assert(WT == WT_Q4_0 || WT == WT_Q8_0, "F16 runs on gemm_f16_mfma_kernel");
+    extern __shared__ __attribute__((aligned(16))) float sm_[];
+    constexpr int CE = WT == WT_Q4_0 ? 256 : 128, CB = WT == WT_Q4_0 ? 1152 : 1088, SPC = CE / 64;      // stages per VL chunk
+    const int t = threadIdx.x, lane = t & 63, l = lane & 7, rr = lane >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), rt = wave >> 1, th = wave & 1;
+    int rtile, ttile;
+    if (!(a.xcd_tokens ? vqm_tile_of(a, rtile, ttile) : vl_tile_of(a, rtile, ttile))) return;
+    const int row0 = rtile * VQM_ROWS, tok0 = ttile * VQM_TOK;
+    const int nst = a.k >> 6, ngroups = (a.rows + 7) >> 3;
+    const size_t gbytes = (size_t)(a.k / CE) * CB;
+    // staging roles: weights — thread = (group wave, lane) of the VL layout; x — two float4 per thread and stage
+    const uint8_t* wb = a.w + (size_t)min(ngroups - 1, rtile * 8 + wave) * gbytes;
+    const float* px[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = t + 512 * j, tk = min(a.ntok - 1, tok0 + (p >> 4));
+        px[j] = a.X + (size_t)tk * a.x_stride + 4 * (p & 15);
+    }
+    int4 wq, wsc; float4 rx[2];
+#define VQM_WLOAD(c_) do { \
+        const uint8_t* cb_ = wb + (size_t)(c_) * CB; \
+        wq = ld16<false>(cb_ + 16 * lane); \
+        if (WT == WT_Q4_0) wsc = ld16<false>(cb_ + 1024 + 16 * rr); \
+        else { const uint2 s2_ = *reinterpret_cast<const uint2*>(cb_ + 1024 + 8 * rr); wsc = make_int4((int)s2_.x, (int)s2_.y, 0, 0); } \
+    } while (0)
+#define VQM_XLOAD(s_) do { \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) rx[j] = *reinterpret_cast<const float4*>(px[j] + (size_t)(s_) * 64); \
+    } while (0)
+    // stage s_ of chunk registers cq_ / cs_ -> LDS buffer buf_: x as loaded, the two blocks' quants as f32, their scales
+#define VQM_LSTORE(buf_, s_, cq_, cs_) do { \
+        float* XF_ = sm_ + (size_t)(buf_) * VQM_STAGE_FLOATS; \
+        float* QF_ = XF_ + VQM_TOK * VQM_XP; \
+        float* WS_ = QF_ + 2 * VQM_SB; \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) { \
+            const int p = t + 512 * j; \
+            *reinterpret_cast<float4*>(XF_ + (p >> 4) * VQM_XP + 4 * (p & 15)) = rx[j]; \
+        } \
+        const int sub_ = (s_) % SPC; \
+        float* qd_ = QF_ + l * VQM_SL + wave * 8 + rr; \
+        if (WT == WT_Q4_0) { \
+            const uint32_t aw_ = (uint32_t)(sub_ < 2 ? (cq_).x : (cq_).y) >> (16 * (sub_ & 1)); \
+            const uint32_t bw_ = (uint32_t)(sub_ < 2 ? (cq_).z : (cq_).w) >> (16 * (sub_ & 1)); \
+            _Pragma("unroll") for (int b = 0; b < 2; ++b) { \
+                const uint32_t ab_ = (aw_ >> (8 * b)) & 0xFFu, bb_ = (bw_ >> (8 * b)) & 0xFFu; \
+                qd_[b * VQM_SB + 0 * VQM_SQ] = (float)(ab_ & 0xFu) - 8.0f;      /* element l */      \
+                qd_[b * VQM_SB + 1 * VQM_SQ] = (float)(bb_ & 0xFu) - 8.0f;      /* element 8 + l */  \
+                qd_[b * VQM_SB + 2 * VQM_SQ] = (float)(ab_ >> 4) - 8.0f;        /* element 16 + l */ \
+                qd_[b * VQM_SB + 3 * VQM_SQ] = (float)(bb_ >> 4) - 8.0f;        /* element 24 + l */ \
+            } \
+        } else { \
+            _Pragma("unroll") for (int b = 0; b < 2; ++b) { \
+                const uint32_t qw_ = (uint32_t)(sub_ == 0 ? (b == 0 ? (cq_).x : (cq_).y) : (b == 0 ? (cq_).z : (cq_).w)); \
+                qd_[b * VQM_SB + 0 * VQM_SQ] = (float)(int8_t)(qw_ & 0xFFu); \
+                qd_[b * VQM_SB + 1 * VQM_SQ] = (float)(int8_t)((qw_ >> 8) & 0xFFu); \
+                qd_[b * VQM_SB + 2 * VQM_SQ] = (float)(int8_t)((qw_ >> 16) & 0xFFu); \
+                qd_[b * VQM_SB + 3 * VQM_SQ] = (float)(int8_t)(qw_ >> 24); \
+            } \
+        } \
+        if (l == 0) { \
+            const uint32_t sw_ = (uint32_t)(sub_ == 0 ? (cs_).x : sub_ == 1 ? (cs_).y : sub_ == 2 ? (cs_).z : (cs_).w); \
+            WS_[wave * 8 + rr] = cvt_lo(sw_); \
+            WS_[VQM_ROWS + wave * 8 + rr] = cvt_hi(sw_); \
+        } \
+    } while (0)
+
+    typedef float v2f_q __attribute__((ext_vector_type(2)));
+    v2f_q val[2][8][2];                              // [token tile][accumulator lane][register pair]: tokens 4 (lane >> 4) + 0..3, row lane & 15
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int ll = 0; ll < 8; ++ll) { val[tt][ll][0] = (v2f_q){0.f, 0.f}; val[tt][ll][1] = (v2f_q){0.f, 0.f}; }
+    const bool live = tok0 + th * 32 < a.ntok;       // a token half past the end only helps staging (static-batched decode, B <= 32)
+    const int mq = lane >> 4, mi = lane & 15;        // MFMA operand slot: block q, token / row index
+    VQM_WLOAD(0);
+    VQM_XLOAD(0);
+    VQM_LSTORE(0, 0, wq, wsc);
+    int4 cq = wq, cs = wsc;                          // chunk registers the stages of the current chunk read
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int sn = min(s + 1, nst - 1);          // unconditional loads; the last trip re-reads its own stage
+        if ((sn % SPC) == 0) VQM_WLOAD(sn / SPC);    // wave-uniform: the next stage opens a new VL chunk
+        VQM_XLOAD(sn);
+        if (live) {
+            const float* XF = sm_ + (size_t)(s & 1) * VQM_STAGE_FLOATS;
+            const float* QF = XF + VQM_TOK * VQM_XP;
+            const float* WS = QF + 2 * VQM_SB;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float av[2][8], bv[8];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const float* xa = XF + (th * 32 + tt * 16 + mi) * VQM_XP + 32 * b + 8 * mq;
+                    const float4 lo = *reinterpret_cast<const float4*>(xa), hi = *reinterpret_cast<const float4*>(xa + 4);
+                    av[tt][0] = lo.x; av[tt][1] = lo.y; av[tt][2] = lo.z; av[tt][3] = lo.w;
+                    av[tt][4] = hi.x; av[tt][5] = hi.y; av[tt][6] = hi.z; av[tt][7] = hi.w;
+                }
+#pragma unroll
+                for (int ll = 0; ll < 8; ++ll) bv[ll] = QF[b * VQM_SB + ll * VQM_SL + mq * VQM_SQ + rt * 16 + mi];
+                const float ws = WS[b * VQM_ROWS + rt * 16 + mi];
+                const v2f_q ws2 = {ws, ws};
+                // One MFMA, then its 8 packed VALU instructions, tile after tile.  Issuing the MFMAs ahead of the VALU chain (two or
+                // three P buffers, VALU chain pinned in inline assembly) bought nothing — 1380 vs 1290 us for the 8B gate GEMM:
+                // on gfx950 an MFMA (f32 or bf16) and f32 VALU work of the same SIMD do not overlap, not even between two
+                // wavefronts (scripts/probes/mfma_overlap_probe.hip: 4 MFMA 123 ns + 32 v_pk_fma_f32 153 ns = 258 ns together), so
+                // the matrix core only REPLACES the 8 product instructions of a tile at the same cost (32 cycles) — the gain
+                // over gemm_vlq_kernel comes from the operand traffic and the packed adds, not from a second pipe.
+#pragma unroll
+                for (int ll = 0; ll < 8; ++ll)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const v16f_vl z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        const v16f_vl P = __builtin_amdgcn_mfma_f32_16x16x1f32(av[tt][ll], bv[ll], z, 0, 0, 0);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const v2f_q p0 = {P[2 * h], P[2 * h + 1]}, p1 = {P[4 + 2 * h], P[5 + 2 * h]};
+                            const v2f_q p2 = {P[8 + 2 * h], P[9 + 2 * h]}, p3 = {P[12 + 2 * h], P[13 + 2 * h]};
+                            const v2f_q sm2 = ((p0 + p1) + p2) + p3;                                   // sum0.add(sum1).add(sum2).add(sum3)
+                            val[tt][ll][h] = __builtin_elementwise_fma(sm2, ws2, val[tt][ll][h]);     // .fma(wScale, val)
+                        }
+                    }
+            }
+        }
+        if ((sn % SPC) == 0) { cq = wq; cs = wsc; }
+        VQM_LSTORE((s + 1) & 1, sn, cq, cs);
+        __syncthreads();
+    }
+#undef VQM_WLOAD
+#undef VQM_XLOAD
+#undef VQM_LSTORE
+    // ---- reduceLanes(ADD) in lane order from 0, then the epilogue: lane = row, register = token
+    const int row = row0 + rt * 16 + mi;
+    if (!live || row >= a.rows) return;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = tok0 + th * 32 + tt * 16 + 4 * mq + r;
+            if (b >= a.ntok) continue;
+            float v = 0.f;
+#pragma unroll
+            for (int ll = 0; ll < 8; ++ll) v = v + val[tt][ll][r >> 1][r & 1];
+            float* o = a.out + (size_t)b * a.out_stride + row;
+            if (EPI == EPI_RESID) *o = *o + v * a.out_scale;
+            else *o = v * a.out_scale;
+        }
 }
 
 // hb = silu(gate) * up per element (InferenceCore.java:155-158: exp in double), in place on the gate buffer
