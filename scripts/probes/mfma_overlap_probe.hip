@@ -33,8 +33,16 @@ __global__ __launch_bounds__(512) void rate_kernel(float* out, long long* cyc, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (MODE & 1) {
-                const v16f p = KIND == 0 ? __builtin_amdgcn_mfma_f32_16x16x1f32(r & 1 ? a : b, r & 2 ? a : b, z, 0, 0, 0)
-                                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(r & 1 ? ab : bb, r & 2 ? ab : bb, z, 0, 0, 0);
+                v16f p;
+                if (KIND == 0) p = __builtin_amdgcn_mfma_f32_16x16x1f32(r & 1 ? a : b, r & 2 ? a : b, z, 0, 0, 0);
+                else if (KIND == 1) p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r & 1 ? ab : bb, r & 2 ? ab : bb, z, 0, 0, 0);
+                else {
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    typedef int v16i __attribute__((ext_vector_type(16)));
+                    const v4i ia = {lane, lane + r, 3, 4}, ib = {r, 2, lane, 7};
+                    const v16i zi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    p = __builtin_bit_cast(v16f, __builtin_amdgcn_mfma_i32_32x32x32_i8(ia, ib, zi, 0, 0, 0));
+                }
                 if (r == 0) P0 = p; else if (r == 1) P1 = p; else if (r == 2) P2 = p; else P3 = p;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -102,6 +110,9 @@ int main() {
     run_rate<3, 0>("f32 MFMA + v_pk_fma_f32", 256, out, cyc);
     run_rate<2, 0, true>("16 v_fma_f32 alone", 256, out, cyc);
     run_rate<3, 0, true>("f32 MFMA + 16 v_fma_f32", 256, out, cyc);
+    run_rate<1, 2>("int8 MFMA 32x32x32 alone", 256, out, cyc);
+    run_rate<3, 2>("int8 MFMA + v_pk_fma_f32", 256, out, cyc);
+    run_rate<3, 2, true>("int8 MFMA + 16 v_fma_f32", 256, out, cyc);
     run_rate<1, 1>("bf16 MFMA 32x32x16 alone", 256, out, cyc);
     run_rate<3, 1, true>("bf16 MFMA + 16 v_fma_f32", 256, out, cyc);
     run_rate<3, 1>("bf16 MFMA + v_pk_fma_f32", 256, out, cyc);
