@@ -338,7 +338,10 @@ static int32_t tp_fold_setup(gl3_ctx* ctx) {
     h[(size_t)L * TR_PER_LAYER].w = mk_wait(GB_X, 0);          // embedding: the previous step's last pushes into x
     if (mask & TF_LOGITS) h[(size_t)L * TR_PER_LAYER + 1].w = mk_wait(GB_X, L);
     GL3_HIP(hipMalloc((void**)&ctx->tp_recs, h.size() * sizeof(TpRec)));
-    GL3_HIP(hipMemcpy(ctx->tp_recs, h.data(), h.size() * sizeof(TpRec), hipMemcpyHostToDevice));
+    // on the plan's own stream: a legacy-stream copy would have to wait for every blocking stream of the process, and another rank of an
+    // in-process group may already be CAPTURING its step graph on one (hipErrorStreamCaptureImplicit, seen as a flaky 8-rank test)
+    GL3_HIP(hipMemcpyAsync(ctx->tp_recs, h.data(), h.size() * sizeof(TpRec), hipMemcpyHostToDevice, ctx->stream));
+    GL3_HIP(hipStreamSynchronize(ctx->stream));
     ctx->tp_fold = 1; ctx->tp_fold_mask = mask;
     return GL3_OK;
 }

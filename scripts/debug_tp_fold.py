@@ -18,11 +18,13 @@ toks = pkg.javarand.bench_tokens(m.cfg.vocab, ntok)
 ref = [o.forward(t, p) for p, t in enumerate(toks)]
 grp = plan_mod.make_local_group(tp)
 out, err = [None] * tp, [None] * tp
+ready = threading.Barrier(tp)        # a host-level barrier between plan creation and the first forward
 
 def rank_main(r):
     try:
         plan = plan_mod.HipMasterPlan(m, tp_rank=r, tp_size=tp, local_group=grp)
         if r == 0: print("fold mode %d mask %d" % plan.tp_fold_mode(), flush=True)
+        ready.wait()
         res = []
         for p, t in enumerate(toks):
             t0 = time.time(); res.append(plan.forward_decode(t, p)); print("rank %d token %d: %.3f s" % (r, p, time.time() - t0), flush=True)
@@ -30,6 +32,7 @@ def rank_main(r):
         plan.freeTornadoExecutionPlan()
     except Exception as e:
         err[r] = e
+        ready.abort()
 
 th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(tp)]
 t0 = time.time()

@@ -84,7 +84,7 @@ def test_gathers_folded_into_the_consumer_prologues(cfg, tp, mask):
     creation / first launch.  The third case mixes prologue waits (wo, qkv) with wait launches (GL3_TP_FOLD_MASK)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GL3_TP_FOLD="2", GL3_WGS="16", GL3_TP_SPIN_LIMIT="4000000")
+    env = dict(os.environ, GL3_TP_FOLD="2", GL3_WGS="16")
     if mask: env["GL3_TP_FOLD_MASK"] = mask
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "debug_tp_fold.py"), cfg, str(tp), "3"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
