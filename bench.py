@@ -337,6 +337,11 @@ def main():
             mfma_floor_us = 3 * tiles_blocks * 65536 / (peaks["int8_mfma_tops"] * 1e12) * 1e6
             roofline_pp["matrix_pipe_floor_us"] = round(mfma_floor_us, 1)
             roofline_pp["frac_of_matrix_pipe_floor"] = round(mfma_floor_us / g["avg_us"], 4)
+            # r5: an MFMA and f32 VALU work of one SIMD do not execute concurrently on gfx950 (scripts/probes/mfma_overlap_probe.hip), so the
+            # floor of this arithmetic is the SUM: 3 x 32 cycles of MFMA + 32 plain f32 operations at 2 cycles per tile-block
+            # (profiles/r05_prefill_q8_bound.md)
+            roofline_pp["mfma_plus_valu_floor_us"] = round(mfma_floor_us * (96 + 64) / 96, 1)
+            roofline_pp["frac_of_mfma_plus_valu_floor"] = round(mfma_floor_us * (96 + 64) / 96 / g["avg_us"], 4)
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read in-process (--pmc needs its own rocprofv3 pass).  The round's
     # separate FETCH_SIZE pass over this same command is committed as profiles/rNN_pmc_fetch_summary.csv (x2 gfx950 correction) together
