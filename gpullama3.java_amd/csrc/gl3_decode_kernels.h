@@ -1278,7 +1278,7 @@ constexpr int PVT = 128;                   // timesteps per product tile
 constexpr int PV_G = 4, PV_COLS16 = 16;    // a workgroup serves PV_G query heads of one kv head x 16 output columns: 64 chains = one wavefront
 constexpr int PV_HELPERS = 8, PV_RING = 4;  // helper wavefronts (wavefront 0 is the chain); tiles their operands are requested ahead
 constexpr int PV_WAVES = 11;               // wavefronts per workgroup: chain, 8 helpers, and wavefronts 4 and 8 — the chain's SIMD neighbours — which retire at once
-constexpr int PV_QP = 64 * 4 + 4;          // floats per timestep quad in LDS: 64 lanes x 4 steps + 4 (the helpers' scattered 4-byte stores hit 64 different banks)
+constexpr int PV_QP = 64 * 4 + 4;          // floats per timestep quad in LDS: 64 lanes x 4 steps + 4 (rows of consecutive quads 4 banks apart: see the helpers' store)
 __host__ __device__ constexpr size_t attn_pv_smem() { return (size_t)2 * (PVT / 4) * PV_QP * 4; }
 __host__ __device__ inline int attn_pv_hq(int kvmul) { return (kvmul + PV_G - 1) / PV_G; }       // groups of PV_G query heads per kv head
 // floats of the transposed weight buffer att_t[kv head][head quad][t][PV_G] (written by attn_softmax_kernel, read by attn_pv_kernel)
@@ -1381,7 +1381,8 @@ static __global__ __launch_bounds__(64 * PV_WAVES) void attn_pv_kernel(const Att
     if (wave == 0) {
         // ------------------------------------------------------------------ chain: acc = p_t + acc, t ascending
         __builtin_amdgcn_s_setprio(3);
-        const int g = hq * PV_G + (lane >> 4), col = lane & 15;
+        // chain lane -> (head, column): the helpers' layout below puts product (g, 4 c4 + jj) into chain lane 16 g + 8 (jj >> 1) + 2 c4 + (jj & 1)
+        const int g = hq * PV_G + (lane >> 4), col = 4 * ((lane >> 1) & 3) + 2 * ((lane >> 3) & 1) + (lane & 1);
         float acc = 0.f;
         PV_T(long long tw_ = 0; const long long ts_ = clock64();)
         for (int k = 0; k < ntiles; ++k) {
@@ -1443,8 +1444,12 @@ static __global__ __launch_bounds__(64 * PV_WAVES) void attn_pv_kernel(const Att
     const float* vbase = a.vcache + (size_t)kvh * hs + slab * PV_COLS16 + (size_t)(hw * 16) * a.kv_dim;
     const float* abase = a.att_t + ((size_t)(kvh * hq_n + hq) * a.att_stride + hw * 16) * PV_G;
     const unsigned vlane = (unsigned)r * a.kv_dim + 4 * c4;
-    // LDS: row (in tile) rt = hw 16 + r -> quad rt >> 2, step rt & 3; product (g, 4 c4 + jj) -> chain lane g 16 + 4 c4 + jj
-    float* pst = pbuf + (size_t)((hw * 16 + r) >> 2) * PV_QP + (r & 3) + 16 * c4;
+    // LDS: row (in tile) rt = hw 16 + r -> quad rt >> 2, step rt & 3; product (g, 4 c4 + jj) -> chain lane 16 g + 8 (jj >> 1) + 2 c4 + (jj & 1),
+    // i.e. float 4 (chain lane) + step of the quad's row.  One store instruction (fixed g, jj) then writes bank
+    // 4 (r >> 2) + (r & 3) + 8 c4 (+ const) mod 32: the 32 lanes of a half wavefront (8 rows x 4 column quads) hit 32 different banks.
+    // (With chain lane 16 g + 4 c4 + jj the column quads 0 / 2 and 1 / 3 shared their banks — LDS has 32, not 64: SQ_LDS_BANK_CONFLICT was
+    // as large as SQ_ACTIVE_INST_LDS for this kernel, profiles/r05_tg_depth.md.)
+    float* pst = pbuf + (size_t)((hw * 16 + r) >> 2) * PV_QP + (r & 3) + 8 * c4;
     // Lane (r, c4) divides ONE numerator per tile — head c4 of row r: the 16 rows x PV_G heads of the wavefront are exactly its 64 lanes —
     // and reads the other three heads' weights of its row from its quad neighbours as DPP operands of the multiplies (quad = the four
     // lanes of a row).  (Four divisions per lane, each repeated by the row's four lanes, were a third of the helpers' instructions; with
@@ -1461,7 +1466,7 @@ static __global__ __launch_bounds__(64 * PV_WAVES) void attn_pv_kernel(const Att
     } while (0)
 #define PVH_QUAD(X_, G_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, X_), 0x55 * (G_), 0xf, 0xf, false))      /* lane G_ of my quad */
 #define PVH_STORE_G(P_, A_, V_, G_) do { const float ag_ = PVH_QUAD(A_, G_); \
-        (P_)[64 * (G_) + 0] = ag_ * (V_).x; (P_)[64 * (G_) + 4] = ag_ * (V_).y; (P_)[64 * (G_) + 8] = ag_ * (V_).z; (P_)[64 * (G_) + 12] = ag_ * (V_).w; } while (0)
+        (P_)[64 * (G_) + 0] = ag_ * (V_).x; (P_)[64 * (G_) + 4] = ag_ * (V_).y; (P_)[64 * (G_) + 32] = ag_ * (V_).z; (P_)[64 * (G_) + 36] = ag_ * (V_).w; } while (0)
 #define PVH_STORE(S_, K_) do { \
         float* pb_ = pst + (size_t)((K_) & 1) * QPT * PV_QP; \
         float4 v_ = v##S_; \
