@@ -25,6 +25,9 @@ using namespace gl3;
 // gl3_prefill_gemm2.hip (own translation unit, -fno-slp-vectorize): the > 64-token GEMM with the scale products on the matrix pipe (r4)
 void gl3_gemm2_launch(int epi, const GemmArgs& a, int rows, int ntok, int mode, hipStream_t s);
 hipError_t gl3_gemm2_allow_lds();
+// r6: the same arithmetic behind a mid-stage barrier / partial-vmcnt operand ring, every GEMM class (gl3_prefill_gemm3.h)
+void gl3_gemm3_launch(int epi, const GemmArgs& a, int rows, int ntok, hipStream_t s);
+hipError_t gl3_gemm3_allow_lds();
 
 struct gl3_prefill_state {
     int max_batch = 0;
@@ -32,6 +35,8 @@ struct gl3_prefill_state {
     float* X = nullptr;                 // [M][dim] residual stream (rank-chunked [tp][n][dim/tp] under tensor parallelism)
     uint8_t* XQ = nullptr;              // [M][maxk] int8 activations
     float* XS = nullptr;                // [M][maxk/32] activation scales
+    uint8_t* XP = nullptr;              // [maxk/32 + 4][xp_tok][8 B] the activation scales as bf16 MFMA operands {a_hi, a_lo, a_hi, a_lo} (pf_gemm3_kernel)
+    int xp_tok = 0;                     //   token slots per block: max_batch rounded up to the GEMM's 128-token tile
     uint8_t* XQb = nullptr;             // second small-batch operand buffer: hb quantised by the gate/up kernel's own epilogue
     float* XSb = nullptr;               //   (its input still being read by other workgroups)
     float* QKV = nullptr;               // [M][q_dim + 2 kv_dim]
@@ -87,7 +92,8 @@ enum { PQ_PLAIN = 0, PQ_NORM = 1, PQ_NORM_F32 = 2, PQ_PLAIN_F32 = 3 };     // PQ
 template <int MODE>
 __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restrict__ in, int k, int in_stride,
                                                              const float* __restrict__ norm_w, float eps,
-                                                             uint8_t* __restrict__ XQ, float* __restrict__ XS, int maxk, int tslots) {
+                                                             uint8_t* __restrict__ XQ, float* __restrict__ XS, int maxk, int tslots,
+                                                             uint2* __restrict__ XP = nullptr, int xp_tok = 0) {
     constexpr bool NORM = MODE == PQ_NORM || MODE == PQ_NORM_F32;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* xf = reinterpret_cast<float*>(smem);                 // [k + 32]
@@ -128,8 +134,25 @@ __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restr
             v = xquad(qd);
         }
         if (MODE == PQ_NORM_F32 || MODE == PQ_PLAIN_F32) { *reinterpret_cast<float4*>(XS + (size_t)b * k + 4 * qd) = v; continue; }
-        if (tslots == 0) quantize_quad(v, qd, xq, xs);
-        else {                                           // the wave-owned small-batch GEMM's operand layout (gl3_bd_gemm.h)
+        if (tslots == 0) {
+            float qs;
+            const uint32_t packed = quantize_quad_pack(v, qs);
+            // XP set (pf_gemm3_kernel): chunk-major int8 operand XQ3[k / 16][xp_tok token slots][16 B]; otherwise the row layout XQ[token][k]
+            if (XP) *reinterpret_cast<uint32_t*>(XQ + ((size_t)(qd >> 2) * xp_tok + b) * 16 + 4 * (qd & 3)) = packed;
+            else *reinterpret_cast<uint32_t*>(xq + 4 * qd) = packed;
+            if ((qd & 7) == 0) {
+                xs[qd >> 3] = qs;
+                if (XP) {      // the scale as the bf16 pair (hi = top 8 significand bits, lo = the rest: exact, qs is an f16 value) the s / -B s MFMAs read
+                    const float ahi = __uint_as_float(__float_as_uint(qs) & 0xFFFF0000u), alo = qs - ahi;
+                    const uint32_t pr = (__float_as_uint(ahi) >> 16) | (__float_as_uint(alo) & 0xFFFF0000u);
+                    const int blk = qd >> 3;
+                    XP[(size_t)blk * xp_tok + b] = make_uint2(pr, pr);
+                    // ragged K: the padded blocks of the last tile group carry zero weights; give them a zero activation scale too
+                    if (blk == (k >> 5) - 1)
+                        for (int pb = blk + 1; pb < ((blk + 4) & ~3); ++pb) XP[(size_t)pb * xp_tok + b] = make_uint2(0u, 0u);
+                }
+            }
+        } else {                                           // the wave-owned small-batch GEMM's operand layout (gl3_bd_gemm.h)
             float qs;
             const uint32_t packed = quantize_quad_pack(v, qs);
             *reinterpret_cast<uint32_t*>(XQ + bdq_offset(qd, b, tslots)) = packed;
@@ -1129,13 +1152,17 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
         GL3_HIP(hipMalloc((void**)&p->HB, M * d.hidden * 4));
     }
     const size_t MQ = M < BD_TS_MAX ? BD_TS_MAX : M;      // the small-batch operand layout (bd_tslots) always spans its 32 / 64 token slots
-    GL3_HIP(hipMalloc((void**)&p->XQ, MQ * p->maxk + GL3_TAIL_PAD));
+    const size_t MQP = (MQ + 127) & ~(size_t)127;      // token slots of the chunk-major layouts (whole 128-token GEMM tiles)
+    GL3_HIP(hipMalloc((void**)&p->XQ, MQP * p->maxk + GL3_TAIL_PAD));
     GL3_HIP(hipMalloc((void**)&p->XS, MQ * (p->maxk / 32) * 4 + GL3_TAIL_PAD));
+    p->xp_tok = (int)MQP;
+    GL3_HIP(hipMalloc((void**)&p->XP, (size_t)(p->maxk / 32 + 4) * p->xp_tok * 8 + GL3_TAIL_PAD));
+    GL3_HIP(hipMemsetAsync(p->XP, 0, (size_t)(p->maxk / 32 + 4) * p->xp_tok * 8 + GL3_TAIL_PAD, ctx->stream));
     GL3_HIP(hipMalloc((void**)&p->XQb, (size_t)BD_TS_MAX * p->maxk + GL3_TAIL_PAD));
     GL3_HIP(hipMalloc((void**)&p->XSb, (size_t)BD_TS_MAX * (p->maxk / 32) * 4 + GL3_TAIL_PAD));
     GL3_HIP(hipMemsetAsync(p->XQb, 0, (size_t)BD_TS_MAX * p->maxk, ctx->stream));
     GL3_HIP(hipMemsetAsync(p->XSb, 0, (size_t)BD_TS_MAX * (p->maxk / 32) * 4, ctx->stream));
-    GL3_HIP(hipMemsetAsync(p->XQ, 0, MQ * p->maxk, ctx->stream));
+    GL3_HIP(hipMemsetAsync(p->XQ, 0, MQP * p->maxk, ctx->stream));
     GL3_HIP(hipMemsetAsync(p->XS, 0, MQ * (p->maxk / 32) * 4, ctx->stream));
     GL3_HIP(hipMalloc((void**)&p->QKV, M * (ctx->q_dim + 2 * ctx->kv_dim) * 4));
     GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
@@ -1150,6 +1177,7 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_GEMM_LDS(EPI_STORE, 1, 4, 32); GL3_GEMM_LDS(EPI_RESID, 1, 4, 32); GL3_GEMM_LDS(EPI_SWIGLU, 1, 4, 32);
 #undef GL3_GEMM_LDS
     GL3_HIP(gl3_gemm2_allow_lds());                      // pf_gemm2_kernel instantiations (own translation unit)
+    GL3_HIP(gl3_gemm3_allow_lds());
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1163,10 +1191,17 @@ void gl3_prefill_free(gl3_ctx* ctx) {
     if (!p) return;
     for (auto ge : p->step_graphs) if (ge) hipGraphExecDestroy(ge);
     auto f = [](void* q) { if (q) hipFree(q); };
-    f(p->tokens); f(p->XQ); f(p->XS); f(p->XQb); f(p->XSb); f(p->QKV); f(p->ATT); f(p->seqpos); f(p->amax); f(p->amx_v); f(p->amx_i); f(p->XN); f(p->HB2);
+    f(p->tokens); f(p->XQ); f(p->XS); f(p->XP); f(p->XQb); f(p->XSb); f(p->QKV); f(p->ATT); f(p->seqpos); f(p->amax); f(p->amx_v); f(p->amx_i); f(p->XN); f(p->HB2);
     if (!p->in_arena) { f(p->X); f(p->AO); f(p->HB); f(p->LOGITS); }
     delete p;
     ctx->pf = nullptr;
+}
+
+// > 64-token GEMMs on pf_gemm3_kernel (default) or on the r3 / r4 kernels (GL3_PF_GEMM3=0): the quantiser and the GEMM of a step must agree on the
+// activation layout, so both ask here
+static bool pf_use_gemm3() {
+    static const bool on = !(getenv("GL3_PF_GEMM3") && atoi(getenv("GL3_PF_GEMM3")) == 0);
+    return on;
 }
 
 // Token slots of the XQ2 / XS2 operand layout when a step of n tokens runs on the wave-owned small-batch GEMM
@@ -1185,6 +1220,7 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     a.XQ = second_operand ? p->XQb : p->XQ; a.XS = second_operand ? p->XSb : p->XS;
     a.maxk = p->maxk; a.ntok = ntok; a.out = out; a.out_stride = out_stride; a.out_scale = out_scale;
     a.XQo = p->XQb; a.XSo = p->XSb;
+    a.XP = p->XP; a.xp_tok = p->xp_tok;
     // 128-row tiles only when they still give >= 2 workgroups per CU; otherwise 64-row tiles, and 8 wavefronts per
     // workgroup when even those leave a single workgroup per CU
     if (const int ts = bd_tslots(ntok)) {      // static-batched decode / small chunks: one wavefront per (16-row strip, 16 tokens), all of K
@@ -1217,6 +1253,9 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     // for the r3 kernel at 512 tokens of the 8B layer; the other shapes stay on the r3 kernel (qkv 79 vs 80, wo 57 vs 45, down 222 vs 139:
     // profiles/r04_gemm_experiments.md).  GL3_PF_GEMM2=0: r3 kernel everywhere; GL3_PF_GEMM2_ALL=1: r4 kernel for every shape;
     // GL3_PF_GEMM2=1: A/B form (-B s on the VALU).
+    // r6: every class on pf_gemm3_kernel (mid-stage barrier, partial vmcnt, scale-operand side table, chunk-major activations);
+    // GL3_PF_GEMM3=0 restores the r5 choice below (the quantiser then writes the row layout those kernels read)
+    if (pf_use_gemm3()) { gl3_gemm3_launch(EPI, a, w.rows, ntok, ctx->stream); return; }
     static const int g2 = getenv("GL3_PF_GEMM2") ? atoi(getenv("GL3_PF_GEMM2")) : 2;
     static const bool g2_all = getenv("GL3_PF_GEMM2_ALL") && atoi(getenv("GL3_PF_GEMM2_ALL"));
     if (g2 && (EPI == EPI_SWIGLU || g2_all)) { gl3_gemm2_launch(EPI, a, w.rows, ntok, g2, ctx->stream); return; }
@@ -1438,14 +1477,14 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         gl3_layer& L = ctx->layers[l];
         Gl3Range layer_range("layer", l);
         hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.attn_norm, d.rms_eps,
-                           p->XQ, p->XS, p->maxk, bd_tslots(n));
+                           p->XQ, p->XS, p->maxk, bd_tslots(n), (pf_use_gemm3() && n > 64) ? (uint2*)p->XP : nullptr, p->xp_tok);
         launch_gemm<EPI_STORE>(ctx, L.wqkv, nullptr, n, p->QKV, qkv_dim);
         const bool quantised_ao = fuse_q && one_seq < 0 && fused_decode;
         pf_attention(ctx, l, n, max_pos, one_seq, AOr, quantised_ao);
         if ((r = gl3_all_gather(ctx, GB_PF_AO, (size_t)n * qd)) != GL3_OK) return r;
         if (!quantised_ao)
             hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN>), dim3(n, (ctx->q_dim / 4 + 255) / 256), dim3(256), 0, s, p->AO, ctx->q_dim, qd, (const float*)nullptr,
-                               0.f, p->XQ, p->XS, p->maxk, bd_tslots(n));
+                               0.f, p->XQ, p->XS, p->maxk, bd_tslots(n), (pf_use_gemm3() && n > 64) ? (uint2*)p->XP : nullptr, p->xp_tok);
         if (ctx->wo_replicated) {
             // every rank holds all of Wo: one GEMM per rank chunk of the rank-chunked X (rows [c dml, (c + 1) dml) -> chunk c), no gather
             for (int c = 0; c < d.tp_size; ++c) {
@@ -1459,7 +1498,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
             if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
         }
         hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.ffn_norm, d.rms_eps,
-                           p->XQ, p->XS, p->maxk, bd_tslots(n));
+                           p->XQ, p->XS, p->maxk, bd_tslots(n), (pf_use_gemm3() && n > 64) ? (uint2*)p->XP : nullptr, p->xp_tok);
         if (fuse_q) {
             launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, HBr, hid, 1.0f, false, true);
             launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, Xr, dml, ctx->resid_scale, true);
@@ -1467,7 +1506,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
             launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, HBr, hid);
             if ((r = gl3_all_gather(ctx, GB_PF_HB, (size_t)n * hid)) != GL3_OK) return r;
             hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN>), dim3(n, (d.hidden / 4 + 255) / 256), dim3(256), 0, s, p->HB, d.hidden, hid, (const float*)nullptr, 0.f,
-                               p->XQ, p->XS, p->maxk, bd_tslots(n));
+                               p->XQ, p->XS, p->maxk, bd_tslots(n), (pf_use_gemm3() && n > 64) ? (uint2*)p->XP : nullptr, p->xp_tok);
             launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, Xr, dml, ctx->resid_scale);
         }
         if ((r = gl3_all_gather(ctx, GB_PF_X, (size_t)n * dml)) != GL3_OK) return r;
@@ -1541,7 +1580,7 @@ int32_t gl3_decode_batch_run(gl3_ctx* ctx, const int32_t* tokens, const int32_t*
             hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM_F32>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, (uint8_t*)nullptr, p->XN, 0, 0);
             launch_gemm_vl<EPI_STORE>(ctx, ctx->wcls, n, p->XN, d.dim, p->LOGITS + (size_t)d.tp_rank * n * vl, vl, ctx->logit_scale);
         } else {
-        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk, bd_tslots(n));
+        hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq, s, p->X, d.dim, ctx->dim_l, ctx->out_norm, d.rms_eps, p->XQ, p->XS, p->maxk, bd_tslots(n), (pf_use_gemm3() && n > 64) ? (uint2*)p->XP : nullptr, p->xp_tok);
         // vocab rows are split across ranks: this rank's logits are the chunk [n][vocab / tp] of the rank-chunked buffer
         launch_gemm<EPI_STORE>(ctx, ctx->wcls, nullptr, n, p->LOGITS + (size_t)d.tp_rank * n * vl, vl, ctx->logit_scale);
         }

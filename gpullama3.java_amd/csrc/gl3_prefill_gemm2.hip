@@ -7,6 +7,7 @@
 using namespace gl3;
 #include "gl3_bd_gemm.h"          // GemmArgs
 #include "gl3_prefill_gemm2.h"
+#include "gl3_prefill_gemm3.h"
 
 template <int EPI, int RF>
 constexpr int g2_lds_bytes() { return G2_RING * g2_stage_bytes((EPI == EPI_SWIGLU ? 2 : 1) * RF * 64); }
@@ -68,4 +69,55 @@ void gl3_gemm2_launch(int epi, const GemmArgs& a, int rows, int ntok, int mode, 
     if (epi == EPI_SWIGLU) g2_dispatch<EPI_SWIGLU>(a, rows, ntok, mode, s);
     else if (epi == EPI_RESID) g2_dispatch<EPI_RESID>(a, rows, ntok, mode, s);
     else g2_dispatch<EPI_STORE>(a, rows, ntok, mode, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- r6: pf_gemm3_kernel
+template <int EPI, int RF, int TF, int WR, int WC, int KB>
+constexpr int g3_lds_bytes() { return G3_RING * g3_stage_bytes((EPI == EPI_SWIGLU ? 2 : 1) * RF * 32 * WR, WC * TF * 32, KB); }
+template <int EPI, int RF, int TF, int WR, int WC, int KB, int OCC>
+static void g3_launch(const GemmArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((pf_gemm3_kernel<EPI, RF, TF, WR, WC, KB, OCC>), grid, dim3(64 * WR * WC), (g3_lds_bytes<EPI, RF, TF, WR, WC, KB>()), s, a);
+}
+template <int EPI, int RF, int TF, int WR, int WC, int KB, int OCC>
+static hipError_t g3_allow() {
+    return hipFuncSetAttribute((const void*)pf_gemm3_kernel<EPI, RF, TF, WR, WC, KB, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes<EPI, RF, TF, WR, WC, KB>());
+}
+// tile shapes (rows x tokens per workgroup; wavefront grid; blocks per stage):
+//   BIG   128 x 128, 2 x 2 wavefronts of 2 x 2 fragments, KB 2, two workgroups per CU   (gate + up as 64 + 64 rows; matrices with >= 512 such tiles)
+//   QKV    96 x 128, 3 x 4 one-tile wavefronts, KB 4, one workgroup per CU              (row counts that are a multiple of 96 with 128..384 tiles: 6144-row qkv)
+//   SMALL  64 x 128, 2 x 4 one-tile wavefronts, KB 4, one workgroup per CU              (everything else: the 4096-row wo / down projections)
+template <int EPI>
+static hipError_t g3_allow_epi() {
+    hipError_t e = g3_allow<EPI, EPI == EPI_SWIGLU ? 1 : 2, 2, 2, 2, 2, 2>();
+    if constexpr (EPI != EPI_SWIGLU) {
+        if (e == hipSuccess) e = g3_allow<EPI, 1, 1, 3, 4, 4, 1>();
+        if (e == hipSuccess) e = g3_allow<EPI, 1, 1, 2, 4, 4, 1>();
+    }
+    return e;
+}
+hipError_t gl3_gemm3_allow_lds() {
+    hipError_t e = g3_allow_epi<EPI_SWIGLU>();
+    if (e == hipSuccess) e = g3_allow_epi<EPI_RESID>();
+    if (e == hipSuccess) e = g3_allow_epi<EPI_STORE>();
+    return e;
+}
+template <int EPI>
+static void g3_dispatch(GemmArgs a, int rows, int ntok, hipStream_t s) {
+    const int ntt = (ntok + 127) / 128;
+    a.ntt = ntt;
+    auto grid = [&](int nrt) { a.nrt = nrt; return dim3(8 * ((ntt * nrt + 7) / 8)); };
+    if constexpr (EPI == EPI_SWIGLU) g3_launch<EPI, 1, 2, 2, 2, 2, 2>(a, grid((rows + 63) / 64), s);
+    else {
+        const int t128 = ntt * ((rows + 127) / 128), t96 = ntt * ((rows + 95) / 96);
+        static const int force = getenv("GL3_PF_GEMM3_SHAPE") ? atoi(getenv("GL3_PF_GEMM3_SHAPE")) : 0;      // A/B: 1 BIG, 2 QKV, 3 SMALL
+        const int shape = force ? force : t128 >= 512 ? 1 : (rows % 96 == 0 && t96 > 128 && t96 <= 384) ? 2 : 3;
+        if (shape == 1) g3_launch<EPI, 2, 2, 2, 2, 2, 2>(a, grid((rows + 127) / 128), s);
+        else if (shape == 2) g3_launch<EPI, 1, 1, 3, 4, 4, 1>(a, grid((rows + 95) / 96), s);
+        else g3_launch<EPI, 1, 1, 2, 4, 4, 1>(a, grid((rows + 63) / 64), s);
+    }
+}
+void gl3_gemm3_launch(int epi, const GemmArgs& a, int rows, int ntok, hipStream_t s) {
+    if (epi == EPI_SWIGLU) g3_dispatch<EPI_SWIGLU>(a, rows, ntok, s);
+    else if (epi == EPI_RESID) g3_dispatch<EPI_RESID>(a, rows, ntok, s);
+    else g3_dispatch<EPI_STORE>(a, rows, ntok, s);
 }

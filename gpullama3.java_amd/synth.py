@@ -116,6 +116,9 @@ CONFIGS = {
     # 8-producer kernel; head_size 64) under the TIED 128256 x 2048 vocabulary projection
     "1b-layer": ModelConfig("Llama-3.2-1B-1layer-random", ARCH_LLAMA, 2048, 8192, 1, 32, 8, 64, 128256, 648, 1e-5, 500000.0, True),
     "qwen3-4b-2l": ModelConfig("Qwen3-4B-2layer-random", ARCH_QWEN3, 2560, 9728, 2, 32, 8, 128, 4096, 64, 1e-6, 1000000.0, True),
+    # ragged everything for the > 64-token GEMM: K = 288 / 864 (9 / 27 blocks: the last K stage holds ONE real block), 288 / 480 / 864 rows
+    # (not multiples of the 64- / 96- / 128-row tiles), 9 heads on 3 kv heads
+    "ragged-llama": ModelConfig("ragged-llama-random", ARCH_LLAMA, 288, 864, 2, 9, 3, 32, 544, 200, 1e-5, 10000.0, False),
 }
 
 

@@ -316,6 +316,33 @@ def test_batched_prefill_is_bit_identical_to_the_cpu_path(pkg, orc, planmod, cfg
     plan.freeTornadoExecutionPlan()
 
 
+@pytest.mark.parametrize("cfg,batch,chunks", [("mid-llama", 128, [100, 57]), ("mid-qwen2", 160, [129, 20]), ("mid-phi3", 128, [65, 70]), ("phi3-hs96", 160, [150]),
+                                             ("mid-granite", 96, [96, 50]), ("mid-qwen3", 36, [36]), ("ragged-llama", 192, [131, 66]), ("ragged-llama", 70, [70, 65, 64])])
+def test_batched_prefill_chunks_above_64_tokens(pkg, orc, planmod, cfg, batch, chunks):
+    """Chunks of more than 64 tokens take the LDS-tiled GEMM (r6: pf_gemm3_kernel — 128 x 128, 96 x 128 and 64 x 128 workgroup tiles picked by
+    the matrix's row count): ragged token counts (the last 128-token tile partly empty), row counts that are no multiple of a tile, K = 9 / 27
+    blocks (the last K stage holds one real block: zero scale operands for the padded ones), a chunk that starts at a non-zero position."""
+    plan_mod, hip = planmod
+    m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], seed=35)
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=batch)
+    o = orc.COracle(m)
+    n = sum(chunks)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, n + 1)
+    pos = 0
+    for c in chunks:
+        plan.tornadoVMForwardBatchPrefill(toks[pos:pos + c], pos)
+        o.prefill(toks[pos:pos + c], pos)
+        pos += c
+        assert np.array_equal(plan.x(), o.x())
+    for l in range(m.cfg.n_layers):
+        for p in (0, min(63, n - 1), min(64, n - 1), n // 2, n - 1):
+            k, v = plan.kv(l, p)
+            ko, vo = o.kv(l, p)
+            assert np.array_equal(k, ko) and np.array_equal(v, vo), (l, p)
+    assert np.array_equal(plan.tornadoVMForwardDecode(toks[n], n), o.forward(toks[n], n))
+    plan.freeTornadoExecutionPlan()
+
+
 @pytest.mark.parametrize("cfg,wtype,f32act,batch,chunks", [("mid-llama", 1, False, 64, [40, 23, 3]), ("mid-llama", 2, False, 64, [40, 23, 3]),
                                                           ("mid-qwen3", 1, False, 32, [30, 7]), ("mid-qwen3", 2, False, 32, [17, 20]),
                                                           ("mid-llama", 8, True, 64, [33, 31]), ("mid-qwen2", 8, True, 16, [16, 5]),
