@@ -218,6 +218,14 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
     issue_n(0, 0);
     refill(std::integral_constant<int, 0>{}, smem, smem + STAGE);
     int cur = 0;                                       // ring slot of stage kb
+#ifdef G3_TIMING
+    unsigned long long tm_bar = 0, tm_scale = 0, tm_dma = 0, tm_t, tm_begin = __builtin_readcyclecounter();
+#define G3_T0() tm_t = __builtin_readcyclecounter()
+#define G3_T1(acc_) acc_ += __builtin_readcyclecounter() - tm_t
+#else
+#define G3_T0() do {} while (0)
+#define G3_T1(acc_) do {} while (0)
+#endif
     for (int kb = 0; kb < nkb; ++kb) {
         const int nxt = cur == G3_RING - 1 ? 0 : cur + 1, prv = nxt == G3_RING - 1 ? 0 : nxt + 1;
         const int kf_late = min(kb + 3, nkb - 1);      // window kb (after this iteration's barrier): stage kb + 3 -> slot cur
@@ -250,17 +258,27 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
                 // barrier kb: every read of slot cur has been issued (and is waited for here), so the slot is free; everything older than
                 // window kb - 1's pieces has landed, i.e. stage kb + 1 is complete in slot nxt and the weight scales of stage kb + 3 are in r_ws
                 __builtin_amdgcn_sched_barrier(0);
+                G3_T0();
                 asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)\n\ts_barrier" : "+v"(r_ws) : "n"(NDMA) : "memory");
+                G3_T1(tm_bar);
+                G3_T0();
                 scale_store(cur);
                 scale_load(min(kb + 4, nkb - 1));
+                G3_T1(tm_scale);
                 __builtin_amdgcn_sched_barrier(0);
             }
             refill(std::integral_constant<int, in>{}, next_stage ? sb_nxt : sb_cur, sb_nxt);
+#if defined(G3_TIMING) && G3_TIMING >= 2
+            G3_T0();
+#endif
             if constexpr (i >= BSTEP) {
                 if constexpr (i - BSTEP < NDMA) dma_one(kf_late, cur, i - BSTEP);
             } else {
                 if constexpr (i + NLATE < NDMA) dma_one(kf_early, prv, i + NLATE);
             }
+#if defined(G3_TIMING) && G3_TIMING >= 2
+            G3_T1(tm_dma);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][tf][r] = acc[f][tf][r] + cf[r];       // result +=, blocks ascending
@@ -272,6 +290,11 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
         cur = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(r_ws) :: "memory");      // the loads hidden from the compiler's counters end here
+#ifdef G3_TIMING
+    if (lane == 0 && (J % 61) == 0)
+        printf("g3 EPI %d NW %d KB %d J %d wave %d stages %d: barrier %llu scale %llu dma %llu total %llu cycles\n", EPI, NW, KB, J, wave, nkb, tm_bar, tm_scale, tm_dma,
+               __builtin_readcyclecounter() - tm_begin);
+#endif
     // ---- epilogue.  C layout: token = lane & 31 (column), weight row = (r & 3) + 8 * (r >> 2) + 4 * hi
 #pragma unroll
     for (int tf = 0; tf < TF; ++tf) {

@@ -1,7 +1,7 @@
 #!/bin/bash
-# r4: SQ / LDS / TCP counters of the batched-prefill GEMMs (separate --pmc passes, no tracing), variant = $2 ("VAR=val ...")
+# SQ / LDS / TCP counters of the batched-prefill GEMMs (separate --pmc passes, no tracing), variant = $2 ("VAR=val ...")
 set -u
-O=$1; V=${2:-GL3_PF_GEMM2=2}; mkdir -p $O
+O=$1; V=${2:-GL3_NOOP=1}; mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES"
@@ -10,6 +10,7 @@ P3="SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ
 P4="FETCH_SIZE TCP_TCC_READ_REQ_sum"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
+  [ -n "${PASSES:-}" ] && case " $PASSES " in *" $((i+1)) "*) ;; *) i=$((i+1)); continue;; esac
   i=$((i+1))
   ( cd /tmp && env $V timeout 300 rocprofv3 --pmc $P --output-format csv -d $R/$O/p$i -o p -- python $R/scripts/gemm_ab.py llama-3-8b 2 > $R/$O/p$i.log 2>&1; echo "pass $i rc=$?" )
   python scripts/pmc_table.py $O/p$i gemm > $O/pmc_p$i.csv 2>> $O/p$i.log
