@@ -8,6 +8,7 @@ using namespace gl3;
 #include "gl3_bd_gemm.h"          // GemmArgs
 #include "gl3_prefill_gemm2.h"
 #include "gl3_prefill_gemm3.h"
+#include "gl3_prefill_gemm3t.h"
 
 template <int EPI, int RF>
 constexpr int g2_lds_bytes() { return G2_RING * g2_stage_bytes((EPI == EPI_SWIGLU ? 2 : 1) * RF * 64); }
@@ -95,8 +96,19 @@ static hipError_t g3_allow_epi() {
     }
     return e;
 }
+template <int NFR>
+static hipError_t g3t_allow() { return hipFuncSetAttribute((const void*)pf_gemm3t_kernel<NFR>, hipFuncAttributeMaxDynamicSharedMemorySize, g3t_lds_bytes(NFR)); }
+template <int NFR>
+static void g3t_launch(GemmArgs a, int rows, int ntt, hipStream_t s) {
+    a.ntt = ntt; a.nrt = (rows + 32 * NFR - 1) / (32 * NFR);
+    hipLaunchKernelGGL((pf_gemm3t_kernel<NFR>), dim3(8 * ((a.ntt * a.nrt + 7) / 8)), dim3(512), g3t_lds_bytes(NFR), s, a);
+}
 hipError_t gl3_gemm3_allow_lds() {
     hipError_t e = g3_allow_epi<EPI_SWIGLU>();
+    if (e == hipSuccess) e = g3t_allow<4>();
+    if (e == hipSuccess) e = g3t_allow<5>();
+    if (e == hipSuccess) e = g3t_allow<6>();
+    if (e == hipSuccess) e = g3t_allow<7>();
     if (e == hipSuccess) e = g3_allow_epi<EPI_RESID>();
     if (e == hipSuccess) e = g3_allow_epi<EPI_STORE>();
     return e;
@@ -106,8 +118,24 @@ static void g3_dispatch(GemmArgs a, int rows, int ntok, hipStream_t s) {
     const int ntt = (ntok + 127) / 128;
     a.ntt = ntt;
     auto grid = [&](int nrt) { a.nrt = nrt; return dim3(8 * ((ntt * nrt + 7) / 8)); };
-    if constexpr (EPI == EPI_SWIGLU) g3_launch<EPI, 1, 2, 2, 2, 2, 2>(a, grid((rows + 63) / 64), s);
-    else {
+    if constexpr (EPI == EPI_SWIGLU) {
+        // gate + up: the 128 x 128 tiling (two workgroups per CU, 8 result tiles per SIMD and round) or a tall tiling (one workgroup per CU, 2 NFR tiles per
+        // SIMD and round, gl3_prefill_gemm3t.h) — whichever leaves a SIMD fewer tile-steps.  GL3_PF_GEMM3_TALL: -1 never, 4 .. 7 that shape always.
+        static const int tall_env = getenv("GL3_PF_GEMM3_TALL") ? atoi(getenv("GL3_PF_GEMM3_TALL")) : 0;
+        int best = 0, cost = ((ntt * ((rows + 63) / 64) + 511) / 512) * 8;
+        for (int nfr = 4; nfr <= 7 && tall_env == 0; ++nfr) {
+            const int c = ((ntt * ((rows + 32 * nfr - 1) / (32 * nfr)) + 255) / 256) * 2 * nfr;
+            if (c < cost) { cost = c; best = nfr; }
+        }
+        if (tall_env >= 4 && tall_env <= 7) best = tall_env;
+        switch (best) {
+        case 4: g3t_launch<4>(a, rows, ntt, s); break;
+        case 5: g3t_launch<5>(a, rows, ntt, s); break;
+        case 6: g3t_launch<6>(a, rows, ntt, s); break;
+        case 7: g3t_launch<7>(a, rows, ntt, s); break;
+        default: g3_launch<EPI, 1, 2, 2, 2, 2, 2>(a, grid((rows + 63) / 64), s);
+        }
+    } else {
         const int t128 = ntt * ((rows + 127) / 128), t96 = ntt * ((rows + 95) / 96);
         static const int force = getenv("GL3_PF_GEMM3_SHAPE") ? atoi(getenv("GL3_PF_GEMM3_SHAPE")) : 0;      // A/B: 1 BIG, 2 QKV, 3 SMALL
         const int shape = force ? force : t128 >= 512 ? 1 : (rows % 96 == 0 && t96 > 128 && t96 <= 384) ? 2 : 3;
