@@ -35,7 +35,7 @@ struct gl3_prefill_state {
     float* X = nullptr;                 // [M][dim] residual stream (rank-chunked [tp][n][dim/tp] under tensor parallelism)
     uint8_t* XQ = nullptr;              // [M][maxk] int8 activations
     float* XS = nullptr;                // [M][maxk/32] activation scales
-    uint8_t* XP = nullptr;              // [maxk/32 + 4][xp_tok][8 B] the activation scales as bf16 MFMA operands {a_hi, a_lo, a_hi, a_lo} (pf_gemm3_kernel)
+    uint8_t* XP = nullptr;              // [maxk/32 + 4][2 lane halves][xp_tok][16 B] the activation scales as bf16 MFMA operands (pf_gemm3_kernel)
     int xp_tok = 0;                     //   token slots per block: max_batch rounded up to the GEMM's 128-token tile
     uint8_t* XQb = nullptr;             // second small-batch operand buffer: hb quantised by the gate/up kernel's own epilogue
     float* XSb = nullptr;               //   (its input still being read by other workgroups)
@@ -142,14 +142,22 @@ __global__ __launch_bounds__(256) void pf_norm_quant_kernel(const float* __restr
             else *reinterpret_cast<uint32_t*>(xq + 4 * qd) = packed;
             if ((qd & 7) == 0) {
                 xs[qd >> 3] = qs;
-                if (XP) {      // the scale as the bf16 pair (hi = top 8 significand bits, lo = the rest: exact, qs is an f16 value) the s / -B s MFMAs read
+                if (XP) {
+                    // the scale as the bf16 operands the s / -B s MFMAs read (gl3_prefill_gemm3.h): P = {a_hi, a_lo} (hi = top 8 significand bits, lo = the
+                    // rest: exact, qs is an f16 value), Q = P * -2^23 for the k slots of lane half 0, P * -2^22 for half 1 (their sum is -B = -3 * 2^22)
                     const float ahi = __uint_as_float(__float_as_uint(qs) & 0xFFFF0000u), alo = qs - ahi;
-                    const uint32_t pr = (__float_as_uint(ahi) >> 16) | (__float_as_uint(alo) & 0xFFFF0000u);
+                    auto pk = [](float h, float l) { return (__float_as_uint(h) >> 16) | (__float_as_uint(l) & 0xFFFF0000u); };
+                    const uint32_t pr = pk(ahi, alo), q0 = pk(ahi * -8388608.f, alo * -8388608.f), q1 = pk(ahi * -4194304.f, alo * -4194304.f);
                     const int blk = qd >> 3;
-                    XP[(size_t)blk * xp_tok + b] = make_uint2(pr, pr);
-                    // ragged K: the padded blocks of the last tile group carry zero weights; give them a zero activation scale too
+                    uint4* xp = reinterpret_cast<uint4*>(XP);      // XP[block][half][xp_tok][16 B]
+                    xp[((size_t)blk * 2 + 0) * xp_tok + b] = make_uint4(pr, pr, q0, q0);
+                    xp[((size_t)blk * 2 + 1) * xp_tok + b] = make_uint4(0u, 0u, q1, q1);
+                    // ragged K: the padded blocks of the last tile group carry zero weights; give them zero activation operands too
                     if (blk == (k >> 5) - 1)
-                        for (int pb = blk + 1; pb < ((blk + 4) & ~3); ++pb) XP[(size_t)pb * xp_tok + b] = make_uint2(0u, 0u);
+                        for (int pb = blk + 1; pb < ((blk + 4) & ~3); ++pb) {
+                            xp[((size_t)pb * 2 + 0) * xp_tok + b] = make_uint4(0u, 0u, 0u, 0u);
+                            xp[((size_t)pb * 2 + 1) * xp_tok + b] = make_uint4(0u, 0u, 0u, 0u);
+                        }
                 }
             }
         } else {                                           // the wave-owned small-batch GEMM's operand layout (gl3_bd_gemm.h)
@@ -1156,8 +1164,8 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_HIP(hipMalloc((void**)&p->XQ, MQP * p->maxk + GL3_TAIL_PAD));
     GL3_HIP(hipMalloc((void**)&p->XS, MQ * (p->maxk / 32) * 4 + GL3_TAIL_PAD));
     p->xp_tok = (int)MQP;
-    GL3_HIP(hipMalloc((void**)&p->XP, (size_t)(p->maxk / 32 + 4) * p->xp_tok * 8 + GL3_TAIL_PAD));
-    GL3_HIP(hipMemsetAsync(p->XP, 0, (size_t)(p->maxk / 32 + 4) * p->xp_tok * 8 + GL3_TAIL_PAD, ctx->stream));
+    GL3_HIP(hipMalloc((void**)&p->XP, (size_t)(p->maxk / 32 + 4) * p->xp_tok * 32 + GL3_TAIL_PAD));
+    GL3_HIP(hipMemsetAsync(p->XP, 0, (size_t)(p->maxk / 32 + 4) * p->xp_tok * 32 + GL3_TAIL_PAD, ctx->stream));
     GL3_HIP(hipMalloc((void**)&p->XQb, (size_t)BD_TS_MAX * p->maxk + GL3_TAIL_PAD));
     GL3_HIP(hipMalloc((void**)&p->XSb, (size_t)BD_TS_MAX * (p->maxk / 32) * 4 + GL3_TAIL_PAD));
     GL3_HIP(hipMemsetAsync(p->XQb, 0, (size_t)BD_TS_MAX * p->maxk, ctx->stream));

@@ -96,19 +96,23 @@ static hipError_t g3_allow_epi() {
     }
     return e;
 }
-template <int NFR>
-static hipError_t g3t_allow() { return hipFuncSetAttribute((const void*)pf_gemm3t_kernel<NFR>, hipFuncAttributeMaxDynamicSharedMemorySize, g3t_lds_bytes(NFR)); }
-template <int NFR>
-static void g3t_launch(GemmArgs a, int rows, int ntt, hipStream_t s) {
-    a.ntt = ntt; a.nrt = (rows + 32 * NFR - 1) / (32 * NFR);
-    hipLaunchKernelGGL((pf_gemm3t_kernel<NFR>), dim3(8 * ((a.ntt * a.nrt + 7) / 8)), dim3(512), g3t_lds_bytes(NFR), s, a);
+template <int NFR, int WCN>
+static hipError_t g3t_allow() { return hipFuncSetAttribute((const void*)pf_gemm3t_kernel<NFR, WCN>, hipFuncAttributeMaxDynamicSharedMemorySize, g3t_lds_bytes(NFR, WCN)); }
+template <int NFR, int WCN>
+static void g3t_launch(GemmArgs a, int rows, int ntok, hipStream_t s) {
+    a.ntt = (ntok + 32 * WCN - 1) / (32 * WCN); a.nrt = (rows + 32 * NFR - 1) / (32 * NFR);
+    hipLaunchKernelGGL((pf_gemm3t_kernel<NFR, WCN>), dim3(8 * ((a.ntt * a.nrt + 7) / 8)), dim3(128 * WCN), g3t_lds_bytes(NFR, WCN), s, a);
 }
 hipError_t gl3_gemm3_allow_lds() {
     hipError_t e = g3_allow_epi<EPI_SWIGLU>();
-    if (e == hipSuccess) e = g3t_allow<4>();
-    if (e == hipSuccess) e = g3t_allow<5>();
-    if (e == hipSuccess) e = g3t_allow<6>();
-    if (e == hipSuccess) e = g3t_allow<7>();
+    if (e == hipSuccess) e = g3t_allow<4, 4>();
+    if (e == hipSuccess) e = g3t_allow<5, 4>();
+    if (e == hipSuccess) e = g3t_allow<6, 4>();
+    if (e == hipSuccess) e = g3t_allow<7, 4>();
+    if (e == hipSuccess) e = g3t_allow<4, 2>();
+    if (e == hipSuccess) e = g3t_allow<5, 2>();
+    if (e == hipSuccess) e = g3t_allow<6, 2>();
+    if (e == hipSuccess) e = g3t_allow<7, 2>();
     if (e == hipSuccess) e = g3_allow_epi<EPI_RESID>();
     if (e == hipSuccess) e = g3_allow_epi<EPI_STORE>();
     return e;
@@ -122,19 +126,22 @@ static void g3_dispatch(GemmArgs a, int rows, int ntok, hipStream_t s) {
         // gate + up: the 128 x 128 tiling (two workgroups per CU, 8 result tiles per SIMD and round) or a tall tiling (one workgroup per CU, 2 NFR tiles per
         // SIMD and round, gl3_prefill_gemm3t.h) — whichever leaves a SIMD fewer tile-steps.  GL3_PF_GEMM3_TALL: -1 never, 4 .. 7 that shape always.
         static const int tall_env = getenv("GL3_PF_GEMM3_TALL") ? atoi(getenv("GL3_PF_GEMM3_TALL")) : 0;
+        static const int tall_wcn = getenv("GL3_PF_GEMM3_TALL_WCN") ? atoi(getenv("GL3_PF_GEMM3_TALL_WCN")) : 4;      // 4: one 8-wavefront workgroup per CU (default); 2: two of 4
         int best = 0, cost = ((ntt * ((rows + 63) / 64) + 511) / 512) * 8;
         for (int nfr = 4; nfr <= 7 && tall_env == 0; ++nfr) {
             const int c = ((ntt * ((rows + 32 * nfr - 1) / (32 * nfr)) + 255) / 256) * 2 * nfr;
             if (c < cost) { cost = c; best = nfr; }
         }
         if (tall_env >= 4 && tall_env <= 7) best = tall_env;
+#define GL3_G3T(N_) do { if (tall_wcn == 4) g3t_launch<N_, 4>(a, rows, ntok, s); else g3t_launch<N_, 2>(a, rows, ntok, s); } while (0)
         switch (best) {
-        case 4: g3t_launch<4>(a, rows, ntt, s); break;
-        case 5: g3t_launch<5>(a, rows, ntt, s); break;
-        case 6: g3t_launch<6>(a, rows, ntt, s); break;
-        case 7: g3t_launch<7>(a, rows, ntt, s); break;
+        case 4: GL3_G3T(4); break;
+        case 5: GL3_G3T(5); break;
+        case 6: GL3_G3T(6); break;
+        case 7: GL3_G3T(7); break;
         default: g3_launch<EPI, 1, 2, 2, 2, 2, 2>(a, grid((rows + 63) / 64), s);
         }
+#undef GL3_G3T
     } else {
         const int t128 = ntt * ((rows + 127) / 128), t96 = ntt * ((rows + 95) / 96);
         static const int force = getenv("GL3_PF_GEMM3_SHAPE") ? atoi(getenv("GL3_PF_GEMM3_SHAPE")) : 0;      // A/B: 1 BIG, 2 QKV, 3 SMALL

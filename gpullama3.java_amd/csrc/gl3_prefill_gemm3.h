@@ -12,10 +12,12 @@
 //         window k = [barrier k, barrier k + 1): pieces of stage k + 3 -> slot k % 3 (just freed);
 //         barrier k + 1 waits s_waitcnt vmcnt(NDMA) = everything but window k's own pieces, i.e. stage k + 2 has landed.
 //     Raw s_barrier + partial vmcnt from an asm block: nothing ever waits for a piece it has just issued.
-//   * the activation-side scale operands {bf16(a_hi), bf16(a_lo)} x 2 come from a side table XP[block][token slot][8 B] written by
-//     pf_norm_quant_kernel next to XQ / XS (one entry per (token, block), built once per activation instead of once per row tile) and travel by
-//     LDS-DMA like the int8 operands; only the weight-side entries (one per (row, block) of the stage) are still converted in the kernel, by the
-//     threads of window k right after barrier k from a load issued a whole window earlier (inline asm, so that its wait is the barrier's).
+//   * the lane-half constants of the -B s product (-2^23 in k slots 0-3, -2^22 in slots 4-7) ride on the ACTIVATION side: the side table
+//     XP[block][half][token slot][16 B] = {P, P, Q, Q} with P = {bf16(a_hi), bf16(a_lo)}, Q = the same pair times -2^23 (half 0) / -2^22 (half 1), and
+//     P = 0 in half 1, is written by pf_norm_quant_kernel next to XQ / XS — once per activation instead of once per row tile — and travels by
+//     LDS-DMA like the int8 operands.  The weight side is then ONE 8-byte operand {w_hi, w_hi, w_lo, w_lo} per (row, block) for both scale MFMAs,
+//     converted in the kernel (7 VALU + one 8-byte LDS store per entry; r4's form: 19 VALU + two 16-byte stores) by the threads of window k right
+//     behind barrier k from a load issued a whole window earlier (inline asm, so that its wait is the barrier's).
 //   * the int8 activations are stored chunk-major, XQ3[k / 16][token slot][16 B] (pf_norm_quant_kernel writes that layout when the side table is
 //     on): an activation piece (64 tokens x 16 B of one k chunk) is 1 KB of CONSECUTIVE bytes.  In the row layout XQ[token][k] the same piece was
 //     64 separate 16-byte accesses on 64 cache lines — 8 of a stage's 18 pieces went through the texture addresser one line at a time.
@@ -25,12 +27,12 @@
 //   * generic wave grid WR x WC with NF x TF fragments per wavefront and KB blocks per stage, so that the 4096-row projections (wo / down: 256
 //     workgroups of 64 rows x 128 tokens) run 8 one-tile wavefronts per workgroup with FOUR blocks per stage (a barrier per 4 steps, not 2) and
 //     the qkv projection (6144 rows) 12 one-tile wavefronts on 96-row tiles = exactly one workgroup per CU.
-// Ring slot image (as gemm2): Aq[blk][half][AROWS][16 B] | At[blk][half][AROWS][16 B] | Bq[blk][half][TOK][16 B] | Bs[blk][TOK][8 B].
+// Ring slot image: Aq[blk][half][AROWS][16 B] | At[blk][AROWS][8 B] | Bq[blk][half][TOK][16 B] | Bs[blk][half][TOK][16 B].
 #pragma once
 #include "gl3_prefill_gemm2.h"
 
 constexpr int G3_RING = 3;
-__host__ __device__ constexpr int g3_stage_bytes(int arows, int tok, int kb) { return kb * (2 * arows * 16 + 2 * arows * 16 + 2 * tok * 16 + tok * 8); }
+__host__ __device__ constexpr int g3_stage_bytes(int arows, int tok, int kb) { return kb * (2 * arows * 16 + arows * 8 + 2 * tok * 16 + 2 * tok * 16); }
 
 // first tile of a stage whose operand refill reads the NEXT stage's slot (tiles run block-major, row fragment, token fragment)
 __host__ __device__ constexpr int g3_first_wrap_tile(int kb, int nf, int tf) {
@@ -52,12 +54,12 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
     static_assert(NF <= 2 && TF <= 2, "accumulator budget");
     static_assert(NM == 1 || RF == 1, "SwiGLU: fragment index = matrix");
     static_assert(KB == 2 || KB == 4, "a stage is half a Q8T tile group or a whole one");
-    static_assert(TOK == 128, "one scale-table piece per block");
+    static_assert(TOK == 128, "token tile");
     static_assert(NM == 1 || RPM % 64 == 0, "a weight piece (64 rows) belongs to one matrix");
-    constexpr int OFF_AT = KB * 2 * AROWS * 16, OFF_BQ = 2 * OFF_AT, OFF_BS = OFF_BQ + KB * 2 * TOK * 16;
+    constexpr int OFF_AT = KB * 2 * AROWS * 16, OFF_BQ = OFF_AT + KB * AROWS * 8, OFF_BS = OFF_BQ + KB * 2 * TOK * 16;
     constexpr int STAGE = g3_stage_bytes(AROWS, TOK, KB);
-    static_assert(STAGE == OFF_BS + KB * TOK * 8, "stage layout");
-    constexpr int NLA = KB * 2 * AROWS / 64, NLB = KB * 2 * TOK / 64, NLP = KB;      // LDS-DMA pieces per stage: weights, activations, activation scale operands
+    static_assert(STAGE == OFF_BS + KB * 2 * TOK * 16, "stage layout");
+    constexpr int NLA = KB * 2 * AROWS / 64, NLB = KB * 2 * TOK / 64, NLP = KB * 2 * TOK / 64;      // LDS-DMA pieces per stage: weights, activations, activation scale operands
     constexpr int NPIECE = NLA + NLB + NLP;
     constexpr int NDMA = (NPIECE + NW - 1) / NW;                                       // ... per wavefront
     constexpr int NAT = AROWS * KB;                                                    // weight scale entries per stage (one thread each)
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
     constexpr int FWT = g3_first_wrap_tile(KB, NF, TF), BSTEP = FWT - 1;              // the barrier sits in step BSTEP, before the refill behind tile FWT
     static_assert(BSTEP >= 0 && BSTEP < NTILE, "barrier step");
     constexpr int NLATE = NTILE - BSTEP;                                               // steps BSTEP .. NTILE - 1 follow the barrier inside the iteration
-    static_assert(NDMA <= NTILE, "one LDS-DMA piece per step");
+    constexpr int PPS = (NDMA + NTILE - 1) / NTILE;                                    // LDS-DMA pieces per step
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tl = lane & 31, hi = lane >> 5;
@@ -110,12 +112,12 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
             p_dst[u] = OFF_BQ + 1024 * jb;
             p_base[u] = a.XQ;
             p_sh[u] = 0; p_mul[u] = (uint32_t)(2 * KB) * (uint32_t)a.xp_tok * 16; p_odd[u] = 0;
-        } else {                                       // activation scale operands XP[block][token slot][8 B]: block jp of the stage = one piece
-            const int jp = j - NLA - NLB;
-            p_lane[u] = ((uint32_t)jp * (uint32_t)a.xp_tok + (uint32_t)tok0) * 8 + 16 * lane;
+        } else {                                       // activation scale operands XP[block][half][token slot][16 B], the image of Bs
+            const int jp = j - NLA - NLB, e = 64 * jp + lane, c = e / TOK;      // c = blk * 2 + half
+            p_lane[u] = ((uint32_t)c * (uint32_t)a.xp_tok + (uint32_t)(tok0 + e % TOK)) * 16;
             p_dst[u] = OFF_BS + 1024 * jp;
             p_base[u] = a.XP;
-            p_sh[u] = 0; p_mul[u] = (uint32_t)KB * (uint32_t)a.xp_tok * 8; p_odd[u] = 0;
+            p_sh[u] = 0; p_mul[u] = (uint32_t)(2 * KB) * (uint32_t)a.xp_tok * 16; p_odd[u] = 0;
         }
     }
     auto dma_one = [&](int kf, int slot, int u) {      // piece u of K stage kf -> ring slot; branch-free scalar address arithmetic
@@ -136,10 +138,7 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
         if (t < NAT) {
             const float wf = h2f((uint16_t)r_ws);
             const float whi = __uint_as_float(__float_as_uint(wf) & 0xFFFF0000u), wlo = wf - whi;     // 8 + <= 3 significand bits
-            const v4i_t lo = {(int)g2_bf16_dup(whi), (int)g2_bf16_dup(wlo), (int)g2_bf16_dup(whi * -8388608.f), (int)g2_bf16_dup(wlo * -8388608.f)};
-            const v4i_t hh = {0, 0, (int)g2_bf16_dup(whi * -4194304.f), (int)g2_bf16_dup(wlo * -4194304.f)};
-            *reinterpret_cast<v4i_t*>(base + OFF_AT + ((size_t)(s_blk * 2 + 0) * AROWS + s_row) * 16) = lo;
-            *reinterpret_cast<v4i_t*>(base + OFF_AT + ((size_t)(s_blk * 2 + 1) * AROWS + s_row) * 16) = hh;
+            *reinterpret_cast<uint2*>(base + OFF_AT + ((size_t)s_blk * AROWS + s_row) * 8) = make_uint2(g2_bf16_dup(whi), g2_bf16_dup(wlo));
         }
     };
 
@@ -157,34 +156,34 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
     const v16f2_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // ---- operand fetch of one block from a ring slot; the per-lane LDS offsets are stage-independent
-    v4i_t bf[TF], af[NF], at[NF];
-    v4s_t bp[TF];
+    v4i_t bf[TF], af[NF], bp[TF];                      // bp = {s operand (2 dwords), -B s operand (2 dwords)} of the lane's half
+    v4s_t at[NF];                                      // {w_hi, w_hi, w_lo, w_lo}: the A operand of both scale MFMAs
     v16i_t D[2];
     v16f2_t S[2], N[1];
     uint32_t la[NF], lb[TF][KB], lp[TF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) la[f] = (uint32_t)((hi * AROWS + (NM == 2 ? f * RPM + wr * 32 : wr * (32 * RF) + f * 32) + tl) * 16);
+    for (int f = 0; f < NF; ++f) la[f] = (uint32_t)(NM == 2 ? f * RPM + wr * 32 : wr * (32 * RF) + f * 32) + tl;      // local weight row
 #pragma unroll
     for (int tf = 0; tf < TF; ++tf) {
         const int tk = wc * (32 * TF) + tf * 32 + tl;
-        lp[tf] = (uint32_t)(OFF_BS + tk * 8);
+        lp[tf] = (uint32_t)(OFF_BS + (hi * TOK + tk) * 16);
 #pragma unroll
         for (int b = 0; b < KB; ++b) lb[tf][b] = (uint32_t)(OFF_BQ + ((b * 2 + hi) * TOK + (tk ^ (b * 2 + hi))) * 16);
     }
     auto load_a = [&](const uint8_t* sb, int blk, int f) {
-        af[f] = *reinterpret_cast<const v4i_t*>(sb + la[f] + blk * (2 * AROWS * 16));
-        at[f] = *reinterpret_cast<const v4i_t*>(sb + OFF_AT + la[f] + blk * (2 * AROWS * 16));
+        af[f] = *reinterpret_cast<const v4i_t*>(sb + (hi * AROWS + la[f]) * 16 + blk * (2 * AROWS * 16));
+        at[f] = *reinterpret_cast<const v4s_t*>(sb + OFF_AT + la[f] * 8 + blk * (AROWS * 8));
     };
     auto load_b = [&](const uint8_t* sb, int blk, int tf) {
         bf[tf] = *reinterpret_cast<const v4i_t*>(sb + lb[tf][blk]);
-        bp[tf] = *reinterpret_cast<const v4s_t*>(sb + lp[tf] + blk * (TOK * 8));
+        bp[tf] = *reinterpret_cast<const v4i_t*>(sb + lp[tf] + blk * (2 * TOK * 16));
     };
     auto issue_d = [&](int f, int tf, int buf) { D[buf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[f], bf[tf], cbias, 0, 0, 0); };
     auto issue_s = [&](int f, int tf, int buf) {
-        S[buf] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(v4s_t, v2i_t{at[f][0], at[f][1]}), bp[tf], zero16, 0, 0, 0);
+        S[buf] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(at[f], __builtin_bit_cast(v4s_t, v2i_t{bp[tf][0], bp[tf][1]}), zero16, 0, 0, 0);
     };
     auto issue_n = [&](int f, int tf) {
-        N[0] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(v4s_t, v2i_t{at[f][2], at[f][3]}), bp[tf], zero16, 0, 0, 0);
+        N[0] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(at[f], __builtin_bit_cast(v4s_t, v2i_t{bp[tf][2], bp[tf][3]}), zero16, 0, 0, 0);
     };
     // After the three MFMAs of tile `it` (index inside its stage, whose ring slot is sb_t; sb_f = the slot of the stage after it) have been
     // issued: fragment registers that no later tile of the block reads are refilled with the next block's.
@@ -271,11 +270,14 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
 #if defined(G3_TIMING) && G3_TIMING >= 2
             G3_T0();
 #endif
-            if constexpr (i >= BSTEP) {
-                if constexpr (i - BSTEP < NDMA) dma_one(kf_late, cur, i - BSTEP);
-            } else {
-                if constexpr (i + NLATE < NDMA) dma_one(kf_early, prv, i + NLATE);
-            }
+            g2_static_for<0, PPS>([&](auto pc) {       // window-relative step i' = i - BSTEP behind the barrier, i + NLATE in front of it
+                constexpr int pi = decltype(pc)::value;
+                if constexpr (i >= BSTEP) {
+                    if constexpr (PPS * (i - BSTEP) + pi < NDMA) dma_one(kf_late, cur, PPS * (i - BSTEP) + pi);
+                } else {
+                    if constexpr (PPS * (i + NLATE) + pi < NDMA) dma_one(kf_early, prv, PPS * (i + NLATE) + pi);
+                }
+            });
 #if defined(G3_TIMING) && G3_TIMING >= 2
             G3_T1(tm_dma);
 #endif
