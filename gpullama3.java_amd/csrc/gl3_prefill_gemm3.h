@@ -182,8 +182,8 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
     auto issue_s = [&](int f, int tf, int buf) {
         S[buf] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(at[f], __builtin_bit_cast(v4s_t, v2i_t{bp[tf][0], bp[tf][1]}), zero16, 0, 0, 0);
     };
-    auto issue_n = [&](int f, int tf) {
-        N[0] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(at[f], __builtin_bit_cast(v4s_t, v2i_t{bp[tf][2], bp[tf][3]}), zero16, 0, 0, 0);
+    auto issue_n = [&](int f, int tf, int buf) {
+        N[buf] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(at[f], __builtin_bit_cast(v4s_t, v2i_t{bp[tf][2], bp[tf][3]}), zero16, 0, 0, 0);
     };
     // After the three MFMAs of tile `it` (index inside its stage, whose ring slot is sb_t; sb_f = the slot of the stage after it) have been
     // issued: fragment registers that no later tile of the block reads are refilled with the next block's.
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
     for (int f = 0; f < NF; ++f) load_a(smem, 0, f);
     issue_d(0, 0, 0);
     issue_s(0, 0, 0);
-    issue_n(0, 0);
+    issue_n(0, 0, 0);
     refill(std::integral_constant<int, 0>{}, smem, smem + STAGE);
     int cur = 0;                                       // ring slot of stage kb
 #ifdef G3_TIMING
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
             __builtin_amdgcn_sched_barrier(0);
             fma8(8);
             __builtin_amdgcn_sched_barrier(0);
-            issue_n(fn, tfn);
+            issue_n(fn, tfn, 0);
             if constexpr (i == BSTEP) {
                 // barrier kb: every read of slot cur has been issued (and is waited for here), so the slot is free; everything older than
                 // window kb - 1's pieces has landed, i.e. stage kb + 1 is complete in slot nxt and the weight scales of stage kb + 3 are in r_ws

@@ -10,7 +10,8 @@
     X(6, "v_and_b32 %0, %0, %1") X(7, "v_lshrrev_b32 %0, 4, %0") X(8, "v_add_u32 %0, %0, %1") X(9, "v_cvt_f32_i32 %0, %0") \
     X(10, "v_cvt_f32_ubyte0 %0, %0") X(11, "v_bfe_u32 %0, %0, 4, 4") X(12, "v_cvt_f32_f16 %0, %0") X(13, "v_perm_b32 %0, %0, %1, %1") \
     X(14, "v_cvt_f32_ubyte2 %0, %0") X(15, "v_fma_mix_f32 %0, %0, %1, %1") X(16, "v_mad_u32_u24 %0, %0, %1, %1") X(17, "v_dot4_i32_i8 %0, %0, %1, %0") \
-    X(18, "v_cvt_f32_i32_sdwa %0, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1") X(19, "v_sub_f32 %0, %0, %1")
+    X(18, "v_cvt_f32_i32_sdwa %0, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1") X(19, "v_sub_f32 %0, %0, %1") \
+    X(20, "v_fmac_f32_e32 %0, %1, %1") X(21, "v_fma_f32 %0, %1, %1, %0") X(22, "v_fmac_f32_e64 %0, %1, %1")
 template <int MODE>
 __global__ void k(float* out, long long* cyc, float seed) {
     float a[8];
