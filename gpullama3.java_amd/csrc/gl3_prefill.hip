@@ -22,6 +22,7 @@
 
 using namespace gl3;
 #include "gl3_bd_gemm.h"      // GemmArgs, bdw_gemm_kernel (expects the gl3 names in scope)
+#include "gl3_bdk_gemm.h"     // r6: the same GEMM with K split over producer wavefronts + an ordered chain wavefront
 // gl3_prefill_gemm2.hip (own translation unit, -fno-slp-vectorize): the > 64-token GEMM with the scale products on the matrix pipe (r4)
 void gl3_gemm2_launch(int epi, const GemmArgs& a, int rows, int ntok, int mode, hipStream_t s);
 hipError_t gl3_gemm2_allow_lds();
@@ -1186,6 +1187,11 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
 #undef GL3_GEMM_LDS
     GL3_HIP(gl3_gemm2_allow_lds());                      // pf_gemm2_kernel instantiations (own translation unit)
     GL3_HIP(gl3_gemm3_allow_lds());
+#define GL3_BDK_ATTR(EPI_, P_, DA_, Q_, TS_) GL3_HIP(hipFuncSetAttribute((const void*)bdk_gemm_kernel<EPI_, P_, DA_, Q_, TS_>, hipFuncAttributeMaxDynamicSharedMemorySize, bdk_lds_bytes<EPI_, P_, Q_>()))
+#define GL3_BDK_ATTRS(P_, TS_) GL3_BDK_ATTR(EPI_STORE, P_, 4, false, TS_); GL3_BDK_ATTR(EPI_RESID, P_, 4, false, TS_); GL3_BDK_ATTR(EPI_SWIGLU, P_, 4, false, TS_); GL3_BDK_ATTR(EPI_SWIGLU, (P_ > 2 ? 2 : P_), 4, true, TS_)
+    GL3_BDK_ATTRS(2, BD_TS); GL3_BDK_ATTRS(3, BD_TS); GL3_BDK_ATTRS(4, BD_TS); GL3_BDK_ATTRS(2, BD_TS_MAX); GL3_BDK_ATTRS(3, BD_TS_MAX); GL3_BDK_ATTRS(4, BD_TS_MAX);
+#undef GL3_BDK_ATTRS
+#undef GL3_BDK_ATTR
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1235,6 +1241,23 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
         a.tslots = ts;
         const dim3 grid(bdw_grid((w.rows + 15) / 16, (ntok + 15) / 16));
         const dim3 gridq(bdw_grid((w.rows + 31) / 32, (ntok + 15) / 16));      // quantised output: two strips per workgroup
+        // r6: K split over P producer wavefronts + one chain wavefront per (strip, token tile) (gl3_bdk_gemm.h); GL3_BDK=0: one wavefront per (strip, token tile)
+        // Measured slower than one wavefront per (strip, token tile) on every class (Qwen3-4B B = 32: 3.53 - 4.0 ms per step against 3.14;
+        // profiles/r06_bd32_kslice.md has the per-round stamps), so it is OFF by default and kept as the bit-exact record of that experiment.
+        static const int bdk = getenv("GL3_BDK") ? atoi(getenv("GL3_BDK")) : 0;
+        static const int bdk_p = getenv("GL3_BDK_P") ? atoi(getenv("GL3_BDK_P")) : 3;
+#define GL3_BDK_L(P_, TS_) \
+        do { \
+            if constexpr (EPI == EPI_SWIGLU) { \
+                if (quantised_out) hipLaunchKernelGGL((bdk_gemm_kernel<EPI, (P_ > 2 ? 2 : P_), 4, true, TS_>), gridq, dim3(128 * ((P_ > 2 ? 2 : P_) + 1)), (bdk_lds_bytes<EPI, (P_ > 2 ? 2 : P_), true>()), ctx->stream, a); \
+                else hipLaunchKernelGGL((bdk_gemm_kernel<EPI, P_, 4, false, TS_>), grid, dim3(64 * (P_ + 1)), (bdk_lds_bytes<EPI, P_, false>()), ctx->stream, a); \
+            } else hipLaunchKernelGGL((bdk_gemm_kernel<EPI, P_, 4, false, TS_>), grid, dim3(64 * (P_ + 1)), (bdk_lds_bytes<EPI, P_, false>()), ctx->stream, a); \
+        } while (0)
+#define GL3_BDK(TS_) do { if (bdk_p == 2) GL3_BDK_L(2, TS_); else if (bdk_p == 4) GL3_BDK_L(4, TS_); else GL3_BDK_L(3, TS_); } while (0)
+        static const int bdk_gu = getenv("GL3_BDK_GU") ? atoi(getenv("GL3_BDK_GU")) : 1;      // 0: the gate + up launch stays on bdw_gemm_kernel
+        if (bdk && (EPI != EPI_SWIGLU || bdk_gu)) { if (ts == BD_TS) GL3_BDK(BD_TS); else GL3_BDK(BD_TS_MAX); return; }
+#undef GL3_BDK
+#undef GL3_BDK_L
 #define GL3_BDW(TS_) \
         do { \
             if constexpr (EPI == EPI_SWIGLU) { \
