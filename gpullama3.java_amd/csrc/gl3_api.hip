@@ -86,6 +86,7 @@ static void launch_matvec(gl3_ctx* ctx, int pro, int epi, const Q8Mat& w, const 
         if (w.vl) {                   // Vector-API order (8 accumulator lanes per row): lane = (row, accumulator), HBM-bound
             VlArgs v{};
             v.w = w.w; v.w2 = w2 ? w2->w : nullptr; v.rows = w.rows; v.k = w.k; v.x = x; v.out = out; v.resid_in = resid_in; v.out_scale = out_scale;
+            v.tp = tp;      // folded gathers (gate/up -> hb, down -> x): producer side only, the consumers get wait launches
             const dim3 vg(((w.rows + 7) / 8 + VL_WAVES - 1) / VL_WAVES), vb(64 * VL_WAVES);
             const size_t vs = vl_smem_bytes(w.k);
             if (fuse_rms) {
@@ -300,11 +301,18 @@ static int32_t tp_fold_setup(gl3_ctx* ctx) {
     ctx->tp_fold = 0;
     const int mode = getenv("GL3_TP_FOLD") ? atoi(getenv("GL3_TP_FOLD")) : 1;
     if (!ctx->use_rccl || ctx->transport != GL3_TP_P2P || d.tp_size < 2 || mode <= 0) return GL3_OK;
-    if (ctx->emb.fmt != GL3_TYPE_Q8_0 || !ctx->wo_replicated || d.arch == GL3_ARCH_QWEN2MOE || env_flag("GL3_TP_DEBUG", false)) return GL3_OK;
+    // Q8_0 int8 path, and (r6) the vector-order types F16 / Q4_0 / Q8_0-f32act (matvec_vl_kernel / matvec_vlq_kernel push and publish; their consumers
+    // always wait in a wait launch: mode 1).  The scalar-order kernels (GL3_FLAG_SCALAR_DOT) keep the gather kernels.
+    const bool vl_types = ctx->emb.vl;
+    if ((ctx->emb.fmt != GL3_TYPE_Q8_0 && !vl_types) || !ctx->wo_replicated || d.arch == GL3_ARCH_QWEN2MOE || env_flag("GL3_TP_DEBUG", false)) return GL3_OK;
+    // the producers publish without a per-wavefront release fence: that is only sound on an UNCACHED arena (advisor finding): any other arena kind
+    // (GL3_TP_ARENA=cached | finegrained | unpooled experiments) keeps the gather kernels
+    if (ctx->arena.kind != 0) return GL3_OK;
     const int L = d.n_layers, tp = d.tp_size, me = d.tp_rank;
     // which consumers wait in their own prologue (the others get a wait launch in front): GL3_TP_FOLD=2 all, GL3_TP_FOLD_MASK picks
     int mask = mode >= 2 ? (TF_WO | TF_DOWN | TF_QKV | TF_LOGITS | TF_EMBED) : 0;
     if (getenv("GL3_TP_FOLD_MASK")) mask = atoi(getenv("GL3_TP_FOLD_MASK"));
+    if (vl_types) mask = 0;
     uint8_t* own = ctx->arena.base;
     static const unsigned limit = getenv("GL3_TP_SPIN_LIMIT") ? (unsigned)atol(getenv("GL3_TP_SPIN_LIMIT")) : 20000000u;
     uint32_t* step = reinterpret_cast<uint32_t*>(own + GL3_ARENA_STEP);
@@ -346,6 +354,7 @@ static int32_t tp_fold_setup(gl3_ctx* ctx) {
     return GL3_OK;
 }
 static const TpRec* tp_rec(const gl3_ctx* ctx, int l, int which) {
+    if (ctx->tp_quiet) return nullptr;      // gl3_profile_kernel: launches outside the step protocol must not push into the peers' arenas
     return ctx->tp_fold ? reinterpret_cast<const TpRec*>(ctx->tp_recs) + (size_t)l * TR_PER_LAYER + which : nullptr;
 }
 // mode 1: the consumer side of a folded gather as its own one-wavefront launch
@@ -429,13 +438,14 @@ static int32_t enqueue_decode(gl3_ctx* ctx, bool want_logits, gl3_kernel_times* 
 
     pr.begin(GL3_K_OTHER, (uint64_t)d.dim / 32 * 34);
     const int fold = ctx->tp_fold, fmask = fold ? ctx->tp_fold_mask : 0, L_ = d.n_layers;
+    uint32_t* vl_step = fold ? reinterpret_cast<uint32_t*>(ctx->arena.base + GL3_ARENA_STEP) : (uint32_t*)nullptr;
     if (ctx->emb.fmt == GL3_TYPE_Q8_0)
         hipLaunchKernelGGL(embed_q8t_kernel, dim3(1), dim3(256), 0, s, ctx->emb.w, ctx->emb.ng, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale,
                            (fmask & TF_EMBED) ? tp_rec(ctx, L_, 0) : (const TpRec*)nullptr,
                            fold ? reinterpret_cast<uint32_t*>(ctx->arena.base + GL3_ARENA_STEP) : (uint32_t*)nullptr);
-    else if (ctx->emb.vl && ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_vl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
-    else if (ctx->emb.vl && ctx->emb.fmt == GL3_FMT_Q8V) hipLaunchKernelGGL((embed_vl_kernel<WT_Q8_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
-    else if (ctx->emb.vl) hipLaunchKernelGGL((embed_vl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
+    else if (ctx->emb.vl && ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_vl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale, vl_step);
+    else if (ctx->emb.vl && ctx->emb.fmt == GL3_FMT_Q8V) hipLaunchKernelGGL((embed_vl_kernel<WT_Q8_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale, vl_step);
+    else if (ctx->emb.vl) hipLaunchKernelGGL((embed_vl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale, vl_step);
     else if (ctx->emb.fmt == GL3_TYPE_F16) hipLaunchKernelGGL((embed_rl_kernel<WT_F16>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
     else hipLaunchKernelGGL((embed_rl_kernel<WT_Q4_0>), dim3(1), dim3(256), 0, s, ctx->emb.w, d.dim, ctx->dyn_cur, ctx->x, ctx->emb_scale);
     pr.end();
@@ -1186,6 +1196,8 @@ int32_t gl3_profile_kernel(gl3_ctx* ctx, int32_t klass, int32_t iters, double* o
         }
         return nl;
     };
+    struct Quiet { gl3_ctx* c; ~Quiet() { c->tp_quiet = false; } } quiet{ctx};
+    ctx->tp_quiet = true;                               // these launches are outside the step protocol (advisor finding)
     sweep();                                            // warm-up
     GL3_HIP(hipEventRecord(e0, ctx->stream));
     long n = 0;

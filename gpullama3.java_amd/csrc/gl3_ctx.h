@@ -115,9 +115,11 @@ enum { GL3_TP_NONE = 0, GL3_TP_RCCL = 1, GL3_TP_P2P = 2 };
 //           u32 seq (gathers completed by this rank), u32 arrive (workgroup ticket of the running gather kernel)
 struct gl3_tp_arena {
     uint8_t* base = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0;                             // bytes this plan uses
+    size_t cap = 0;                               // capacity of the allocation (>= bytes when it came from the pool)
     size_t off[8] = {};                           // byte offset of buffer GB_*; 0 = not allocated
     int pf_logits_rows = 0;                       // capacity of the batched-decode logits buffer (rows)
+    int kind = 0;                                 // 0 uncached (default), 1 cached, 2 fine-grained, 3 uncached + hipFree (GL3_TP_ARENA experiments)
     bool pooled = false;                          // base goes back to the process-wide arena pool, not to hipFree (gl3_tp.hip)
 };
 constexpr size_t GL3_ARENA_HDR = 1024, GL3_ARENA_SEQ = 64, GL3_ARENA_ARRIVE = 68;      // bytes 256..511: checksums of GL3_TP_DEBUG (gl3_tp.hip)
@@ -195,6 +197,7 @@ struct gl3_ctx {
     uint8_t* peer_base[GL3_MAX_TP] = {};          // arena of every rank as mapped into this process (peer_base[tp_rank] = arena.base)
     void* ipc_opened[GL3_MAX_TP] = {};            // mappings to close (hipIpcCloseMemHandle)
     int tp_fold_mask = 0;                         // TF_* consumers that wait in their own prologue
+    bool tp_quiet = false;                        // gl3_profile_kernel: launch without the folded hand-overs (no pushes into the peers' arenas)
     int tp_fold = 0;                              // decode gathers folded into producers / consumers (gl3_api.hip tp_fold_setup): 0, 1, 2
     void* tp_recs = nullptr;                      // device TpRec[n_layers * 8 + 2]
     uint32_t* h_tp_err = nullptr;                 // pinned, device-visible: set by a gather kernel whose peers never arrived

@@ -65,26 +65,58 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 namespace {
 struct ArenaPool {
     std::mutex mu;
-    std::vector<std::tuple<int, size_t, uint8_t*>> free_list;
+    std::vector<std::tuple<int, size_t, uint8_t*>> free_list;      // (device, capacity in bytes, base)
 };
 ArenaPool& arena_pool() { static ArenaPool* p = new ArenaPool(); return *p; }      // never destroyed: outlives every plan
-uint8_t* arena_pool_take(int device, size_t bytes) {
+// Best fit: the smallest pooled arena of the device that holds `bytes` (r5 matched the exact size only, so a server that re-created plans with a
+// different ctx / max_batch / vocab kept one dead arena per shape for ever — advisor finding).  With >= matching the shapes converge: the pool never
+// holds more arenas than were alive at the same time.  `cap` returns the arena's real capacity, which is what goes back into the pool.
+uint8_t* arena_pool_take(int device, size_t bytes, size_t* cap) {
     ArenaPool& P = arena_pool();
     std::lock_guard<std::mutex> lk(P.mu);
+    long best = -1;
     for (size_t i = 0; i < P.free_list.size(); ++i)
-        if (std::get<0>(P.free_list[i]) == device && std::get<1>(P.free_list[i]) == bytes) {
-            uint8_t* b = std::get<2>(P.free_list[i]);
-            P.free_list.erase(P.free_list.begin() + (long)i);
-            return b;
-        }
-    return nullptr;
+        if (std::get<0>(P.free_list[i]) == device && std::get<1>(P.free_list[i]) >= bytes &&
+            (best < 0 || std::get<1>(P.free_list[i]) < std::get<1>(P.free_list[(size_t)best]))) best = (long)i;
+    if (best < 0) return nullptr;
+    uint8_t* b = std::get<2>(P.free_list[(size_t)best]);
+    *cap = std::get<1>(P.free_list[(size_t)best]);
+    P.free_list.erase(P.free_list.begin() + best);
+    return b;
 }
-void arena_pool_give(int device, size_t bytes, uint8_t* base) {
+void arena_pool_give(int device, size_t cap, uint8_t* base) {
     ArenaPool& P = arena_pool();
     std::lock_guard<std::mutex> lk(P.mu);
-    P.free_list.emplace_back(device, bytes, base);
+    P.free_list.emplace_back(device, cap, base);
 }
 }  // namespace
+
+// Pool inspection / release for long-lived hosts (include/gpullama3_hip.h).  gl3_tp_pool_trim hands the pooled arenas of a device (-1: all) back to
+// the allocator — the one call that can re-create the recycling fault described above, so it is for a quiescent process (no plan alive on that
+// device that was created after an arena was freed, nothing else allocating): servers call it between model reloads, tests never.
+extern "C" GL3_API int32_t gl3_tp_pool_stats(int32_t device, uint64_t* arenas, uint64_t* bytes) {
+    ArenaPool& P = arena_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    uint64_t n = 0, b = 0;
+    for (auto& e : P.free_list)
+        if (device < 0 || std::get<0>(e) == device) { ++n; b += std::get<1>(e); }
+    if (arenas) *arenas = n;
+    if (bytes) *bytes = b;
+    return GL3_OK;
+}
+extern "C" GL3_API int32_t gl3_tp_pool_trim(int32_t device) {
+    ArenaPool& P = arena_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return GL3_E_HIP;
+    for (size_t i = 0; i < P.free_list.size();) {
+        if (device >= 0 && std::get<0>(P.free_list[i]) != device) { ++i; continue; }
+        if (hipSetDevice(std::get<0>(P.free_list[i])) != hipSuccess || hipFree(std::get<2>(P.free_list[i])) != hipSuccess) { hipSetDevice(cur); return GL3_E_HIP; }
+        P.free_list.erase(P.free_list.begin() + (long)i);
+    }
+    hipSetDevice(cur);
+    return GL3_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ arena
 int32_t gl3_tp_arena_alloc(gl3_ctx* ctx) {
@@ -107,8 +139,10 @@ int32_t gl3_tp_arena_alloc(gl3_ctx* ctx) {
     // the recycling fault described at the pool above).
     const char* mode = getenv("GL3_TP_ARENA");
     const int kind = (mode && !strcmp(mode, "cached")) ? 1 : (mode && !strcmp(mode, "finegrained")) ? 2 : (mode && !strcmp(mode, "unpooled")) ? 3 : 0;
-    A.base = kind == 0 ? arena_pool_take(d.device, A.bytes) : nullptr;
+    A.cap = A.bytes;
+    A.base = kind == 0 ? arena_pool_take(d.device, A.bytes, &A.cap) : nullptr;
     A.pooled = kind == 0;
+    A.kind = kind;
     if (!A.base) {
         hipError_t e = kind == 1 ? hipMalloc((void**)&A.base, A.bytes)
                        : kind == 2 ? hipExtMallocWithFlags((void**)&A.base, A.bytes, hipDeviceMallocFinegrained)
@@ -126,7 +160,7 @@ void gl3_tp_arena_free(gl3_ctx* ctx) {
     for (int p = 0; p < GL3_MAX_TP; ++p)
         if (ctx->ipc_opened[p]) { hipIpcCloseMemHandle(ctx->ipc_opened[p]); ctx->ipc_opened[p] = nullptr; }
     if (ctx->arena.base) {
-        if (ctx->arena.pooled) arena_pool_give(ctx->d.device, ctx->arena.bytes, ctx->arena.base);
+        if (ctx->arena.pooled) arena_pool_give(ctx->d.device, ctx->arena.cap, ctx->arena.base);
         else hipFree(ctx->arena.base);
     }
     ctx->arena.base = nullptr;

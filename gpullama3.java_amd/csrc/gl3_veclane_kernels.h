@@ -74,7 +74,12 @@ static __global__ __launch_bounds__(256) void repack_vl_kernel(const uint8_t* __
 // token_embedding_table.copyTo -> getFloat per element (InferenceCore.java:61): SCALAR semantics (IEEE f16 -> f32)
 template <int WT>
 static __global__ __launch_bounds__(256) void embed_vl_kernel(const uint8_t* __restrict__ emb, int dim, const int* __restrict__ dyn,
-                                                              float* __restrict__ x, float emb_scale) {
+                                                              float* __restrict__ x, float emb_scale, uint32_t* step = nullptr) {
+    if (step) {                              // folded gathers: the kernel opens decode step *step + 1 of the plan (as embed_q8t_kernel; the wait for the
+        const uint32_t s0 = *step;           // previous step's last pushes into x is the wait launch behind the last down projection)
+        __syncthreads();
+        if (threadIdx.x == 0) *step = s0 + 1;
+    }
     const int token = dyn[0], g = token >> 3, rr = token & 7;
     const uint8_t* gb = emb + (size_t)g * vl_group_bytes(WT, dim);
     for (int i = threadIdx.x; i < dim; i += 256) {
@@ -103,6 +108,7 @@ struct VlArgs {
     float* out; const float* resid_in;      // EPI_RESID: out[i] = resid_in[i] + result
     float out_scale;                        // result *= out_scale first (Granite residual / logit scaling; 1 otherwise)
     const float* norm_w; float eps;         // RMS variant: x is the raw residual stream, normalised in the kernel's prologue
+    const TpRec* tp;                        // tensor parallel, folded gathers (r6): results also go to the peers' arenas, the last wavefront publishes (NULL: no)
 };
 
 constexpr int VL_WAVES = 2;                 // 16 rows per workgroup: 4096-row matrices still give one workgroup per CU
@@ -377,13 +383,17 @@ static __global__ __launch_bounds__(64 * VW, WT == WT_F16 ? 1 : 2) void matvec_v
     }
     const int row = g * 8 + rr;
     if (l == 0 && row < a.rows) {
-        if (EPI == EPI_STORE) a.out[row] = res[0] * a.out_scale;
-        if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + res[0] * a.out_scale : res[0] * a.out_scale;
+        float o = 0.f;
+        if (EPI == EPI_STORE) o = res[0] * a.out_scale;
+        if (EPI == EPI_RESID) o = a.resid_in ? a.resid_in[row] + res[0] * a.out_scale : res[0] * a.out_scale;
         if (EPI == EPI_SWIGLU) {                               // InferenceCore.java:155-158, exp in double
             const float gte = res[0] / (float)(1.0 + exp(-(double)res[0]));
-            a.out[row] = gte * res[NM - 1];
+            o = gte * res[NM - 1];
         }
+        a.out[row] = o;
+        if (a.tp) tp_push_store(a.tp->p, a.out + row, o);
     }
+    if (a.tp && a.tp->p.npeers) tp_publish(a.tp->p, ngroups);      // every live wavefront of the launch reaches its epilogue
 }
 
 // ---- Q4_0 / Q8_0-with-f32-activation, K split over the wavefronts of a workgroup.
@@ -583,13 +593,17 @@ static __global__ __launch_bounds__(64 * MAXW) void matvec_vlq_kernel(const VlAr
     }
     const int row = g * 8 + rr;
     if (l == 0 && row < a.rows) {
-        if (EPI == EPI_STORE) a.out[row] = res[0] * a.out_scale;
-        if (EPI == EPI_RESID) a.out[row] = a.resid_in ? a.resid_in[row] + res[0] * a.out_scale : res[0] * a.out_scale;
+        float o = 0.f;
+        if (EPI == EPI_STORE) o = res[0] * a.out_scale;
+        if (EPI == EPI_RESID) o = a.resid_in ? a.resid_in[row] + res[0] * a.out_scale : res[0] * a.out_scale;
         if (EPI == EPI_SWIGLU) {                               // InferenceCore.java:155-158, exp in double
             const float gte = res[0] / (float)(1.0 + exp(-(double)res[0]));
-            a.out[row] = gte * res[NM - 1];
+            o = gte * res[NM - 1];
         }
+        a.out[row] = o;
+        if (a.tp) tp_push_store(a.tp->p, a.out + row, o);
     }
+    if (a.tp && a.tp->p.npeers) tp_publish(a.tp->p, gridDim.x);      // wavefront 0 of every workgroup
 }
 
 }  // namespace gl3

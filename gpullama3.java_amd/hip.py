@@ -65,6 +65,8 @@ _SIGS = {  # symbol -> (restype, argtypes): exactly the declarations of include/
     "gl3_get_sample_probs": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "gl3_get_topp_counts": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gl3_tp_fold_mode": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gl3_tp_pool_stats": (C.c_int32, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "gl3_tp_pool_trim": (C.c_int32, [C.c_int32]),
     "gl3_pin_host_buffer": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "gl3_unpin_host_buffer": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "gl3_forward_prefill": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),

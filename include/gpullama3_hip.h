@@ -209,6 +209,13 @@ GL3_API int32_t gl3_tp_attach_local(gl3_ctx* ctx, gl3_local_group* g);
  * write their results into the peers' arenas themselves.  *consumer_mask: bit set = that consumer waits for the peers in its own
  * prologue (1 wo, 2 down, 4 qkv, 8 logits, 16 embedding; GL3_TP_FOLD=2 sets all), clear = a one-wavefront wait launch precedes it. */
 GL3_API int32_t gl3_tp_fold_mode(gl3_ctx* ctx, int32_t* mode, int32_t* consumer_mask);
+/* The per-rank arena is UNCACHED device memory and is never returned to the allocator when a plan is destroyed: it waits in a process-wide pool and
+ * is re-used by the next tensor-parallel plan of the device that fits into it (best fit, capacity >= request), so a process retains at most as many
+ * arenas as it had tensor-parallel plans alive at the same time.  gl3_tp_pool_stats reports what is retained (device -1: all devices);
+ * gl3_tp_pool_trim releases it — only for a quiescent process (model reload in a server): freed uncached pages that come back from a later
+ * hipMalloc under the cached policy were the root cause of stale activation rows (tensor parallelism). */
+GL3_API int32_t gl3_tp_pool_stats(int32_t device, uint64_t* arenas, uint64_t* bytes);
+GL3_API int32_t gl3_tp_pool_trim(int32_t device);
 
 /* forceCopyInReadOnlyData(): checks that every tensor arrived, ties wcls to token_embd when
  * GL3_T_OUTPUT was not uploaded (AbstractModelLoader.java:194), captures the decode hipGraph. */

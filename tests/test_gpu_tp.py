@@ -52,17 +52,18 @@ def test_row_split_ranks_are_bit_identical_to_the_oracle(pkg, orc, planmod, cfg,
 
 
 def test_q8_decode_gathers_are_folded_into_the_producers(pkg, orc, planmod):
-    """The default hand-over of the Q8_0 int8 decode step: the attention / gate-up / down kernels write their results into the peers'
-    arenas (mode 1), the F16 / Q4_0 plans keep the gather launches (mode 0).  (Bit-exactness of both: the row-split test above.)"""
+    """The default hand-over of the decode step: the attention / gate-up / down kernels write their results into the peers' arenas (mode 1) — the
+    Q8_0 int8 path and, since r6, the vector-order F16 / Q4_0 plans (BASELINE configs[3] is Q4_0 TP = 8); the scalar-order kernels
+    (GL3_FLAG_SCALAR_DOT) keep the gather launches (mode 0).  (Bit-exactness of all of them: the row-split test above.)"""
     plan_mod, hip = planmod
-    for wtype, want in ((8, 1), (2, 0)):
+    for wtype, flags, want in ((8, 0, 1), (2, 0, 1), (1, 0, 1), (2, hip.FLAG_SCALAR_DOT, 0)):
         m = pkg.synth.make_numpy(pkg.synth.CONFIGS["tiny-llama"], wtype=wtype, seed=3)
         grp = plan_mod.make_local_group(2)
         modes, err = [None, None], [None, None]
 
         def rank_main(r):
             try:
-                plan = plan_mod.HipMasterPlan(m, tp_rank=r, tp_size=2, local_group=grp)
+                plan = plan_mod.HipMasterPlan(m, tp_rank=r, tp_size=2, local_group=grp, flags=flags)
                 modes[r] = plan.tp_fold_mode()
                 plan.forward_decode(1, 0)
                 plan.freeTornadoExecutionPlan()
@@ -72,7 +73,7 @@ def test_q8_decode_gathers_are_folded_into_the_producers(pkg, orc, planmod):
         [t.start() for t in th]; [t.join(timeout=300) for t in th]
         hip.lib().gl3_local_group_destroy(grp)
         assert err == [None, None], err
-        assert modes == [(want, 0), (want, 0)], (wtype, modes)
+        assert modes == [(want, 0), (want, 0)], (wtype, flags, modes)
 
 
 @pytest.mark.parametrize("cfg,tp,mask", [("mid-llama", 4, None), ("mid-qwen3", 8, None), ("mid-llama", 2, "5")])
