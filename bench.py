@@ -416,6 +416,7 @@ def main():
                                    "inside the timed region); pp%d -b %d reported beside it" %
                                    (cfg.name, WT, args.n_gen, args.n_gen, args.n_prompt, args.batch),
                        "parallelism": ("tp%d (row split, %s all-gathers)" % (world, "peer-write xGMI" if transport != "rccl" else "RCCL")) if world > 1 else "single GPU",
+                       "ranks": world, "transport": (transport if world > 1 else None), "fold_mode": (list(plan.tp_fold_mode()) if world > 1 else None),
                        "ctx": cfg.ctx, "tokens": "java.util.Random(42)"},
             "tg_tok_s_mean": round(float(mean), 3), "tg_tok_s_stddev": round(sd, 3),
             "pp": pp, "pp_rows": pp_rows,

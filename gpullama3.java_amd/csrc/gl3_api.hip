@@ -625,8 +625,9 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     }
     if (d.weight_type == GL3_TYPE_Q4_0 && !(d.flags & GL3_FLAG_SCALAR_DOT) && (d.dim % 256 || d.hidden % 256 || (d.n_heads * d.head_size) % 256))
         return bail(GL3_E_UNSUPPORTED, "Q4_0 in Vector-API order needs inner dimensions that are multiples of 256 (or GL3_FLAG_SCALAR_DOT)");
-    if (d.weight_type != GL3_TYPE_Q8_0 && d.tp_size > 1 && (d.vocab / d.tp_size) % 64)
-        return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0 tensor parallel needs vocab/tp_size to be a multiple of 64");
+    // a rank's vocabulary slice is whole weight groups: 8 rows in the vector order (128256 / 8 = 16032 = 2004 groups: BASELINE configs[3]), 64 in the scalar order
+    if (d.weight_type != GL3_TYPE_Q8_0 && d.tp_size > 1 && (d.vocab / d.tp_size) % ((d.flags & GL3_FLAG_SCALAR_DOT) ? 64 : 8))
+        return bail(GL3_E_UNSUPPORTED, "F16 / Q4_0 tensor parallel needs vocab/tp_size to be a multiple of 8 (64 with GL3_FLAG_SCALAR_DOT)");
     if (d.dim <= 0 || d.dim % 32 || d.hidden % 32 || d.n_layers <= 0 || d.n_heads <= 0 || d.n_kv_heads <= 0 ||
         d.n_heads % d.n_kv_heads || d.vocab <= 0 || d.ctx <= 0)
         return bail(GL3_E_ARG, "bad model dimensions");

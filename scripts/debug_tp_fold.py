@@ -1,5 +1,6 @@
-"""Debug helper: tensor-parallel decode of the Q8_0 int8 path with folded gathers, ranks as threads of one process.
-    GL3_TP_FOLD=2 [GL3_TP_FOLD_MASK=m] python scripts/debug_tp_fold.py mid-llama 4"""
+"""Tensor-parallel decode with folded gathers, ranks as threads of ONE fresh process, every rank's logits compared with the CPU oracle bit for bit
+(used by tests/test_gpu_tp.py: a fresh process has one hardware queue per rank stream, see tests/conftest.py).
+    GL3_TP_FOLD=2 [GL3_TP_FOLD_MASK=m] python scripts/debug_tp_fold.py mid-llama 4 [tokens] [ggml type: 8 Q8_0 | 2 Q4_0 | 1 F16]"""
 import sys, os, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
@@ -12,8 +13,9 @@ from oracle import oracle_c as orc
 orc.build()
 cfg, tp = sys.argv[1], int(sys.argv[2])
 ntok = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=8, seed=17)
-o = orc.COracle(m, vector_bits=0)
+wtype = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=17)
+o = orc.COracle(m, vector_bits=0 if wtype == 8 else 256)
 toks = pkg.javarand.bench_tokens(m.cfg.vocab, ntok)
 ref = [o.forward(t, p) for p, t in enumerate(toks)]
 grp = plan_mod.make_local_group(tp)

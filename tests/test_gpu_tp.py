@@ -21,8 +21,18 @@ def planmod():
 
 @pytest.mark.parametrize("cfg,tp,wtype", [("mid-llama", 2, 8), ("mid-llama", 4, 8), ("mid-qwen3", 2, 8), ("tiny-llama-tied", 2, 8),
                                           ("mid-llama", 2, 2), ("mid-llama", 4, 1), ("mid-qwen3", 2, 1), ("mid-qwen2", 2, 8),
-                                          ("mid-llama", 8, 8), ("mid-llama", 8, 2), ("mid-qwen3", 8, 8), ("mid-granite", 2, 8), ("mid-phi3", 2, 8), ("mid-phi3", 4, 2)])   # BASELINE configs[3]: Q4_0 row split, tp = 8 (one kv head per rank)
+                                          ("mid-llama", 8, 8), ("mid-llama", 8, 2), ("mid-qwen3", 8, 8), ("mid-granite", 2, 8), ("mid-phi3", 2, 8), ("mid-phi3", 4, 2),
+                                          ("tiny-llama-tied", 4, 2)])    # vocab / tp = 160: whole 8-row groups, not a multiple of 64 (Llama-3's 128256 / 8 = 16032)   # BASELINE configs[3]: Q4_0 row split, tp = 8 (one kv head per rank)
 def test_row_split_ranks_are_bit_identical_to_the_oracle(pkg, orc, planmod, cfg, tp, wtype):
+    if tp >= 4:
+        # four or more polling ranks need one hardware queue per rank stream; late in a long-lived process the runtime multiplexes streams onto shared
+        # queues (tests/conftest.py: seen as a gather time-out in the 10th group of a process), so these groups run in a fresh process each
+        import os, subprocess, sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "debug_tp_fold.py"), cfg, str(tp), "2", str(wtype)], cwd=root,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
     plan_mod, hip = planmod
     m = pkg.synth.make_numpy(pkg.synth.CONFIGS[cfg], wtype=wtype, seed=17)
     o = orc.COracle(m, vector_bits=0 if wtype == 8 else 256)         # F16 / Q4_0: the plan's default Vector-API dot order
@@ -76,16 +86,17 @@ def test_q8_decode_gathers_are_folded_into_the_producers(pkg, orc, planmod):
         assert modes == [(want, 0), (want, 0)], (wtype, flags, modes)
 
 
-@pytest.mark.parametrize("cfg,tp,mask", [("mid-llama", 4, None), ("mid-qwen3", 8, None), ("mid-llama", 2, "5")])
-def test_gathers_folded_into_the_consumer_prologues(cfg, tp, mask):
+@pytest.mark.parametrize("cfg,tp,mask,wgs", [("mid-llama", 4, None, 16), ("mid-qwen3", 8, None, 16), ("mid-llama", 2, "5", 16), ("mid-llama", 2, None, 256)])
+def test_gathers_folded_into_the_consumer_prologues(cfg, tp, mask, wgs):
     """GL3_TP_FOLD=2: no launch between producer and consumer — wo / down / qkv / logits / the embedding wait for the peers in their own
     prologue.  A consumer that polls holds its compute units, so ranks that SHARE one GPU (this test) must leave room for each other's
     producers: GL3_WGS=16 caps every matvec at 16 workgroups (with full grids four ranks' wo launches fill the chip and the laggard's
     attention kernel never starts — seen as a gather time-out, not a wrong result).  Separate process: the switches are read at plan
-    creation / first launch.  The third case mixes prologue waits (wo, qkv) with wait launches (GL3_TP_FOLD_MASK)."""
+    creation / first launch.  The third case mixes prologue waits (wo, qkv) with wait launches (GL3_TP_FOLD_MASK); the fourth runs two ranks at the
+    production launch geometry of one workgroup per CU and rank (GL3_WGS=256: both ranks' polling consumers and producers fit the chip together)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GL3_TP_FOLD="2", GL3_WGS="16")
+    env = dict(os.environ, GL3_TP_FOLD="2", GL3_WGS=str(wgs))
     if mask: env["GL3_TP_FOLD_MASK"] = mask
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "debug_tp_fold.py"), cfg, str(tp), "3"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
