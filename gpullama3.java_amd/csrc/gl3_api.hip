@@ -409,6 +409,14 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
         attn_head_dispatch(d.head_size, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ctx->heads_l), dim3(256), attn_head_smem(d.head_size), ctx->stream, aa); });
         return;
     }
+    // r6: positions AF_MAXN .. 767 in one launch (attn_mid_kernel); GL3_ATTN_FUSED_MID=0: the r4 pair
+    static const bool fused_mid = env_flag("GL3_ATTN_FUSED_MID", true);
+    if (which == 0 && amode == ATT_MID && fused_mid && kvmul <= 4 && ctx->attn_mid <= AM_MAXN && (d.head_size == 128 || d.head_size == 64)) {
+        const dim3 mg(d.head_size / 16, ctx->kv_heads_l);
+        if (d.head_size == 128) hipLaunchKernelGGL(attn_mid_kernel<128>, mg, dim3(256), attn_mid_smem<128>(), ctx->stream, aa);
+        else hipLaunchKernelGGL(attn_mid_kernel<64>, mg, dim3(256), attn_mid_smem<64>(), ctx->stream, aa);
+        return;
+    }
     // GL3_ATTN_SCORES_LOOP=0: the one-tile-per-workgroup scores kernel at every depth (A/B switch)
     static const bool scores_loop = env_flag("GL3_ATTN_SCORES_LOOP", true);
     if (which != 2 && amode == ATT_LONG && scores_loop && kvmul <= 4 && (d.head_size == 128 || d.head_size == 64)) {
@@ -737,6 +745,8 @@ int32_t gl3_create(const gl3_model_desc* desc, gl3_ctx** out) {
     TRYHIP(hipFuncSetAttribute((const void*)attn_scores_loop_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     TRYHIP(hipFuncSetAttribute((const void*)attn_scores_loop_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     TRYHIP(hipFuncSetAttribute((const void*)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    TRYHIP(hipFuncSetAttribute((const void*)attn_mid_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_mid_smem<128>()));
+    TRYHIP(hipFuncSetAttribute((const void*)attn_mid_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_mid_smem<64>()));
     TRYHIP(hipFuncSetAttribute((const void*)attn_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_sum_smem()));
     TRYHIP(hipFuncSetAttribute((const void*)attn_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_pv_smem()));
     // softmax rows longer than the LDS window (16384 positions; GL3_ATTN_WINDOW, a multiple of 1024, shrinks it for tests) run in

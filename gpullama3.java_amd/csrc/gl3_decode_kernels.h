@@ -1257,6 +1257,167 @@ static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnA
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Decode attention for positions AF_MAXN .. AM_MAXN - 1 in ONE launch (r6; head_size 64 / 128, kvMul <= 4).  The r4 pair (attn_scores_kernel +
+// attn_softmax_pv_kernel) spent 18.8 us per 8B layer at depth 256 and 23.3 us at 512 against 0.3 - 0.6 us of KV read: two launches, a round trip of
+// the scores through memory, a softmax recomputed by each of a head's hs / 16 column workgroups with its strict sum on ONE wavefront, and three of the
+// four wavefronts idle during the weighted V sum.  Here a workgroup owns (kv head, 16 output columns) for ALL query heads of the group, wavefront =
+// query head:
+//   * the group's K rows stream through LDS in tiles of AM_TT timesteps (registers one tile ahead), every wavefront runs the strict q . k chains
+//     of its head for two timesteps per lane; the scores never leave LDS;
+//   * the V slab [n][16] is in flight from the first instruction and lands in LDS behind the scores;
+//   * max, (float)exp((double)(s - max)), the strictly sequential sum (LDS reads pinned three groups ahead) and the division run per wavefront, the
+//     four heads side by side; a_t * v rounded on the VALU, added in order on the matrix pipe (16x16x4, B = 1.0) — four chains side by side.
+//   * RoPE (+ Qwen3 per-head RMSNorm, Qwen2 bias) of q and of this position's key in every workgroup (the key row is a score operand); the KV write by
+//     the workgroups of column slab 0.
+// Same arithmetic and order as the pair: positions 128 .. 767 of every decode parity test compare np.array_equal.
+constexpr int AM_TT = 128;       // timesteps per K tile
+constexpr int AM_MAXN = 768;     // rows of the score / V slab buffers: positions < AM_MAXN
+template <int HS>
+__host__ __device__ constexpr size_t attn_mid_smem() { return ((size_t)4 * HS + HS + HS + 4 * AM_MAXN + (size_t)AM_MAXN * 16 + (size_t)AM_TT * (HS + 4)) * 4; }
+
+template <int HS>
+static __global__ __launch_bounds__(256, 1) void attn_mid_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float am_sm[];
+    constexpr int PITCH = HS + 4, HALF = HS / 2, Q4 = HS / 4;
+    constexpr int KREG = AM_TT * Q4 / 256;             // float4s of a K tile per thread
+    constexpr int SU = AM_MAXN * 4 / 256;              // float4s of the V slab per thread: thread = (row t >> 2 + 64 u, column quad t & 3)
+    float* q_s = am_sm;                                // [4][HS]
+    float* kcur = q_s + 4 * HS;                        // [HS] this position's key
+    float* cr_s = kcur + HS;
+    float* ci_s = cr_s + HALF;
+    float* e_s = ci_s + HALF;                          // [4][AM_MAXN] scores, then softmax weights
+    float* vbuf = e_s + 4 * AM_MAXN;                   // [AM_MAXN][16]
+    float* kt = vbuf + AM_MAXN * 16;                   // [AM_TT][PITCH]
+    const int kvmul = a.n_heads / a.n_kv_heads;
+    const int t = threadIdx.x, lane = t & 63, hq = t >> 6;
+    const int j0 = blockIdx.x * 16, kvh = blockIdx.y;
+    const int pos = a.dyn[1], n = pos + 1;
+    const bool writer = blockIdx.x == 0;               // this workgroup writes the position's K / V rows into the cache
+    // ---- V slab rows 0 .. pos - 1 from the cache (row pos comes from the raw qkv below)
+    float4 sreg[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+        sreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (64 * u < pos) {                            // uniform condition + clamped row ("conditional loads")
+            const int row = min((t >> 2) + 64 * u, pos - 1);
+            sreg[u] = *reinterpret_cast<const float4*>(a.vcache + (size_t)row * a.kv_dim + kvh * HS + j0 + 4 * (t & 3));
+        }
+    }
+    // ---- first K tile (rows < pos) to registers
+    float4 kreg[KREG];
+    auto k_issue = [&](int t0) {
+        const int nr = min(AM_TT, pos - t0);           // cache rows of the tile (<= 0: none)
+#pragma unroll
+        for (int u = 0; u < KREG; ++u) {
+            kreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nr > 0) {
+                const int i = min(t + 256 * u, nr * Q4 - 1);
+                kreg[u] = *reinterpret_cast<const float4*>(a.kcache + (size_t)(t0 + i / Q4) * a.kv_dim + kvh * HS + 4 * (i % Q4));
+            }
+        }
+    };
+    k_issue(0);
+    // ---- raw q of the group's heads, raw k / v of this kv head, the RoPE row of pos
+    for (int i = t; i < kvmul * HS; i += 256) q_s[i] = a.bq ? a.qkv[(kvh * kvmul) * HS + i] + a.bq[(kvh * kvmul) * HS + i] : a.qkv[(kvh * kvmul) * HS + i];
+    for (int i = t; i < HALF; i += 256) { cr_s[i] = a.rope_cr[(size_t)pos * HALF + i]; ci_s[i] = a.rope_ci[(size_t)pos * HALF + i]; }
+    for (int i = t; i < HS; i += 256) kcur[i] = a.bk ? a.qkv[a.q_dim + kvh * HS + i] + a.bk[kvh * HS + i] : a.qkv[a.q_dim + kvh * HS + i];
+    float vraw = 0.f;                                  // writer: element t of the v row (HS <= 256); others: column j0 + t for t < 16
+    {
+        const int i = writer ? t : j0 + t;
+        if (writer ? t < HS : t < 16) vraw = a.bv ? a.qkv[a.q_dim + a.kv_dim + kvh * HS + i] + a.bv[kvh * HS + i] : a.qkv[a.q_dim + a.kv_dim + kvh * HS + i];
+    }
+    __syncthreads();
+    if (a.arch == 1) {                                 // Qwen3: per-head RMSNorm of q and k before RoPE, one wavefront per vector
+        for (int vec = hq; vec < kvmul + 1; vec += 4) head_rmsnorm_wave(vec < kvmul ? q_s + vec * HS : kcur, vec < kvmul ? a.qnorm : a.knorm, HS, a.eps, lane);
+        __syncthreads();
+    }
+    for (int h = 0; h < kvmul; ++h) rope_head(q_s + h * HS, HS, cr_s, ci_s, a.arch, t, 256);
+    rope_head(kcur, HS, cr_s, ci_s, a.arch, t, 256);
+    __syncthreads();
+    if (writer && t < HS) {                            // KV write, InferenceCore.java:92-93
+        a.kcache[(size_t)pos * a.kv_dim + kvh * HS + t] = kcur[t];
+        a.vcache[(size_t)pos * a.kv_dim + kvh * HS + t] = vraw;
+    }
+    if (writer ? (t >= j0 && t < j0 + 16) : t < 16) vbuf[pos * 16 + (writer ? t - j0 : t)] = vraw;      // row pos of the slab (j0 = 0 for the writer)
+    // ---- scores: tiles of AM_TT timesteps, lane = timesteps r and r + 64 of the tile, strict j order, mul then add (FloatTensor.scalarDot)
+    const float sqrt_hs = (float)sqrt((double)HS);
+    float mx = -INFINITY;
+    for (int t0 = 0; t0 < n; t0 += AM_TT) {
+        const int nr = min(AM_TT, pos - t0);
+#pragma unroll
+        for (int u = 0; u < KREG; ++u) {
+            const int i = t + 256 * u;
+            if (nr > 0 && i < nr * Q4) *reinterpret_cast<float4*>(kt + (i / Q4) * PITCH + 4 * (i % Q4)) = kreg[u];
+        }
+        if (pos >= t0 && pos < t0 + AM_TT && t < Q4) *reinterpret_cast<float4*>(kt + (pos - t0) * PITCH + 4 * t) = *reinterpret_cast<const float4*>(kcur + 4 * t);
+        __syncthreads();
+        if (t0 + AM_TT < n) k_issue(t0 + AM_TT);       // next tile in flight under this tile's chains
+        if (hq < kvmul) {
+            const float* q = q_s + hq * HS;
+            const int r0 = min(lane, n - 1 - t0), r1 = min(lane + 64, n - 1 - t0);      // clamped rows: lanes past the end recompute the last timestep
+            const float* k0 = kt + r0 * PITCH;
+            const float* k1 = kt + r1 * PITCH;
+            float s0 = 0.f, s1 = 0.f;
+            float4 qv = *reinterpret_cast<const float4*>(q), ka = *reinterpret_cast<const float4*>(k0), kb = *reinterpret_cast<const float4*>(k1);
+            for (int j = 4; j < HS; j += 4) {
+                const float4 qn = *reinterpret_cast<const float4*>(q + j), kan = *reinterpret_cast<const float4*>(k0 + j), kbn = *reinterpret_cast<const float4*>(k1 + j);
+                s0 = s0 + qv.x * ka.x; s1 = s1 + qv.x * kb.x; s0 = s0 + qv.y * ka.y; s1 = s1 + qv.y * kb.y;
+                s0 = s0 + qv.z * ka.z; s1 = s1 + qv.z * kb.z; s0 = s0 + qv.w * ka.w; s1 = s1 + qv.w * kb.w;
+                qv = qn; ka = kan; kb = kbn;
+            }
+            s0 = s0 + qv.x * ka.x; s1 = s1 + qv.x * kb.x; s0 = s0 + qv.y * ka.y; s1 = s1 + qv.y * kb.y;
+            s0 = s0 + qv.z * ka.z; s1 = s1 + qv.z * kb.z; s0 = s0 + qv.w * ka.w; s1 = s1 + qv.w * kb.w;
+            s0 = a.att_mul != 0.f ? s0 * a.att_mul : s0 / sqrt_hs;
+            s1 = a.att_mul != 0.f ? s1 * a.att_mul : s1 / sqrt_hs;
+            if (t0 + lane < n) { e_s[hq * AM_MAXN + t0 + lane] = s0; mx = fmaxf(mx, s0); }
+            if (t0 + lane + 64 < n) { e_s[hq * AM_MAXN + t0 + lane + 64] = s1; mx = fmaxf(mx, s1); }
+        }
+        __syncthreads();
+    }
+    // ---- softmax of the wavefront's head (FloatTensor.softmaxInPlace :211-219): max, exp in double, strictly sequential sum, divide
+    if (hq < kvmul) {
+        float* e = e_s + hq * AM_MAXN;
+        mx = wave_max(mx);
+        for (int i = lane; i < n; i += 64) e[i] = (float)exp((double)(e[i] - mx));
+        const float sum = seq_sum_lds_ring(e, n);
+        for (int i = lane; i < n; i += 64) e[i] = e[i] / sum;
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u)
+        if ((t >> 2) + 64 * u < pos) *reinterpret_cast<float4*>(vbuf + 4 * (t + 256 * u)) = sreg[u];
+    __syncthreads();
+    // ---- weighted V sum of the wavefront's head: xb[j] = a_t * v[t][j] + xb[j], t ascending (saxpyInPlace :221-227); lane = (column l & 15, timestep 4 g + (l >> 4))
+    if (hq >= kvmul) return;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int col = lane & 15, k = lane >> 4;
+        const float* ap = e_s + hq * AM_MAXN;
+        int g = 0;
+        for (; 4 * g + 16 <= n; g += 4) {                  // 4 MFMAs per iteration, operands fetched first
+            float p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int r = 4 * (g + u) + k; p[u] = ap[r] * vbuf[r * 16 + col]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p[u], 1.0f, acc, 0, 0, 0);
+        }
+        for (; 4 * g < n; ++g) {
+            const int r = 4 * g + k;
+            const float p = r < n ? ap[r] * vbuf[r * 16 + col] : 0.f;      // +0 pads the last group
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p, 1.0f, acc, 0, 0, 0);
+        }
+    }
+    if ((lane & 15) == 0) {                            // D[row][col]: row = slab column 4 * (lane >> 4) + reg; every MFMA column holds the same chain
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* o = a.xb + (kvh * kvmul + hq) * HS + j0 + 4 * (lane >> 4) + r;
+            *o = acc[r];
+            if (a.tp) tp_push_store(a.tp->p, o, acc[r]);
+        }
+    }
+    if (a.tp) tp_publish(a.tp->p, gridDim.x * gridDim.y * kvmul);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Long-context decode attention, round 5: the softmax and the weighted V sum as TWO launches shaped after what bounds them.
 // At depth (llama-bench -d) the one-launch pair above spends its time in two strictly sequential chains per workgroup: the
 // softmax denominator (n dependent adds at ~11 cycles each, recomputed by each of the hs / 16 workgroups of a head) and the

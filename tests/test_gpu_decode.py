@@ -198,6 +198,45 @@ def test_graph_and_eager_launches_agree_bitwise(pkg, orc, planmod):
     a.freeTornadoExecutionPlan(); b.freeTornadoExecutionPlan()
 
 
+@pytest.mark.parametrize("cfg,depths", [("mid-llama", [129, 255, 511, 640, 764]), ("mid-qwen3", [200, 513, 765]), ("mid-qwen2", [300]), ("mid-granite", [257, 700]),
+                                        ("mid-phi3", [384, 766]), ("mha-llama", [450])])      # head sizes 64 / 128, kvMul 4 / 6 (pair fallback) / 3 / 1, qk-norm, bias, attention scale
+def test_one_launch_attention_between_128_and_767_positions(pkg, orc, planmod, cfg, depths):
+    """r6: positions 128 .. 767 run attn_mid_kernel — RoPE, KV write, scores (K streamed through LDS), softmax and the weighted V sum of a kv head's
+    query heads in ONE launch per layer (GL3_ATTN_FUSED_MID=0: the r4 pair, which kvMul > 4 and other head sizes keep).  Decode steps behind a batched
+    prefill of d positions, at depths on both sides of every 128-step K tile edge and at the last position of the regime; logits and the KV rows the
+    steps wrote must equal the oracle bit for bit, and the r4 pair must give the same logits."""
+    plan_mod, hip = planmod
+    base = pkg.synth.CONFIGS[cfg]
+    m = pkg.synth.make_numpy(pkg.synth.ModelConfig(**{**base.__dict__, "ctx": 776}), seed=31)
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=256)
+    os.environ["GL3_ATTN_FUSED_MID"] = "0"
+    try:
+        pair = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=256)
+    finally:
+        os.environ.pop("GL3_ATTN_FUSED_MID", None)
+    o = orc.COracle(m)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 776)
+    done = 0
+    for d in depths:
+        while done < d:                                   # prefill up to depth d in chunks
+            c = min(256, d - done)
+            for pl in (plan, pair):
+                pl.tornadoVMForwardBatchPrefill(toks[done:done + c], done)
+            o.prefill(toks[done:done + c], done)
+            done += c
+        for pos in range(d, min(d + 2, 768)):
+            ref = o.forward(toks[pos], pos)
+            got = plan.forward_decode(toks[pos], pos)
+            assert np.array_equal(got, ref), (cfg, pos, rel(got, ref))
+            assert np.array_equal(pair.forward_decode(toks[pos], pos), ref), (cfg, "pair", pos)
+            done = pos + 1
+        for l in range(m.cfg.n_layers):
+            k, v = plan.kv(l, done - 1)
+            ko, vo = o.kv(l, done - 1)
+            assert np.array_equal(k, ko) and np.array_equal(v, vo), (cfg, l, done - 1)
+    plan.freeTornadoExecutionPlan(); pair.freeTornadoExecutionPlan()
+
+
 @pytest.mark.parametrize("cfg", ["mid-llama", "mid-qwen3", "mid-qwen2", "mha-llama", "mid-granite", "phi3-hs96"])   # head sizes 64 / 128 / 96, kvMul 4 / 6 / 1
 def test_fused_short_context_attention_and_the_handover_at_128(pkg, orc, planmod, cfg):
     """Positions < 128 run attn_head_kernel (one launch per layer, one workgroup per query head), later ones the scores +
