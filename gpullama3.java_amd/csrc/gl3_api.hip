@@ -409,8 +409,8 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
         attn_head_dispatch(d.head_size, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ctx->heads_l), dim3(256), attn_head_smem(d.head_size), ctx->stream, aa); });
         return;
     }
-    // r6: positions AF_MAXN .. 767 in one launch (attn_mid_kernel); GL3_ATTN_FUSED_MID=0: the r4 pair
-    static const bool fused_mid = env_flag("GL3_ATTN_FUSED_MID", true);
+    // r6 experiment: positions AF_MAXN .. 767 in one launch (attn_mid_kernel): measured slower than the pair (gl3_decode_kernels.h), off unless GL3_ATTN_FUSED_MID=1
+    static const bool fused_mid = env_flag("GL3_ATTN_FUSED_MID", false);
     if (which == 0 && amode == ATT_MID && fused_mid && kvmul <= 4 && ctx->attn_mid <= AM_MAXN && (d.head_size == 128 || d.head_size == 64)) {
         const dim3 mg(d.head_size / 16, ctx->kv_heads_l);
         if (d.head_size == 128) hipLaunchKernelGGL(attn_mid_kernel<128>, mg, dim3(256), attn_mid_smem<128>(), ctx->stream, aa);

@@ -1191,7 +1191,7 @@ static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnA
             for (int i = t; i < n; i += 256) e_s[i] = (float)exp((double)(e_s[i] - mx));
             __syncthreads();
             ATT_STAMP(3);
-            if (wave == 0) { const float sm = seq_sum_lds<false>(e_s, n); if (lane == 0) red_s[4] = sm; }
+            if (wave == 0) { const float sm = seq_sum_lds_ring(e_s, n); if (lane == 0) red_s[4] = sm; }      // reads pinned three groups ahead: ~6 instead of ~11 cycles per element
             __syncthreads();
             ATT_STAMP(4);
             sum = red_s[4];
@@ -1204,7 +1204,7 @@ static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnA
                 __syncthreads();
                 for (int i = t; i < len; i += 256) e_s[i] = (float)exp((double)(sc[c0 + i] - mx));
                 __syncthreads();
-                if (wave == 0) { const float sm = seq_sum_lds<false>(e_s, len, c0 == 0 ? 0.f : red_s[4]); if (lane == 0) red_s[4] = sm; }
+                if (wave == 0) { const float sm = seq_sum_lds_ring(e_s, len, c0 == 0 ? 0.f : red_s[4]); if (lane == 0) red_s[4] = sm; }
             }
             __syncthreads();
             sum = red_s[4];
@@ -1257,6 +1257,9 @@ static __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(const AttnA
 }
 
 // ---------------------------------------------------------------------------------------------------
+// MEASURED SLOWER than the pair and therefore OFF by default (GL3_ATTN_FUSED_MID=1 selects it): 19.0 us per 8B layer at depth 256 and 28.9 us at 512
+// against 18.8 / 23.3 for the pair (tg128@d512 352 vs 397 tok/s).  64 workgroups of one wavefront per SIMD expose every LDS and memory latency that
+// the pair hides behind 256 column workgroups; kept as the bit-exact record of the experiment (profiles/r06_mid_attention.md).
 // Decode attention for positions AF_MAXN .. AM_MAXN - 1 in ONE launch (r6; head_size 64 / 128, kvMul <= 4).  The r4 pair (attn_scores_kernel +
 // attn_softmax_pv_kernel) spent 18.8 us per 8B layer at depth 256 and 23.3 us at 512 against 0.3 - 0.6 us of KV read: two launches, a round trip of
 // the scores through memory, a softmax recomputed by each of a head's hs / 16 column workgroups with its strict sum on ONE wavefront, and three of the

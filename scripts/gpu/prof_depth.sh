@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel statistics of decode at depth (8 layers of the 8B shape): rocprofv3 --kernel-trace --stats, csv
 set -u
-O=gpurun_out/r5_prof_depth; mkdir -p $O
+O=gpurun_out/${OUT:-prof_depth}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for d in ${DEPTHS:-4096 16384}; do

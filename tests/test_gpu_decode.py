@@ -201,17 +201,18 @@ def test_graph_and_eager_launches_agree_bitwise(pkg, orc, planmod):
 @pytest.mark.parametrize("cfg,depths", [("mid-llama", [129, 255, 511, 640, 764]), ("mid-qwen3", [200, 513, 765]), ("mid-qwen2", [300]), ("mid-granite", [257, 700]),
                                         ("mid-phi3", [384, 766]), ("mha-llama", [450])])      # head sizes 64 / 128, kvMul 4 / 6 (pair fallback) / 3 / 1, qk-norm, bias, attention scale
 def test_one_launch_attention_between_128_and_767_positions(pkg, orc, planmod, cfg, depths):
-    """r6: positions 128 .. 767 run attn_mid_kernel — RoPE, KV write, scores (K streamed through LDS), softmax and the weighted V sum of a kv head's
-    query heads in ONE launch per layer (GL3_ATTN_FUSED_MID=0: the r4 pair, which kvMul > 4 and other head sizes keep).  Decode steps behind a batched
-    prefill of d positions, at depths on both sides of every 128-step K tile edge and at the last position of the regime; logits and the KV rows the
-    steps wrote must equal the oracle bit for bit, and the r4 pair must give the same logits."""
+    """Positions 128 .. 767: the two-launch pair (scores; softmax + weighted V sum) by default, and the r6 experiment attn_mid_kernel
+    (GL3_ATTN_FUSED_MID=1: RoPE, KV write, scores with K streamed through LDS, softmax and the weighted V sum of a kv head's query heads in ONE launch
+    per layer — measured slower, kept selectable; kvMul > 4 and other head sizes always take the pair).  Decode steps behind a batched prefill of d
+    positions, at depths on both sides of every 128-step K tile edge and at the last position of the regime; logits and the KV rows the steps wrote
+    must equal the oracle bit for bit on both forms."""
     plan_mod, hip = planmod
     base = pkg.synth.CONFIGS[cfg]
     m = pkg.synth.make_numpy(pkg.synth.ModelConfig(**{**base.__dict__, "ctx": 776}), seed=31)
-    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=256)
-    os.environ["GL3_ATTN_FUSED_MID"] = "0"
+    pair = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=256)
+    os.environ["GL3_ATTN_FUSED_MID"] = "1"
     try:
-        pair = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=256)
+        plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=256)
     finally:
         os.environ.pop("GL3_ATTN_FUSED_MID", None)
     o = orc.COracle(m)
