@@ -87,28 +87,30 @@ static hipError_t g3_allow() {
 //   BIG   128 x 128, 2 x 2 wavefronts of 2 x 2 fragments, KB 2, two workgroups per CU   (gate + up as 64 + 64 rows; matrices with >= 512 such tiles)
 //   QKV    96 x 128, 3 x 4 one-tile wavefronts, KB 4, one workgroup per CU              (row counts that are a multiple of 96 with 128..384 tiles: 6144-row qkv)
 //   SMALL  64 x 128, 2 x 4 one-tile wavefronts, KB 4, one workgroup per CU              (everything else: the 4096-row wo / down projections)
+//   SMALL2 64 x 64,  2 x 2 one-tile wavefronts, KB 4, two workgroups per CU             (A/B: GL3_PF_GEMM3_SHAPE=4 — two independent barrier domains per CU)
 template <int EPI>
 static hipError_t g3_allow_epi() {
     hipError_t e = g3_allow<EPI, EPI == EPI_SWIGLU ? 1 : 2, 2, 2, 2, 2, 2>();
     if constexpr (EPI != EPI_SWIGLU) {
         if (e == hipSuccess) e = g3_allow<EPI, 1, 1, 3, 4, 4, 1>();
         if (e == hipSuccess) e = g3_allow<EPI, 1, 1, 2, 4, 4, 1>();
+        if (e == hipSuccess) e = g3_allow<EPI, 1, 1, 2, 2, 4, 2>();
     }
     return e;
 }
-template <int NFR, int WCN>
-static hipError_t g3t_allow() { return hipFuncSetAttribute((const void*)pf_gemm3t_kernel<NFR, WCN>, hipFuncAttributeMaxDynamicSharedMemorySize, g3t_lds_bytes(NFR, WCN)); }
-template <int NFR, int WCN>
+template <int NFR, int KBT>
+static hipError_t g3t_allow() { return hipFuncSetAttribute((const void*)pf_gemm3t_kernel<NFR, KBT>, hipFuncAttributeMaxDynamicSharedMemorySize, g3t_lds_bytes(NFR, KBT)); }
+template <int NFR, int KBT>
 static void g3t_launch(GemmArgs a, int rows, int ntok, hipStream_t s) {
-    a.ntt = (ntok + 32 * WCN - 1) / (32 * WCN); a.nrt = (rows + 32 * NFR - 1) / (32 * NFR);
-    hipLaunchKernelGGL((pf_gemm3t_kernel<NFR, WCN>), dim3(8 * ((a.ntt * a.nrt + 7) / 8)), dim3(128 * WCN), g3t_lds_bytes(NFR, WCN), s, a);
+    a.ntt = (ntok + 127) / 128; a.nrt = (rows + 32 * NFR - 1) / (32 * NFR);
+    hipLaunchKernelGGL((pf_gemm3t_kernel<NFR, KBT>), dim3(8 * ((a.ntt * a.nrt + 7) / 8)), dim3(512), g3t_lds_bytes(NFR, KBT), s, a);
 }
 hipError_t gl3_gemm3_allow_lds() {
     hipError_t e = g3_allow_epi<EPI_SWIGLU>();
-    if (e == hipSuccess) e = g3t_allow<4, 4>();
-    if (e == hipSuccess) e = g3t_allow<5, 4>();
-    if (e == hipSuccess) e = g3t_allow<6, 4>();
-    if (e == hipSuccess) e = g3t_allow<7, 4>();
+    if (e == hipSuccess) e = g3t_allow<4, 1>();
+    if (e == hipSuccess) e = g3t_allow<5, 1>();
+    if (e == hipSuccess) e = g3t_allow<6, 1>();
+    if (e == hipSuccess) e = g3t_allow<7, 1>();
     if (e == hipSuccess) e = g3t_allow<4, 2>();
     if (e == hipSuccess) e = g3t_allow<5, 2>();
     if (e == hipSuccess) e = g3t_allow<6, 2>();
@@ -126,14 +128,14 @@ static void g3_dispatch(GemmArgs a, int rows, int ntok, hipStream_t s) {
         // gate + up: the 128 x 128 tiling (two workgroups per CU, 8 result tiles per SIMD and round) or a tall tiling (one workgroup per CU, 2 NFR tiles per
         // SIMD and round, gl3_prefill_gemm3t.h) — whichever leaves a SIMD fewer tile-steps.  GL3_PF_GEMM3_TALL: -1 never, 4 .. 7 that shape always.
         static const int tall_env = getenv("GL3_PF_GEMM3_TALL") ? atoi(getenv("GL3_PF_GEMM3_TALL")) : 0;
-        static const int tall_wcn = getenv("GL3_PF_GEMM3_TALL_WCN") ? atoi(getenv("GL3_PF_GEMM3_TALL_WCN")) : 4;      // 4: one 8-wavefront workgroup per CU (default); 2: two of 4
+        static const int tall_kb = getenv("GL3_PF_GEMM3_TALL_KB") ? atoi(getenv("GL3_PF_GEMM3_TALL_KB")) : 2;      // blocks per K stage of the tall tiling (1 | 2)
         int best = 0, cost = ((ntt * ((rows + 63) / 64) + 511) / 512) * 8;
         for (int nfr = 4; nfr <= 7 && tall_env == 0; ++nfr) {
             const int c = ((ntt * ((rows + 32 * nfr - 1) / (32 * nfr)) + 255) / 256) * 2 * nfr;
             if (c < cost) { cost = c; best = nfr; }
         }
         if (tall_env >= 4 && tall_env <= 7) best = tall_env;
-#define GL3_G3T(N_) do { if (tall_wcn == 4) g3t_launch<N_, 4>(a, rows, ntok, s); else g3t_launch<N_, 2>(a, rows, ntok, s); } while (0)
+#define GL3_G3T(N_) do { if (tall_kb == 1) g3t_launch<N_, 1>(a, rows, ntok, s); else g3t_launch<N_, 2>(a, rows, ntok, s); } while (0)
         switch (best) {
         case 4: GL3_G3T(4); break;
         case 5: GL3_G3T(5); break;
@@ -148,6 +150,7 @@ static void g3_dispatch(GemmArgs a, int rows, int ntok, hipStream_t s) {
         const int shape = force ? force : t128 >= 512 ? 1 : (rows % 96 == 0 && t96 > 128 && t96 <= 384) ? 2 : 3;
         if (shape == 1) g3_launch<EPI, 2, 2, 2, 2, 2, 2>(a, grid((rows + 127) / 128), s);
         else if (shape == 2) g3_launch<EPI, 1, 1, 3, 4, 4, 1>(a, grid((rows + 95) / 96), s);
+        else if (shape == 4) { a.ntt = (ntok + 63) / 64; const int nrt = (rows + 63) / 64; a.nrt = nrt; g3_launch<EPI, 1, 1, 2, 2, 4, 2>(a, dim3(8 * ((a.ntt * nrt + 7) / 8)), s); }
         else g3_launch<EPI, 1, 1, 2, 4, 4, 1>(a, grid((rows + 63) / 64), s);
     }
 }

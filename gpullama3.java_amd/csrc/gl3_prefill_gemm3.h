@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64 * WR * WC, (OCC * WR * WC + 3) / 4) void pf_gemm
     static_assert(NF <= 2 && TF <= 2, "accumulator budget");
     static_assert(NM == 1 || RF == 1, "SwiGLU: fragment index = matrix");
     static_assert(KB == 2 || KB == 4, "a stage is half a Q8T tile group or a whole one");
-    static_assert(TOK == 128, "token tile");
+    static_assert(TOK == 128 || TOK == 64, "token tile");
     static_assert(NM == 1 || RPM % 64 == 0, "a weight piece (64 rows) belongs to one matrix");
     constexpr int OFF_AT = KB * 2 * AROWS * 16, OFF_BQ = OFF_AT + KB * AROWS * 8, OFF_BS = OFF_BQ + KB * 2 * TOK * 16;
     constexpr int STAGE = g3_stage_bytes(AROWS, TOK, KB);

@@ -6,107 +6,109 @@
 //     8 wavefronts = {gate, up} x 4 token fragments, each owning NFR row fragments x ONE token fragment    (NFR = 7: 224 rows per matrix x 128 tokens)
 // one workgroup per CU, two wavefronts per SIMD, 64 x 4 = 256 workgroups for the 8B layer.  NFR = 4 .. 7 covers the other hidden sizes
 // (8192 = 64 x 128 rows: NFR 4; 9728 = 60.8 x 160: NFR 5 -> 244 workgroups); the host picks the shape with the fewest tile-steps per CU.
-//   * a K stage is ONE block (the weight side of a stage is 28 KB at NFR = 7): ring = 3 x 33 KB.  NFR may be odd, so the loop body is two
-//     stages (the result-tile register sets alternate with the global tile count).
+//   * a K stage is KBT blocks (1 or 2): the weight side of a block is 17.5 KB at NFR = 7, a stage of two 51 KB, the ring 3 x 51 = 153 KB.  All 8
+//     wavefronts of a CU share ONE barrier domain here, so both wavefronts of every SIMD sit in the barrier / scale-conversion phase together and the
+//     matrix pipe idles through it (stamps: 429 + 228 of 2685 cycles per one-block stage): two blocks per stage halve those phases.  With KBT = 1 and
+//     NFR odd the loop body is two stages (the result-tile register sets alternate with the global tile count).
 //   * the token fragment's B operands are read once per block and serve NFR tiles; the A operands stream through two register sets, tile
 //     q + 2's fragment is fetched when tile q + 1's MFMAs have been issued.
 //   * gate and up tiles of an output element sit in different wavefronts: after the K loop each wavefront parks half of its tiles in LDS (the ring is
 //     dead by then), takes the partner's other half, and applies SwiGLU to its share; 16-byte stores (a lane owns 4 consecutive hidden units).
-// WCN = token fragments per workgroup.  WCN 4: the 8-wavefront form above (ring of 3, partial vmcnt).  WCN 2: 4 wavefronts = {gate, up} x 2 token
-// fragments, 64 tokens, a ring of TWO slots (61 KB at NFR = 7), so that two INDEPENDENT workgroups share a CU as in the 128 x 128 tiling: with all 8
-// wavefronts of a CU in one barrier domain, both wavefronts of every SIMD sit in the barrier / scale-conversion phase at the same time and the matrix pipe
-// idles; two domains fill each other's gaps.  With two slots the pieces of window k (stage k + 2 -> the slot barrier k freed) must have landed by barrier
-// k + 1, one whole stage later: they are issued in a burst right behind the barrier and the wait is a plain vmcnt(0).
+// Slot image: Aq[blk][row fragment][half][32 rows][16 B] | At[blk][row][8 B] | Bq[blk][half][TOK][16 B] | Bs[blk][half][TOK][16 B].
+// (A form with two 4-wavefront workgroups per CU and a ring of two slots was measured at 217 us against 200 for this one and removed.)
 #pragma once
 #include "gl3_prefill_gemm3.h"
 
-__host__ __device__ constexpr int g3t_stage_bytes(int nfr, int wcn) { return 2 * (64 * nfr) * 16 + (64 * nfr) * 8 + 2 * (32 * wcn) * 16 + 2 * (32 * wcn) * 16; }
-__host__ __device__ constexpr int g3t_ring(int wcn) { return wcn == 4 ? 3 : 2; }
-__host__ __device__ constexpr int g3t_lds_bytes(int nfr, int wcn) {
-    return g3t_ring(wcn) * g3t_stage_bytes(nfr, wcn) > 4096 * wcn * nfr ? g3t_ring(wcn) * g3t_stage_bytes(nfr, wcn) : 4096 * wcn * nfr;
+__host__ __device__ constexpr int g3t_stage_bytes(int nfr, int kbt) { return kbt * (2 * (64 * nfr) * 16 + (64 * nfr) * 8 + 2 * 128 * 16 + 2 * 128 * 16); }
+__host__ __device__ constexpr int g3t_lds_bytes(int nfr, int kbt) {
+    return G3_RING * g3t_stage_bytes(nfr, kbt) > 16384 * nfr ? G3_RING * g3t_stage_bytes(nfr, kbt) : 16384 * nfr;
 }
 
-template <int NFR, int WCN>
-__global__ __launch_bounds__(128 * WCN, 2) void pf_gemm3t_kernel(const GemmArgs a) {
+template <int NFR, int KBT>
+__global__ __launch_bounds__(512, 2) void pf_gemm3t_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int NW = 2 * WCN, NT = 64 * NW, RPM = 32 * NFR, AROWS = 2 * RPM, TOK = 32 * WCN, RING = g3t_ring(WCN);
-    constexpr int OFF_AT = 2 * AROWS * 16, OFF_BQ = OFF_AT + AROWS * 8, OFF_BS = OFF_BQ + 2 * TOK * 16, STAGE = g3t_stage_bytes(NFR, WCN);
-    static_assert(STAGE == OFF_BS + 2 * TOK * 16, "stage layout");
-    constexpr int NLA = 2 * AROWS / 64, NLB = 2 * TOK / 64, NPIECE = NLA + 2 * NLB;      // pieces per stage: weights, int8 activations, activation scale operands
+    constexpr int NW = 8, NT = 512, RPM = 32 * NFR, AROWS = 2 * RPM, TOK = 128, RING = G3_RING;
+    constexpr int ABLK = 2 * AROWS * 16, BBLK = 2 * TOK * 16;                            // bytes of one block's int8 weights / activations (and scale operands)
+    constexpr int OFF_AT = KBT * ABLK, OFF_BQ = OFF_AT + KBT * AROWS * 8, OFF_BS = OFF_BQ + KBT * BBLK, STAGE = g3t_stage_bytes(NFR, KBT);
+    static_assert(STAGE == OFF_BS + KBT * BBLK, "stage layout");
+    static_assert(KBT == 1 || KBT == 2, "blocks per stage");
+    constexpr int NLA = KBT * 2 * NFR, NLB = KBT * BBLK / 1024, NPIECE = NLA + 2 * NLB;  // pieces per stage: weights, int8 activations, activation scale operands
     constexpr int NDMA = (NPIECE + NW - 1) / NW;
-    constexpr int BSTEP = NFR - 2, NLATE = NFR - BSTEP;                                  // first step that fetches an A fragment of the next stage
-    constexpr int PPS = RING == 3 ? 1 : 2;                                               // pieces per step behind the barrier (ring of 2: a burst)
-    constexpr int NSC = (AROWS + NT - 1) / NT;                                           // weight scale entries per thread and stage
-    static_assert(WCN == 2 || WCN == 4, "token fragments per workgroup");
-    static_assert(NFR >= 3 && NDMA <= PPS * NFR, "shape");
+    constexpr int NSTEP = KBT * NFR;                                                     // tile steps per stage
+    constexpr int SPB = (NSTEP & 1) ? 2 : 1;                                             // stages per loop body (register-set parity)
+    constexpr int BSTEP = NSTEP - 2, NLATE = 2;                                          // first step that fetches an A fragment of the next stage
+    constexpr int NSC = (KBT * AROWS + NT - 1) / NT;                                     // weight scale entries per thread and stage
+    static_assert(NFR >= 3 && NDMA <= NSTEP && NSC <= 2, "shape");
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tl = lane & 31, hi = lane >> 5;
-    const int wm = wave / WCN, wc = wave % WCN;        // matrix (0 gate, 1 up), token fragment
+    const int wm = wave >> 2, wc = wave & 3;           // matrix (0 gate, 1 up), token fragment
     const int ntt_g = a.ntt, per_xcd = (a.ntt * a.nrt + 7) >> 3;
     const int lin = blockIdx.x, J = (lin & 7) * per_xcd + (lin >> 3);
     if (J >= ntt_g * a.nrt) return;
     const int row0 = (J / ntt_g) * RPM;
     const int tok0 = (J % ntt_g) * TOK;
     const uint32_t strip_bytes = (uint32_t)a.ng * TILE_BYTES;
-    const int nkb = a.nb;                              // one block per stage
+    const int nkb = (a.nb + KBT - 1) / KBT;            // stages that hold at least one real block
     const int nstrips = (a.rows + 15) >> 4;
     auto strip_off = [&](int lr) -> uint32_t { return (uint32_t)min(nstrips - 1, (row0 >> 4) + (lr >> 4)) * strip_bytes; };      // lr = row inside the matrix' RPM rows
 
     // ---- LDS-DMA pieces of this wavefront: uniform base pointer + 32-bit per-lane offset.  A weight piece = one 32-row fragment (rows of ONE
-    // matrix) x both 16-byte halves of the block: slot image Aq[row fragment][half][32 rows][16 B] | At[row][8 B] | Bq[half][TOK][16 B] | Bs[half][TOK][16 B]
+    // matrix) x both 16-byte halves of one block.  Per-stage source offset = (kf >> p_sh) * p_mul + (kf & ((1 << p_sh) - 1)) * p_odd: stage kf starts at
+    // block kf * KBT = tile group (kf * KBT) >> 2, block (kf * KBT) & 3 inside it (KBT = 2: even, so both blocks sit in one tile group).
     const uint8_t* p_base[NDMA];
     uint32_t p_lane[NDMA], p_dst[NDMA], p_mul[NDMA], p_odd[NDMA];
-    int p_sh[NDMA];                                    // per-stage offset = (kf >> p_sh) * p_mul + (kf & ((1 << p_sh) - 1)) * p_odd
+    int p_sh[NDMA];
 #pragma unroll
     for (int u = 0; u < NDMA; ++u) {
         int j = wave + NW * u;
         if (j >= NPIECE) j -= NPIECE;                  // surplus slot: re-load a piece (every wavefront issues exactly NDMA pieces per window)
         if (j < NLA) {
-            const int lr = (j % NFR) * 32 + tl;        // row inside the matrix' RPM rows; fragment j = matrix j / NFR, fragment j % NFR
-            p_base[u] = j >= NFR ? a.w2 : a.w;
-            p_lane[u] = strip_off(lr) + (hi ? 1152 : 128) + 16 * (lr & 15);
-            p_dst[u] = 1024 * j; p_sh[u] = 2; p_mul[u] = TILE_BYTES; p_odd[u] = 256;
+            const int blk = j / (2 * NFR), g = j % (2 * NFR), lr = (g % NFR) * 32 + tl;       // fragment g = matrix g / NFR, fragment g % NFR
+            p_base[u] = g >= NFR ? a.w2 : a.w;
+            p_lane[u] = strip_off(lr) + (hi ? 1152 : 128) + 16 * (lr & 15) + blk * 256;
+            p_dst[u] = blk * ABLK + 1024 * g; p_sh[u] = KBT == 1 ? 2 : 1; p_mul[u] = TILE_BYTES; p_odd[u] = 256 * KBT;
         } else if (j < NLA + NLB) {
-            const int jb = j - NLA, e = 64 * jb + lane, c = e / TOK, tk = (e % TOK) ^ c;       // LDS slot p holds token p ^ c (bank spread)
+            const int jb = j - NLA, e = 64 * jb + lane, c = e / TOK, tk = (e % TOK) ^ (c & 1);      // c = blk * 2 + half; LDS slot p holds token p ^ half
             p_base[u] = a.XQ;
             p_lane[u] = ((uint32_t)c * (uint32_t)a.xp_tok + (uint32_t)(tok0 + tk)) * 16;
-            p_dst[u] = OFF_BQ + 1024 * jb; p_sh[u] = 0; p_mul[u] = 2u * (uint32_t)a.xp_tok * 16; p_odd[u] = 0;
+            p_dst[u] = OFF_BQ + 1024 * jb; p_sh[u] = 0; p_mul[u] = (uint32_t)(2 * KBT) * (uint32_t)a.xp_tok * 16; p_odd[u] = 0;
         } else {                                       // activation scale operands XP[block][half][token slot][16 B], the image of Bs
             const int jp = j - NLA - NLB, e = 64 * jp + lane, c = e / TOK;
             p_base[u] = a.XP;
             p_lane[u] = ((uint32_t)c * (uint32_t)a.xp_tok + (uint32_t)(tok0 + e % TOK)) * 16;
-            p_dst[u] = OFF_BS + 1024 * jp; p_sh[u] = 0; p_mul[u] = 2u * (uint32_t)a.xp_tok * 16; p_odd[u] = 0;
+            p_dst[u] = OFF_BS + 1024 * jp; p_sh[u] = 0; p_mul[u] = (uint32_t)(2 * KBT) * (uint32_t)a.xp_tok * 16; p_odd[u] = 0;
         }
     }
     auto dma_one = [&](int kf, int slot, int u) {
         const uint32_t off = ((uint32_t)kf >> p_sh[u]) * p_mul[u] + ((uint32_t)kf & ((1u << p_sh[u]) - 1)) * p_odd[u];
         g2_dma16(p_base[u] + (p_lane[u] + off), smem + slot * STAGE + p_dst[u]);
     };
-    // ---- weight scale operands: thread t owns the entries of rows t, t + NT, .. (< AROWS) of every stage
+    // ---- weight scale operands: thread t owns the entries t, t + NT (< KBT * AROWS) of every stage; entry = (block e / AROWS, row e % AROWS)
     const uint8_t* s_wp[NSC];
     uint32_t r_ws[NSC];
 #pragma unroll
     for (int k = 0; k < NSC; ++k) {
-        const int row = t + NT * k, lr = row % RPM;
-        s_wp[k] = (row >= RPM ? a.w2 : a.w) + strip_off(lr) + 2 * (lr & 15);
+        const int e = t + NT * k, blk = e / AROWS, row = e % AROWS, lr = row % RPM;
+        s_wp[k] = (row >= RPM ? a.w2 : a.w) + strip_off(lr) + 2 * (lr & 15) + blk * 32;
         r_ws[k] = 0;
     }
     auto scale_load = [&](int kf) {
+        const uint32_t b0 = (uint32_t)kf * KBT;
 #pragma unroll
         for (int k = 0; k < NSC; ++k) {
-            const uint8_t* p = s_wp[k] + (size_t)(kf >> 2) * TILE_BYTES + (kf & 3) * 32;
-            if (t + NT * k < AROWS) asm volatile("global_load_ushort %0, %1, off" : "=v"(r_ws[k]) : "v"(p) : "memory");
+            const uint8_t* p = s_wp[k] + (size_t)(b0 >> 2) * TILE_BYTES + (b0 & 3) * 32;
+            if (t + NT * k < KBT * AROWS) asm volatile("global_load_ushort %0, %1, off" : "=v"(r_ws[k]) : "v"(p) : "memory");
         }
     };
     auto scale_store = [&](int slot) {
         uint8_t* base = smem + slot * STAGE;
 #pragma unroll
         for (int k = 0; k < NSC; ++k) {
-            const int row = t + NT * k;
-            if (row < AROWS) {
+            const int e = t + NT * k;
+            if (e < KBT * AROWS) {
                 const float wf = h2f((uint16_t)r_ws[k]);
                 const float whi = __uint_as_float(__float_as_uint(wf) & 0xFFFF0000u), wlo = wf - whi;
-                *reinterpret_cast<uint2*>(base + OFF_AT + row * 8) = make_uint2(g2_bf16_dup(whi), g2_bf16_dup(wlo));
+                *reinterpret_cast<uint2*>(base + OFF_AT + e * 8) = make_uint2(g2_bf16_dup(whi), g2_bf16_dup(wlo));      // At[blk][row]: e = blk * AROWS + row
             }
         }
     };
@@ -117,7 +119,6 @@ __global__ __launch_bounds__(128 * WCN, 2) void pf_gemm3t_kernel(const GemmArgs 
         if constexpr (NSC == 1) asm volatile(text_ : "+v"(r_ws[0]) : __VA_ARGS__ : "memory");               \
         else asm volatile(text_ : "+v"(r_ws[0]), "+v"(r_ws[NSC - 1]) : __VA_ARGS__ : "memory");             \
     } while (0)
-    static_assert(NSC <= 2, "scale entries per thread");
 
     float acc[NFR][16];
 #pragma unroll
@@ -133,18 +134,18 @@ __global__ __launch_bounds__(128 * WCN, 2) void pf_gemm3t_kernel(const GemmArgs 
     v4i_t af[2], bf[2], bp[2];                         // bp = {s operand, -B s operand} of the lane's half
     v4s_t at[2];                                       // {w_hi, w_hi, w_lo, w_lo}
     v16i_t D[2];
-    constexpr bool SSB = NFR >= 6;
+    constexpr bool SSB = NFR >= 6;                     // register budget: the s tile single-buffered
     v16f2_t S[SSB ? 1 : 2], N[1];
     const uint32_t la = (uint32_t)(wm * NFR * 1024 + hi * 512 + tl * 16);
     const uint32_t lat = (uint32_t)(OFF_AT + (wm * RPM + tl) * 8);
     const uint32_t lb = (uint32_t)(OFF_BQ + (hi * TOK + ((wc * 32 + tl) ^ hi)) * 16), lp = (uint32_t)(OFF_BS + (hi * TOK + wc * 32 + tl) * 16);
-    auto load_a = [&](const uint8_t* sb, int f, int set) {
-        af[set] = *reinterpret_cast<const v4i_t*>(sb + la + f * 1024);
-        at[set] = *reinterpret_cast<const v4s_t*>(sb + lat + f * 256);
+    auto load_a = [&](const uint8_t* sb, int blk, int f, int set) {
+        af[set] = *reinterpret_cast<const v4i_t*>(sb + blk * ABLK + la + f * 1024);
+        at[set] = *reinterpret_cast<const v4s_t*>(sb + blk * (AROWS * 8) + lat + f * 256);
     };
-    auto load_b = [&](const uint8_t* sb, int set) {
-        bf[set] = *reinterpret_cast<const v4i_t*>(sb + lb);
-        bp[set] = *reinterpret_cast<const v4i_t*>(sb + lp);
+    auto load_b = [&](const uint8_t* sb, int blk, int set) {
+        bf[set] = *reinterpret_cast<const v4i_t*>(sb + blk * BBLK + lb);
+        bp[set] = *reinterpret_cast<const v4i_t*>(sb + blk * BBLK + lp);
     };
 
     // ---- prologue: the ring full (stages 0 .. RING - 1), the weight scales of stage RING in flight, tile 0's MFMAs issued
@@ -159,9 +160,9 @@ __global__ __launch_bounds__(128 * WCN, 2) void pf_gemm3t_kernel(const GemmArgs 
     }
     scale_load(min(RING, nkb - 1));
     G3T_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier", "n"(0));
-    load_b(smem, 0);
-    load_a(smem, 0, 0);
-    load_a(smem, 1, 1);
+    load_b(smem, 0, 0);
+    load_a(smem, 0, 0, 0);
+    load_a(smem, 0, 1, 1);
     D[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0], cbias, 0, 0, 0);
     S[0] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(at[0], __builtin_bit_cast(v4s_t, v2i_t{bp[0][0], bp[0][1]}), zero16, 0, 0, 0);
     N[0] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(at[0], __builtin_bit_cast(v4s_t, v2i_t{bp[0][2], bp[0][3]}), zero16, 0, 0, 0);
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(128 * WCN, 2) void pf_gemm3t_kernel(const GemmArgs 
 #define G3T_T0() do {} while (0)
 #define G3T_T1(acc_) do {} while (0)
 #endif
-    // one K stage; PS = parity of the stage inside the two-stage loop body (all register-set indices are static)
+    // one K stage; PS = index of the stage inside the loop body (all register-set indices are static)
     auto stage = [&](auto psc, int kb) {
         constexpr int PS = decltype(psc)::value;
         // window kb (behind this stage's barrier): stage kb + RING -> slot cur; the steps in front of the barrier still belong to window kb - 1:
@@ -183,17 +184,18 @@ __global__ __launch_bounds__(128 * WCN, 2) void pf_gemm3t_kernel(const GemmArgs 
         const int kf_late = min(kb + RING, nkb - 1), kf_early = min(kb + RING - 1, nkb - 1);
         const uint8_t* sb_cur = smem + cur * STAGE;
         const uint8_t* sb_nxt = smem + nxt * STAGE;
-        g2_static_for<0, NFR>([&](auto ic) {
-            constexpr int i = decltype(ic)::value, q = PS * NFR + i, qb = q & 1, qn = (q + 1) & 1;
-            constexpr bool last = i + 1 == NFR;
-            constexpr int bn = last ? (PS ^ 1) : PS;                   // B register set of the next tile's stage
+        g2_static_for<0, NSTEP>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, q = PS * NSTEP + i, qb = q & 1, qn = (q + 1) & 1;      // q: tile count inside the body (register-set parity)
+            constexpr int blk = i / NFR, f = i % NFR;
+            constexpr int gb = PS * KBT + blk;                                     // block count inside the body: B register set gb & 1
+            constexpr int bn = (gb + (f == NFR - 1 ? 1 : 0)) & 1;                  // B set of the next tile's block
             float cf[16];
             auto fma8 = [&](int r0) {
 #pragma unroll
                 for (int r = r0; r < r0 + 8; ++r) cf[r] = __builtin_fmaf(__int_as_float(D[qb][r]), S[SSB ? 0 : qb][r], N[0][r]);
                 asm volatile("" : "+v"(cf[r0]), "+v"(cf[r0 + 1]), "+v"(cf[r0 + 2]), "+v"(cf[r0 + 3]), "+v"(cf[r0 + 4]), "+v"(cf[r0 + 5]), "+v"(cf[r0 + 6]), "+v"(cf[r0 + 7]));
             };
-            // SSB (NFR >= 6, register budget): the s tile single-buffered — both fma halves first, then the s and -B s MFMAs back to back under the adds
+            // SSB: both fma halves first, then the s and -B s MFMAs back to back under the adds
             constexpr int sn = SSB ? 0 : qn;
             D[qn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[qn], bf[bn], cbias, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -214,42 +216,43 @@ __global__ __launch_bounds__(128 * WCN, 2) void pf_gemm3t_kernel(const GemmArgs 
                 // barrier kb (see gl3_prefill_gemm3.h): slot cur has been read for the last time, stage kb + 1 has landed in slot nxt
                 __builtin_amdgcn_sched_barrier(0);
                 G3T_T0();
-                if constexpr (RING == 3) G3T_WAIT("s_waitcnt vmcnt(%[n]) lgkmcnt(0)\n\ts_barrier", [n] "n"(NDMA));
-                else G3T_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier", "n"(0));
+                G3T_WAIT("s_waitcnt vmcnt(%[n]) lgkmcnt(0)\n\ts_barrier", [n] "n"(NDMA));
                 G3T_T1(tm_bar);
                 G3T_T0();
                 scale_store(cur);
                 scale_load(min(kb + RING + 1, nkb - 1));
                 G3T_T1(tm_scale);
-                load_b(sb_nxt, PS ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (i + 2 < NFR) load_a(sb_cur, i + 2, qb);      // tile q + 2's fragment into the set tile q has released
-            else load_a(sb_nxt, i + 2 - NFR, qb);
-            g2_static_for<0, PPS>([&](auto pc) {
-                constexpr int pi = decltype(pc)::value;
-                if constexpr (i >= BSTEP) {
-                    if constexpr (PPS * (i - BSTEP) + pi < NDMA) dma_one(kf_late, cur, PPS * (i - BSTEP) + pi);
-                } else {
-                    if constexpr (PPS * (i + NLATE) + pi < NDMA) dma_one(kf_early, erl, PPS * (i + NLATE) + pi);
-                }
-            });
+            // the B operands of the next block, two steps before its first tile
+            if constexpr (f == NFR - 2) {
+                if constexpr (blk + 1 < KBT) load_b(sb_cur, blk + 1, (gb + 1) & 1);
+                else load_b(sb_nxt, 0, (gb + 1) & 1);
+            }
+            // tile q + 2's A fragment into the set tile q has released
+            if constexpr (i + 2 < NSTEP) load_a(sb_cur, (i + 2) / NFR, (i + 2) % NFR, qb);
+            else load_a(sb_nxt, (i + 2 - NSTEP) / NFR, (i + 2 - NSTEP) % NFR, qb);
+            if constexpr (i >= BSTEP) {
+                if constexpr (i - BSTEP < NDMA) dma_one(kf_late, cur, i - BSTEP);
+            } else {
+                if constexpr (i + NLATE < NDMA) dma_one(kf_early, erl, i + NLATE);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] + cf[r];               // result +=, blocks ascending
-            asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]), "+v"(acc[i][4]), "+v"(acc[i][5]), "+v"(acc[i][6]), "+v"(acc[i][7]),
-                              "+v"(acc[i][8]), "+v"(acc[i][9]), "+v"(acc[i][10]), "+v"(acc[i][11]), "+v"(acc[i][12]), "+v"(acc[i][13]), "+v"(acc[i][14]), "+v"(acc[i][15]));
+            for (int r = 0; r < 16; ++r) acc[f][r] = acc[f][r] + cf[r];               // result +=, blocks ascending
+            asm volatile("" : "+v"(acc[f][0]), "+v"(acc[f][1]), "+v"(acc[f][2]), "+v"(acc[f][3]), "+v"(acc[f][4]), "+v"(acc[f][5]), "+v"(acc[f][6]), "+v"(acc[f][7]),
+                              "+v"(acc[f][8]), "+v"(acc[f][9]), "+v"(acc[f][10]), "+v"(acc[f][11]), "+v"(acc[f][12]), "+v"(acc[f][13]), "+v"(acc[f][14]), "+v"(acc[f][15]));
             __builtin_amdgcn_sched_barrier(0);
         });
         cur = nxt;
     };
-    for (int kb = 0; kb < nkb; kb += 2) {
+    for (int kb = 0; kb < nkb; kb += SPB) {
         stage(std::integral_constant<int, 0>{}, kb);
-        if (kb + 1 < nkb) stage(std::integral_constant<int, 1>{}, kb + 1);
+        if constexpr (SPB == 2) { if (kb + 1 < nkb) stage(std::integral_constant<int, 1>{}, kb + 1); }
     }
 #ifdef G3_TIMING
     if (lane == 0 && (J % 31) == 0)
-        printf("g3t NFR %d WCN %d J %d wave %d stages %d: barrier %llu scale %llu total %llu cycles\n", NFR, WCN, J, wave, nkb, tm_bar, tm_scale, __builtin_readcyclecounter() - tm_begin);
+        printf("g3t NFR %d KBT %d J %d wave %d stages %d: barrier %llu scale %llu total %llu cycles\n", NFR, KBT, J, wave, nkb, tm_bar, tm_scale, __builtin_readcyclecounter() - tm_begin);
 #endif
     G3T_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier", "n"(0));      // ring dead: LDS becomes the gate / up exchange
 #undef G3T_WAIT

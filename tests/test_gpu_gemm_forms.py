@@ -2,7 +2,7 @@
 parity tests (ragged small shapes to the 8B / 1B layers at 512 tokens) in its own pytest subprocess.
    default                     r6: pf_gemm3_kernel for qkv / wo / down, the tall one-round tiling (pf_gemm3t_kernel) or the 128 x 128 tiling for gate + up — normal suite
    GL3_PF_GEMM3_TALL=-1        gate + up on the 128 x 128 tiling everywhere;  =4..7 the tall tiling with that many row fragments on EVERY shape
-   GL3_PF_GEMM3_TALL_WCN=2     two 4-wavefront tall workgroups per CU (ring of two slots)
+   GL3_PF_GEMM3_TALL_KB=1      one block per K stage of the tall tiling (default: two)
    GL3_PF_GEMM3_SHAPE=1|2|3    128 x 128 / 96 x 128 / 64 x 128 workgroup tiles for every non-SwiGLU projection
    GL3_PF_GEMM3=0              the r5 kernels (row-layout activations): r4 kernel for gate + up, r3 kernel elsewhere; with GL3_PF_GEMM2=0 the r3 kernel
                                everywhere, GL3_PF_FUSED_ATTN=0 the three-kernel prefill attention"""
@@ -17,9 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("env", [{"GL3_PF_GEMM3": "0"}, {"GL3_PF_GEMM3": "0", "GL3_PF_GEMM2": "0", "GL3_PF_FUSED_ATTN": "0"}, {"GL3_PF_GEMM3_TALL": "-1"},
-                                 {"GL3_PF_GEMM3_TALL": "4"}, {"GL3_PF_GEMM3_TALL": "5", "GL3_PF_GEMM3_TALL_WCN": "2"}, {"GL3_PF_GEMM3_TALL": "6"},
+                                 {"GL3_PF_GEMM3_TALL": "4"}, {"GL3_PF_GEMM3_TALL": "5", "GL3_PF_GEMM3_TALL_KB": "1"}, {"GL3_PF_GEMM3_TALL": "6"},
                                  {"GL3_PF_GEMM3_TALL": "7", "GL3_PF_GEMM3_SHAPE": "1"}, {"GL3_PF_GEMM3_SHAPE": "2"}, {"GL3_PF_GEMM3_SHAPE": "3"}],
-                         ids=["r5-kernels", "r3-kernels", "g3-128x128", "tall4", "tall5-two-workgroups", "tall6", "tall7-shape1", "shape2", "shape3"])
+                         ids=["r5-kernels", "r3-kernels", "g3-128x128", "tall4", "tall5-one-block-stages", "tall6", "tall7-shape1", "shape2", "shape3"])
 def test_prefill_parity_of_a_gemm_form(env):
     e = dict(os.environ, **env)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_decode.py"), os.path.join(ROOT, "tests", "test_gpu_fullsize.py"),
