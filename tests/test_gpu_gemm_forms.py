@@ -16,10 +16,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("env", [{"GL3_PF_GEMM3": "0"}, {"GL3_PF_GEMM3": "0", "GL3_PF_GEMM2": "0", "GL3_PF_FUSED_ATTN": "0"}, {"GL3_PF_GEMM3_TALL": "-1"},
-                                 {"GL3_PF_GEMM3_TALL": "4"}, {"GL3_PF_GEMM3_TALL": "5", "GL3_PF_GEMM3_TALL_KB": "1"}, {"GL3_PF_GEMM3_TALL": "6"},
-                                 {"GL3_PF_GEMM3_TALL": "7", "GL3_PF_GEMM3_SHAPE": "1"}, {"GL3_PF_GEMM3_SHAPE": "2"}, {"GL3_PF_GEMM3_SHAPE": "3"}],
-                         ids=["r5-kernels", "r3-kernels", "g3-128x128", "tall4", "tall5-one-block-stages", "tall6", "tall7-shape1", "shape2", "shape3"])
+@pytest.mark.parametrize("env", [{"GL3_PF_GEMM3": "0"}, {"GL3_PF_GEMM3_TALL": "-1"}, {"GL3_PF_GEMM3_TALL": "4"}, {"GL3_PF_GEMM3_TALL": "5", "GL3_PF_GEMM3_TALL_KB": "1"},
+                                 {"GL3_PF_GEMM3_TALL": "7", "GL3_PF_GEMM3_SHAPE": "1"}, {"GL3_PF_GEMM3_TALL": "6", "GL3_PF_GEMM3_SHAPE": "2"}],
+                         ids=["r5-kernels", "g3-128x128", "tall4", "tall5-one-block-stages", "tall7-shape1", "tall6-shape2"])
 def test_prefill_parity_of_a_gemm_form(env):
     e = dict(os.environ, **env)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_decode.py"), os.path.join(ROOT, "tests", "test_gpu_fullsize.py"),
