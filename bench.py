@@ -319,7 +319,7 @@ def main():
         # matrix-pipe time of the r4 kernel: three 32-cycle MFMAs per (32 x 32 tile, block) — the int8 dot and the two exact bf16-split
         # outer products s = wScale aScale, -B s (gl3_prefill_gemm2.h) — on 4 SIMDs x CUs; the honest MFMA-bound floor of this arithmetic
         tiles_blocks = 2 * (cfg.hidden // world // 32) * ((ntok_pp + 31) // 32) * (cfg.dim // 32)
-        roofline_pp = dict(bound="mfma", kernel="pf_gemm2_kernel<EPI_SWIGLU> (gate/up Q8_0 x int8-activation GEMM + SwiGLU, 2 x %dx%d x %d tokens)" %
+        roofline_pp = dict(bound="mfma", kernel="pf_gemm3t_kernel (tall one-round tiling) / pf_gemm3_kernel (gate/up Q8_0 x int8-activation GEMM + SwiGLU, 2 x %dx%d x %d tokens)" %
                            (cfg.hidden // world, cfg.dim, ntok_pp),
                            achieved=g["tops"], peak=INT8_MFMA_PEAK_TOPS, unit="TOP/s", frac=g["frac_of_int8_mfma_peak"], traffic=None,
                            avg_us=g["avg_us"], int8_ops_per_launch=g["int8_ops_per_launch"],
@@ -328,7 +328,8 @@ def main():
                            note="the int8-peak fraction counts only the int8 dot; the reference's per-32-block f32 arithmetic "
                                 "(result += isum * (wScale * aScale), one rounding per operation) cannot reach 50 % of the int8 peak bit-exactly: r3 needed 4 VALU "
                                 "lane-ops per output and block (VALU-bound), r4 moves two of them onto the matrix pipe as exact outer products, which "
-                                "makes the pipe 3 x 32 cycles per tile-block = 1/3 int8 work at best; measured breakdown in profiles/r04_gemm_experiments.md",
+                                "makes the pipe 3 x 32 cycles per tile-block = 1/3 int8 work at best; r6 (gl3_prefill_gemm3.h / gl3_prefill_gemm3t.h): mid-stage "
+                                "barrier + partial vmcnt, scale-operand side table, chunk-major activations, one-round tall tiles; profiles/r06_prefill_gemm.md",
                            gemms=pk, method="one HIP event pair around 3 sweeps x %d layers per GEMM class" % cfg.n_layers)
         if peaks:
             roofline_pp["peak_measured"] = peaks["int8_mfma_tops"]
@@ -353,13 +354,15 @@ def main():
         import glob
         import hashlib
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_summary.csv")))[-1]
-        src_sha = hashlib.sha256(open(os.path.join(ROOT, "gpullama3.java_amd", "csrc", "gl3_decode_kernels.h"), "rb").read()).hexdigest()
+        # every file the dominant kernel and its launch geometry are built from (r5 hashed the kernel header alone: an edit to the launch code left the hash valid)
+        src_sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "gpullama3.java_amd", "csrc", n), "rb").read()
+                                          for n in ("gl3_decode_kernels.h", "gl3_seqsum.h", "gl3_ctx.h", "gl3_api.hip", "Makefile"))).hexdigest()
         meta_path = f.replace(".csv", ".meta.json")
         meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
         for r in csv.reader(open(f)):
             if "matvec_q8t_kernel<0, 2" in r[0] and world == 1 and args.model == "llama-3-8b" and args.wtype == "q8_0":
                 src = os.path.relpath(f, ROOT) + " (FETCH_SIZE x 2, separate rocprofv3 --pmc pass of this command)"
-                if meta.get("gl3_decode_kernels_sha256") == src_sha:
+                if meta.get("kernel_sources_sha256") == src_sha:
                     roofline["traffic"] = int(r[-1])
                     roofline["method"] += "; traffic: not measured in this run — " + src + ", taken on this build's kernel source (sha256 " + src_sha[:12] + ")"
                 else:

@@ -26,6 +26,7 @@ struct GemmArgs {
     float* out; int out_stride;           // EPI_STORE / EPI_SWIGLU: out[b*stride + row]; EPI_RESID: out +=
     float out_scale;                      // EPI_STORE / EPI_RESID: result *= out_scale first (Granite; 1 otherwise, exact)
     uint8_t* XQo; float* XSo;             // bdw_gemm_kernel<EPI_SWIGLU, .., QOUT>: hb leaves the kernel quantised (XQ2 / XS2 layout)
+    uint8_t* XPo;                         // pf_gemm3t_kernel<.., QOUT>: the quantised hb's scale-operand table (XQo = its int8 chunks)
     const uint8_t* XP; int xp_tok;        // pf_gemm3_kernel: activation scale operands XP[block][half][xp_tok token slots][16 B] (gl3_prefill_gemm3.h)
 };
 

@@ -28,6 +28,7 @@ void gl3_gemm2_launch(int epi, const GemmArgs& a, int rows, int ntok, int mode, 
 hipError_t gl3_gemm2_allow_lds();
 // r6: the same arithmetic behind a mid-stage barrier / partial-vmcnt operand ring, every GEMM class (gl3_prefill_gemm3.h)
 void gl3_gemm3_launch(int epi, const GemmArgs& a, int rows, int ntok, hipStream_t s);
+bool gl3_gemm3_swiglu_quantises(int rows, int ntok);
 hipError_t gl3_gemm3_allow_lds();
 
 struct gl3_prefill_state {
@@ -38,6 +39,8 @@ struct gl3_prefill_state {
     float* XS = nullptr;                // [M][maxk/32] activation scales
     uint8_t* XP = nullptr;              // [maxk/32 + 4][2 lane halves][xp_tok][16 B] the activation scales as bf16 MFMA operands (pf_gemm3_kernel)
     int xp_tok = 0;                     //   token slots per block: max_batch rounded up to the GEMM's 128-token tile
+    uint8_t* XQh = nullptr;             // second operand set of the > 64-token path: hb quantised by the gate + up GEMM's own epilogue (pf_gemm3t_kernel<.., QOUT>)
+    uint8_t* XPh = nullptr;             //   while other workgroups still read XQ / XP
     uint8_t* XQb = nullptr;             // second small-batch operand buffer: hb quantised by the gate/up kernel's own epilogue
     float* XSb = nullptr;               //   (its input still being read by other workgroups)
     float* QKV = nullptr;               // [M][q_dim + 2 kv_dim]
@@ -1167,6 +1170,12 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     p->xp_tok = (int)MQP;
     GL3_HIP(hipMalloc((void**)&p->XP, (size_t)(p->maxk / 32 + 4) * p->xp_tok * 32 + GL3_TAIL_PAD));
     GL3_HIP(hipMemsetAsync(p->XP, 0, (size_t)(p->maxk / 32 + 4) * p->xp_tok * 32 + GL3_TAIL_PAD, ctx->stream));
+    if (M > 64 && d.tp_size == 1) {
+        GL3_HIP(hipMalloc((void**)&p->XQh, MQP * p->maxk + GL3_TAIL_PAD));
+        GL3_HIP(hipMalloc((void**)&p->XPh, (size_t)(p->maxk / 32 + 4) * p->xp_tok * 32 + GL3_TAIL_PAD));
+        GL3_HIP(hipMemsetAsync(p->XQh, 0, MQP * p->maxk + GL3_TAIL_PAD, ctx->stream));
+        GL3_HIP(hipMemsetAsync(p->XPh, 0, (size_t)(p->maxk / 32 + 4) * p->xp_tok * 32 + GL3_TAIL_PAD, ctx->stream));
+    }
     GL3_HIP(hipMalloc((void**)&p->XQb, (size_t)BD_TS_MAX * p->maxk + GL3_TAIL_PAD));
     GL3_HIP(hipMalloc((void**)&p->XSb, (size_t)BD_TS_MAX * (p->maxk / 32) * 4 + GL3_TAIL_PAD));
     GL3_HIP(hipMemsetAsync(p->XQb, 0, (size_t)BD_TS_MAX * p->maxk, ctx->stream));
@@ -1205,7 +1214,7 @@ void gl3_prefill_free(gl3_ctx* ctx) {
     if (!p) return;
     for (auto ge : p->step_graphs) if (ge) hipGraphExecDestroy(ge);
     auto f = [](void* q) { if (q) hipFree(q); };
-    f(p->tokens); f(p->XQ); f(p->XS); f(p->XP); f(p->XQb); f(p->XSb); f(p->QKV); f(p->ATT); f(p->seqpos); f(p->amax); f(p->amx_v); f(p->amx_i); f(p->XN); f(p->HB2);
+    f(p->tokens); f(p->XQ); f(p->XS); f(p->XP); f(p->XQh); f(p->XPh); f(p->XQb); f(p->XSb); f(p->QKV); f(p->ATT); f(p->seqpos); f(p->amax); f(p->amx_v); f(p->amx_i); f(p->XN); f(p->HB2);
     if (!p->in_arena) { f(p->X); f(p->AO); f(p->HB); f(p->LOGITS); }
     delete p;
     ctx->pf = nullptr;
@@ -1286,7 +1295,12 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
     // GL3_PF_GEMM2=1: A/B form (-B s on the VALU).
     // r6: every class on pf_gemm3_kernel (mid-stage barrier, partial vmcnt, scale-operand side table, chunk-major activations);
     // GL3_PF_GEMM3=0 restores the r5 choice below (the quantiser then writes the row layout those kernels read)
-    if (pf_use_gemm3()) { gl3_gemm3_launch(EPI, a, w.rows, ntok, ctx->stream); return; }
+    if (pf_use_gemm3()) {
+        if (quantised_out) { a.XQo = p->XQh; a.XPo = p->XPh; }          // gate + up: hb as the down projection's operand (tall tiling, one rank)
+        if (second_operand) { a.XQ = p->XQh; a.XP = p->XPh; }            // down: reads it
+        gl3_gemm3_launch(EPI, a, w.rows, ntok, ctx->stream);
+        return;
+    }
     static const int g2 = getenv("GL3_PF_GEMM2") ? atoi(getenv("GL3_PF_GEMM2")) : 2;
     static const bool g2_all = getenv("GL3_PF_GEMM2_ALL") && atoi(getenv("GL3_PF_GEMM2_ALL"));
     if (g2 && (EPI == EPI_SWIGLU || g2_all)) { gl3_gemm2_launch(EPI, a, w.rows, ntok, g2, ctx->stream); return; }
@@ -1530,7 +1544,9 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         }
         hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.ffn_norm, d.rms_eps,
                            p->XQ, p->XS, p->maxk, bd_tslots(n), (pf_use_gemm3() && n > 64) ? (uint2*)p->XP : nullptr, p->xp_tok);
-        if (fuse_q) {
+        // > 64 tokens on one rank: the tall gate + up tiling writes hb quantised (no f32 round trip, no quantise launch)
+        const bool fuse_big = !fuse_off && n > 64 && d.tp_size == 1 && p->XQh && pf_use_gemm3() && gl3_gemm3_swiglu_quantises(L.w1.rows, n);
+        if (fuse_q || fuse_big) {
             launch_gemm<EPI_SWIGLU>(ctx, L.w1, &L.w3, n, HBr, hid, 1.0f, false, true);
             launch_gemm<EPI_RESID>(ctx, L.w2, nullptr, n, Xr, dml, ctx->resid_scale, true);
         } else {

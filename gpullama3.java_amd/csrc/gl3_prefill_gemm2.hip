@@ -99,11 +99,37 @@ static hipError_t g3_allow_epi() {
     return e;
 }
 template <int NFR, int KBT>
-static hipError_t g3t_allow() { return hipFuncSetAttribute((const void*)pf_gemm3t_kernel<NFR, KBT>, hipFuncAttributeMaxDynamicSharedMemorySize, g3t_lds_bytes(NFR, KBT)); }
+static hipError_t g3t_allow() {
+    hipError_t e = hipFuncSetAttribute((const void*)pf_gemm3t_kernel<NFR, KBT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g3t_lds_bytes(NFR, KBT));
+    if (e == hipSuccess && KBT == 2) e = hipFuncSetAttribute((const void*)pf_gemm3t_kernel<NFR, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g3t_lds_bytes(NFR, 2));
+    return e;
+}
 template <int NFR, int KBT>
 static void g3t_launch(GemmArgs a, int rows, int ntok, hipStream_t s) {
     a.ntt = (ntok + 127) / 128; a.nrt = (rows + 32 * NFR - 1) / (32 * NFR);
-    hipLaunchKernelGGL((pf_gemm3t_kernel<NFR, KBT>), dim3(8 * ((a.ntt * a.nrt + 7) / 8)), dim3(512), g3t_lds_bytes(NFR, KBT), s, a);
+    const dim3 g(8 * ((a.ntt * a.nrt + 7) / 8));
+    if (KBT == 2 && a.XPo) hipLaunchKernelGGL((pf_gemm3t_kernel<NFR, 2, true>), g, dim3(512), g3t_lds_bytes(NFR, 2), s, a);      // hb leaves the kernel quantised
+    else hipLaunchKernelGGL((pf_gemm3t_kernel<NFR, KBT, false>), g, dim3(512), g3t_lds_bytes(NFR, KBT), s, a);
+}
+// the tiling the gate + up launch of (rows, ntok) takes: 0 = 128 x 128, 4 .. 7 = tall with that many row fragments (gl3_prefill_gemm3t.h)
+static int g3_tall_choice(int rows, int ntok, int* kb) {
+    static const int tall_env = getenv("GL3_PF_GEMM3_TALL") ? atoi(getenv("GL3_PF_GEMM3_TALL")) : 0;
+    static const int tall_kb = getenv("GL3_PF_GEMM3_TALL_KB") ? atoi(getenv("GL3_PF_GEMM3_TALL_KB")) : 2;      // blocks per K stage of the tall tiling (1 | 2)
+    if (kb) *kb = tall_kb;
+    const int ntt = (ntok + 127) / 128;
+    int best = 0, cost = ((ntt * ((rows + 63) / 64) + 511) / 512) * 8;      // 128 x 128: two workgroups per CU, 8 result tiles per SIMD and round
+    for (int nfr = 4; nfr <= 7 && tall_env == 0; ++nfr) {                   // tall: one workgroup per CU, 2 NFR tiles per SIMD and round
+        const int c = ((ntt * ((rows + 32 * nfr - 1) / (32 * nfr)) + 255) / 256) * 2 * nfr;
+        if (c < cost) { cost = c; best = nfr; }
+    }
+    if (tall_env >= 4 && tall_env <= 7) best = tall_env;
+    return best;
+}
+// true when the gate + up launch can write hb quantised (pf_gemm3t_kernel<.., QOUT>): the caller then passes XQo / XPo and skips the quantise launch
+bool gl3_gemm3_swiglu_quantises(int rows, int ntok) {
+    static const bool off = getenv("GL3_PF_GEMM3_QOUT") && atoi(getenv("GL3_PF_GEMM3_QOUT")) == 0;
+    int kb = 0;
+    return !off && g3_tall_choice(rows, ntok, &kb) != 0 && kb == 2 && rows % 32 == 0;
 }
 hipError_t gl3_gemm3_allow_lds() {
     hipError_t e = g3_allow_epi<EPI_SWIGLU>();
@@ -125,16 +151,10 @@ static void g3_dispatch(GemmArgs a, int rows, int ntok, hipStream_t s) {
     a.ntt = ntt;
     auto grid = [&](int nrt) { a.nrt = nrt; return dim3(8 * ((ntt * nrt + 7) / 8)); };
     if constexpr (EPI == EPI_SWIGLU) {
-        // gate + up: the 128 x 128 tiling (two workgroups per CU, 8 result tiles per SIMD and round) or a tall tiling (one workgroup per CU, 2 NFR tiles per
-        // SIMD and round, gl3_prefill_gemm3t.h) — whichever leaves a SIMD fewer tile-steps.  GL3_PF_GEMM3_TALL: -1 never, 4 .. 7 that shape always.
-        static const int tall_env = getenv("GL3_PF_GEMM3_TALL") ? atoi(getenv("GL3_PF_GEMM3_TALL")) : 0;
-        static const int tall_kb = getenv("GL3_PF_GEMM3_TALL_KB") ? atoi(getenv("GL3_PF_GEMM3_TALL_KB")) : 2;      // blocks per K stage of the tall tiling (1 | 2)
-        int best = 0, cost = ((ntt * ((rows + 63) / 64) + 511) / 512) * 8;
-        for (int nfr = 4; nfr <= 7 && tall_env == 0; ++nfr) {
-            const int c = ((ntt * ((rows + 32 * nfr - 1) / (32 * nfr)) + 255) / 256) * 2 * nfr;
-            if (c < cost) { cost = c; best = nfr; }
-        }
-        if (tall_env >= 4 && tall_env <= 7) best = tall_env;
+        // gate + up: the 128 x 128 tiling or a tall tiling (gl3_prefill_gemm3t.h) — whichever leaves a SIMD fewer tile-steps (g3_tall_choice).
+        // GL3_PF_GEMM3_TALL: -1 never, 4 .. 7 that shape always.
+        int tall_kb = 2;
+        const int best = g3_tall_choice(rows, ntok, &tall_kb);
 #define GL3_G3T(N_) do { if (tall_kb == 1) g3t_launch<N_, 1>(a, rows, ntok, s); else g3t_launch<N_, 2>(a, rows, ntok, s); } while (0)
         switch (best) {
         case 4: GL3_G3T(4); break;

@@ -24,7 +24,11 @@ __host__ __device__ constexpr int g3t_lds_bytes(int nfr, int kbt) {
     return G3_RING * g3t_stage_bytes(nfr, kbt) > 16384 * nfr ? G3_RING * g3t_stage_bytes(nfr, kbt) : 16384 * nfr;
 }
 
-template <int NFR, int KBT>
+// QOUT: hb = silu(gate) * up leaves the kernel as the down projection's operand — int8 chunks (XQ3 layout), block scales and the scale-operand table
+// entries of gl3_prefill_gemm3.h — instead of f32: a result tile's 32 rows ARE one 32-element activation block of a token (16 values in the lane,
+// 16 in lane ^ 32), so the block maximum is a register maximum and one cross-lane exchange.  Saves the f32 round trip of hb and the quantise launch
+// (pf_norm_quant_kernel<PQ_PLAIN>, 15 us per 8B layer at 512 tokens).  One rank only (under tensor parallelism the f32 hb is gathered first).
+template <int NFR, int KBT, bool QOUT = false>
 __global__ __launch_bounds__(512, 2) void pf_gemm3t_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NW = 8, NT = 512, RPM = 32 * NFR, AROWS = 2 * RPM, TOK = 128, RING = G3_RING;
@@ -269,21 +273,57 @@ __global__ __launch_bounds__(512, 2) void pf_gemm3t_kernel(const GemmArgs a) {
     auto finish = [&](auto fc, auto gatec) {       // fragment f: this wavefront holds the gate tile (gatec) or the up tile; the other comes from X
         constexpr int f = decltype(fc)::value;
         constexpr bool have_gate = decltype(gatec)::value;
-        if (b >= a.ntok) return;
+        if (!QOUT && b >= a.ntok) return;
+        float o[16];
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const int row = row0 + f * 32 + 8 * q4 + 4 * hi;
-            float o[4];
+        for (int r = 0; r < 16; ++r) {
+            const float other = X[((wc * NFR + f) * 16 + r) * 64 + lane];
+            float g = have_gate ? acc[f][r] : other;
+            const float up = have_gate ? other : acc[f][r];
+            g = g / (float)(1.0 + exp(-(double)g));
+            o[r] = g * up;
+        }
+        if constexpr (!QOUT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * q4 + e;
-                const float other = X[((wc * NFR + f) * 16 + r) * 64 + lane];
-                float g = have_gate ? acc[f][r] : other;
-                const float up = have_gate ? other : acc[f][r];
-                g = g / (float)(1.0 + exp(-(double)g));
-                o[e] = g * up;
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int row = row0 + f * 32 + 8 * q4 + 4 * hi;
+                if (row < a.rows) *reinterpret_cast<float4*>(a.out + (size_t)b * a.out_stride + row) = make_float4(o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3]);
             }
-            if (row < a.rows) *reinterpret_cast<float4*>(a.out + (size_t)b * a.out_stride + row) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            // Q8_0 activation quantisation of the block (Q8_0FloatTensor.java:96-118; quantize_quad_pack's arithmetic): rows of a block = k index
+            float amax = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(o[r]));
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            const float qs = amax / 127.0f;
+            const float ainv = qs != 0.f ? 1.0f / qs : 0.f;
+            const int blk = (row0 + f * 32) >> 5;
+            if (row0 + f * 32 < a.rows && b < a.ntok) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {           // rows 8 q4 + 4 hi .. + 3 = bytes (8 q4 + 4 hi) & 15 of chunk 2 blk + (q4 >> 1)
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sv = o[4 * q4 + e] * ainv;
+                        packed |= (uint32_t)((int)(sv + copysignf(0.5f, sv)) & 0xFF) << (8 * e);
+                    }
+                    *reinterpret_cast<uint32_t*>(a.XQo + ((size_t)(2 * blk + (q4 >> 1)) * a.xp_tok + b) * 16 + ((8 * q4 + 4 * hi) & 15)) = packed;
+                }
+                if (hi == 0) {
+                    const float qf = (float)(_Float16)qs;                              // float16ToFloat(floatToFloat16(qs))
+                    const float ahi = __uint_as_float(__float_as_uint(qf) & 0xFFFF0000u), alo = qf - ahi;
+                    auto pk = [](float h, float l) { return (__float_as_uint(h) >> 16) | (__float_as_uint(l) & 0xFFFF0000u); };
+                    const uint32_t pr = pk(ahi, alo), q0 = pk(ahi * -8388608.f, alo * -8388608.f), q1 = pk(ahi * -4194304.f, alo * -4194304.f);
+                    uint4* xp = reinterpret_cast<uint4*>(a.XPo);
+                    xp[((size_t)blk * 2 + 0) * a.xp_tok + b] = make_uint4(pr, pr, q0, q0);
+                    xp[((size_t)blk * 2 + 1) * a.xp_tok + b] = make_uint4(0u, 0u, q1, q1);
+                    if (blk == (a.rows >> 5) - 1)                                        // ragged K of the consumer: zero operands for the padded blocks
+                        for (int pb = blk + 1; pb < ((blk + 4) & ~3); ++pb) {
+                            xp[((size_t)pb * 2 + 0) * a.xp_tok + b] = make_uint4(0u, 0u, 0u, 0u);
+                            xp[((size_t)pb * 2 + 1) * a.xp_tok + b] = make_uint4(0u, 0u, 0u, 0u);
+                        }
+                }
+            }
         }
     };
     // two straight-line branches (a shared loop with a run-time fragment index would move the accumulators to scratch)

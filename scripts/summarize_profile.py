@@ -38,8 +38,9 @@ if os.path.isdir(pmc_dir):
     # which kernel source the counters belong to: bench.py fills roofline.traffic from this table only while the hash still matches
     import hashlib
     import json
-    hdr = os.path.join(os.path.dirname(out), "gpullama3.java_amd", "csrc", "gl3_decode_kernels.h")
-    json.dump({"gl3_decode_kernels_sha256": hashlib.sha256(open(hdr, "rb").read()).hexdigest(),
+    csrc = os.path.join(os.path.dirname(out), "gpullama3.java_amd", "csrc")
+    files = ("gl3_decode_kernels.h", "gl3_seqsum.h", "gl3_ctx.h", "gl3_api.hip", "Makefile")      # the dominant decode kernel + its launch geometry + build flags (bench.py hashes the same list)
+    json.dump({"kernel_sources_sha256": hashlib.sha256(b"".join(open(os.path.join(csrc, n), "rb").read() for n in files)).hexdigest(), "files": list(files),
                "command": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 1 --no-pp --no-cpu-baseline"},
               open(os.path.join(out, tag + "_pmc_fetch_summary.meta.json"), "w"))
 print("wrote", [x for x in os.listdir(out) if x.startswith(tag)])
