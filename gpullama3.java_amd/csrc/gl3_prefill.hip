@@ -826,7 +826,8 @@ __host__ __device__ constexpr size_t fa_smem_bytes(int hs, int kvmul, int sstrid
 template <int HS>
 __global__ __launch_bounds__(512) void pf_attn_fused_kernel(const float* __restrict__ Q, int q_stride, const float* __restrict__ kc, const float* __restrict__ vc,
                                                             float* __restrict__ out, int out_stride, int n_kv_heads, int kvmul, int kv_dim,
-                                                            int pos0, int ntok, float att_mul, int sstride) {
+                                                            int pos0, int ntok, float att_mul, int sstride,
+                                                            uint8_t* __restrict__ xq_out = nullptr, uint4* __restrict__ xp_out = nullptr, int xp_tok = 0) {
     extern __shared__ __attribute__((aligned(16))) float fa_sm[];
     constexpr int PITCH = HS + 4, H4 = HS / 4, NCOL = HS > 64 ? 2 : 1;
     float* Ssc = fa_sm;                                             // [kvmul][FA_TB][sstride] score -> softmax rows
@@ -1042,6 +1043,35 @@ __global__ __launch_bounds__(512) void pf_attn_fused_kernel(const float* __restr
     fa_t3 = __builtin_readcyclecounter();
     if (lane == 0 && kvh == 0 && (tile % 9) == 0) printf("fa tile %d wave %d: scores %llu softmax %llu pv %llu\n", tile, wave, fa_t1 - fa_t0, fa_t2 - fa_t1, fa_t3 - fa_t2);
 #endif
+    if (NCOL == 2 && xq_out) {
+        // r6: the attention output leaves the kernel as the wo projection's operand (int8 chunks XQ3[k / 16][token slot][16 B] + the scale-operand table
+        // of gl3_prefill_gemm3.h) instead of f32 + a quantise launch.  A 32-element block of a token's row = 32 consecutive columns = the 16 lanes of a
+        // DPP row, two columns each; Q8_0FloatTensor.java:96-118 arithmetic as quantize_quad_pack.
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tb = 4 * grp + u;
+            float amax = fmaxf(fabsf(acc[u][0]), fabsf(acc[u][NCOL - 1]));
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+            const float qs = amax / 127.0f;
+            const float ainv = qs != 0.f ? 1.0f / qs : 0.f;
+            const float s0 = acc[u][0] * ainv, s1 = acc[u][NCOL - 1] * ainv;
+            const uint32_t q0 = (uint32_t)((int)(s0 + copysignf(0.5f, s0)) & 0xFF), q1 = (uint32_t)((int)(s1 + copysignf(0.5f, s1)) & 0xFF);
+            if (tb >= nb) continue;
+            const int col = head * HS + 2 * lane, b = b0 + tb;
+            *reinterpret_cast<uint16_t*>(xq_out + ((size_t)(col >> 4) * xp_tok + b) * 16 + (col & 15)) = (uint16_t)(q0 | (q1 << 8));
+            if ((lane & 15) == 0) {
+                const float qf = (float)(_Float16)qs;
+                const float ahi = __uint_as_float(__float_as_uint(qf) & 0xFFFF0000u), alo = qf - ahi;
+                auto pk = [](float h, float l) { return (__float_as_uint(h) >> 16) | (__float_as_uint(l) & 0xFFFF0000u); };
+                const uint32_t pr = pk(ahi, alo), n0 = pk(ahi * -8388608.f, alo * -8388608.f), n1 = pk(ahi * -4194304.f, alo * -4194304.f);
+                const int blk = col >> 5;
+                xp_out[((size_t)blk * 2 + 0) * xp_tok + b] = make_uint4(pr, pr, n0, n0);
+                xp_out[((size_t)blk * 2 + 1) * xp_tok + b] = make_uint4(0u, 0u, n1, n1);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int tb = 4 * grp + u;
@@ -1321,7 +1351,8 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
 
 // RoPE + KV write + attention of layer l for the n tokens whose raw q | k | v rows are in p->QKV -> AOr (this rank's chunk of the
 // attention output).  fuse_q: static-batched decode on one rank writes the output as the wo projection's int8 operand instead.
-static void pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, float* AOr, bool fuse_q) {
+// returns true when the attention output was written as the wo projection's int8 operand (no quantise launch needed)
+static bool pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, float* AOr, bool fuse_q) {
     gl3_prefill_state* p = ctx->pf;
     const gl3_model_desc& d = ctx->d;
     hipStream_t s = ctx->stream;
@@ -1357,7 +1388,7 @@ static void pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
         ha.group = bd_group;
         if (fuse_q) { ha.xq_out = p->XQ; ha.xs_out = p->XS; ha.xq_slots = bd_tslots(n); }
         attn_head_dispatch(hs, [&](auto kern) { hipLaunchKernelGGL(kern, dim3(H / bd_group, n), dim3(256), attn_head_smem(hs, bd_group), s, ha); });
-        return;
+        return fuse_q;
     }
     hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(H + KVH, n), dim3(64), 0, s, ra);
     const bool tiled = one_seq >= 0 && kvmul <= 4 && (hs == 32 || hs == 64 || hs == 128) && (size_t)(max_pos + 1) * 4 <= 60 * 1024;
@@ -1369,13 +1400,18 @@ static void pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
         const size_t sms = fa_smem_bytes(hs, kvmul, fa_sstride);
         const float* kc1 = aa.kcache + (size_t)one_seq * ctx->kv_seq_stride;
         const float* vc1 = aa.vcache + (size_t)one_seq * ctx->kv_seq_stride;
+        // r6: > 64 tokens on one rank with head size 128: the output is written quantised for the wo GEMM (pf_gemm3_kernel's operand layout)
+        static const bool qao_off = getenv("GL3_PF_ATTN_QOUT") && atoi(getenv("GL3_PF_ATTN_QOUT")) == 0;
+        const bool qao = !qao_off && hs == 128 && n > 64 && d.tp_size == 1 && pf_use_gemm3() && p->XP && (getenv("GL3_NO_FUSED_QUANT") == nullptr || atoi(getenv("GL3_NO_FUSED_QUANT")) == 0);
+        uint8_t* xqo = qao ? p->XQ : nullptr;
+        uint4* xpo = qao ? reinterpret_cast<uint4*>(p->XP) : nullptr;
 #define GL3_FA(HS_) hipLaunchKernelGGL((pf_attn_fused_kernel<HS_>), dim3(KVH * ntile), dim3(128 * kvmul), sms, s, aa.Q, aa.q_stride, kc1, vc1, aa.out, aa.out_stride, \
-                                       KVH, kvmul, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride)
+                                       KVH, kvmul, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride, xqo, xpo, p->xp_tok)
         if (hs == 128) GL3_FA(128);
         else if (hs == 64) GL3_FA(64);
         else GL3_FA(32);
 #undef GL3_FA
-        return;
+        return qao;
     }
     if (tiled) {
         const int pos0 = max_pos + 1 - n, ntt = (n + PA_TB - 1) / PA_TB;
@@ -1399,6 +1435,7 @@ static void pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
         aa.win = ctx->attn_win;
         hipLaunchKernelGGL(pf_attn_softmax_pv_kernel, dim3(H * ((d.head_size + 63) / 64), n), dim3(64), (size_t)ctx->attn_win * 4 + 16, s, aa);
     }
+    return false;
 }
 
 static bool env_flag_cached_vlq_mfma() { static const bool on = env_flag("GL3_VLQ_MFMA", true); return on; }
@@ -1524,8 +1561,7 @@ static int32_t pf_layers(gl3_ctx* ctx, int n, int max_pos, int one_seq) {
         hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_NORM>), dim3(n), dim3(256), nq_smem(d.dim), s, p->X, d.dim, dml, L.attn_norm, d.rms_eps,
                            p->XQ, p->XS, p->maxk, bd_tslots(n), (pf_use_gemm3() && n > 64) ? (uint2*)p->XP : nullptr, p->xp_tok);
         launch_gemm<EPI_STORE>(ctx, L.wqkv, nullptr, n, p->QKV, qkv_dim);
-        const bool quantised_ao = fuse_q && one_seq < 0 && fused_decode;
-        pf_attention(ctx, l, n, max_pos, one_seq, AOr, quantised_ao);
+        const bool quantised_ao = pf_attention(ctx, l, n, max_pos, one_seq, AOr, fuse_q && one_seq < 0 && fused_decode);
         if ((r = gl3_all_gather(ctx, GB_PF_AO, (size_t)n * qd)) != GL3_OK) return r;
         if (!quantised_ao)
             hipLaunchKernelGGL((pf_norm_quant_kernel<PQ_PLAIN>), dim3(n, (ctx->q_dim / 4 + 255) / 256), dim3(256), 0, s, p->AO, ctx->q_dim, qd, (const float*)nullptr,
