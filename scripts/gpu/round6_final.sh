@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-5 closing session: the GPU test suite file by file, the headline bench line, rocprofv3 kernel statistics + separate --pmc passes
+# Round-6 closing session: the GPU test suite file by file, the headline bench line, rocprofv3 kernel statistics + separate --pmc passes
 # (never combined with tracing), and >= 5-step bench lines WITH a cpu_baseline leg for the other configurations.  Every command bounded.
-#   bash scripts/gpu/round5_final.sh gpurun_out/r5_final [tests|bench|prof|lines ...]    (no stage list = all)
+#   bash scripts/gpu/round6_final.sh gpurun_out/r6_final [tests|bench|prof|lines ...]    (no stage list = all)
 set -u
-O=${1:-gpurun_out/r5_final}; shift || true
+O=${1:-gpurun_out/r6_final}; shift || true
 STAGES=${*:-tests bench prof lines depth}
 mkdir -p $O
 export TMPDIR=/tmp
@@ -51,6 +51,7 @@ except Exception as e: print("no json", e)
 PY
   ;;
 depth)
+  # r6: mid-regime rows included
   ( timeout 600 python bench.py --steps 3 --warmup 1 --depth 256,512,1024,4096,16384 --no-pp > $O/bench_8b_depth.json 2> $O/bench_8b_depth.err; echo "depth rc=$?" )
   python - <<PY
 import json
@@ -58,7 +59,7 @@ try:
     d = json.load(open("$O/bench_8b_depth.json")); print("depth:", [(r["test"], r.get("tok_s"), r.get("attention_us_per_layer")) for r in d["depth_rows"]])
 except Exception as e: print("no json", e)
 PY
-  DEPTHS="4096 16384" bash scripts/gpu/r5_prof_depth.sh 2>&1 | grep "gl3::attn\|== depth"
+  DEPTHS="4096 16384" OUT=$(basename $O)/prof_depth bash scripts/gpu/prof_depth.sh 2>&1 | grep "gl3::attn\|== depth"
   ( GL3_CTX=8192 timeout 900 python scripts/native_bench_8b.py llama-3-8b -p 512 -n 128 -pg 512,128 -d 0,4096 -b 512 -r 3 -o jsonl > $O/native_bench_8b.log 2>&1; echo "native rc=$?"; tail -8 $O/native_bench_8b.log )
   ;;
 esac; done
