@@ -299,6 +299,16 @@ def main():
                            "avg_us_instrumented_steps: start/stop events passed into each dispatch (hipExtLaunchKernel), mean over %d "
                            "launches in %d eager decode steps at positions 64.." % (cfg.n_layers, n_prof * cfg.n_layers, n_prof))
 
+    if args.wtype == "q4_0":
+        # r6: the VALU floor of the Q4_0 gate/up matvec beside its HBM fraction.  Main loop of matvec_vl_kernel<WT_Q4_0, EPI_SWIGLU, RMS> (hipcc -S, one trip =
+        # 64 (block, accumulator lane) units): 256 v_fma_mix_f32 + 128 v_pk_add_f16 + 128 v_and_or_b32 + 96 v_pk_add_f32 + 96 v_lshrrev_b32 + 32 v_pk_fma_f32 +
+        # 64 v_cvt_f32_f16 + ~34 moves / address adds = 13.0 VALU instructions per unit; at the measured issue rates of those opcodes
+        # (profiles/r03_valu_op_rates.txt, >= 2 wavefronts per SIMD: 2.04 / 2.09 / 2.08 / 2.15 / 1.17 / 2.15 / 1.94 / 1.2 ns) 25.1 ns per unit and SIMD.
+        units = 2 * (cfg.hidden // world) * 8 * (cfg.dim // 32)
+        floor_us = units / (1024 * 64) * 25.1e-3
+        roofline["valu_floor"] = dict(valu_instructions_per_block_and_lane=13.0, ns_per_block_and_lane=25.1, floor_us=round(floor_us, 2),
+                                      frac_of_valu_floor=round(floor_us / dom["avg_us"], 4),
+                                      note="the nibble unpack + 4 rounded products + 3 adds + 1 fma per 32-element block and accumulator lane bound this kernel, not HBM")
     # measured-achievable peaks of THIS device beside the spec-sheet denominators; frac stays on the spec peak
     peaks = probe_peaks(local_rank) if rank == 0 else None
     if peaks:
