@@ -53,6 +53,47 @@ __global__ __launch_bounds__(512) void link_kernel(float* buf, unsigned* done, i
     }
 }
 
+// r6 (review item 7): the hand-over the r5 table argued away on paper — per-XCD counters instead of ONE word.  Every workgroup of link k bumps
+// done8[16 * xcc_id] (its own XCD's word, 64 bytes apart); lanes 0..7 of the next link's workgroups poll the 8 words.  FENCE = 0 leaves out the agent-scope
+// release / acquire fences (NOT a valid hand-over for data: it isolates the price of the counter traffic from the price of the fences).
+template <int FENCE>
+__global__ __launch_bounds__(512) void link8_kernel(float* buf, unsigned* done8, int wait_for /* per XCD */, int spin_limit, unsigned* err, int work) {
+    __shared__ float red[8];
+    if (wait_for >= 0) {
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            int spins = 0;
+            for (;;) {
+                const bool ok = l >= 8 || (int)(__hip_atomic_load(done8 + 16 * l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)wait_for) >= 0;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > spin_limit) { *err = 1; break; }
+            }
+        }
+        __syncthreads();
+        if (FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    float v = buf[(blockIdx.x * 512 + threadIdx.x) & 4095];
+    for (int i = 0; i < work; ++i) v = v * 1.0000001f + 1e-7f;
+    v += __shfl_xor(v, 1, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0;
+        for (int i = 0; i < 8; ++i) s += red[i];
+        buf[4096 + blockIdx.x] = s;
+    }
+    if (wait_for >= 0) {
+        if (FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            __hip_atomic_fetch_add(done8 + 16 * (xcc & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 int main() {
     hipStream_t s;
     CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -109,6 +150,32 @@ int main() {
             printf("chain of %d links (512 wgs x 512 thr, work %d): mode %d (%s): %.2f us per link on the device, host enqueue %.2f us per launch, err %u\n", N, work, mode,
                    mode == 0 ? "queue barrier" : mode == 1 ? "any-order + counter wait" : "queue barrier + counter wait", ms * 1e3 / N,
                    std::chrono::duration<double, std::micro>(h1 - h0).count() / N, *err);
+        }
+    }
+    // ---------------------------------------------------------------- 3. r6: per-XCD counters (workgroup b runs on XCD b % 8: 64 arrivals per word and link)
+    unsigned* done8;
+    CK(hipMalloc((void**)&done8, 8 * 64));
+    for (int work : {0, 2000}) {
+        for (int fence = 1; fence >= 0; --fence) {
+            CK(hipMemset(done8, 0, 8 * 64));
+            CK(hipDeviceSynchronize());
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            int limit = 4000000;
+            unsigned base = 0;
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < N; ++i) {
+                int wait_for = (int)base;
+                void* args[] = {&buf, &done8, &wait_for, &limit, &err, (void*)&work};
+                CK(hipExtLaunchKernel(fence ? (const void*)link8_kernel<1> : (const void*)link8_kernel<0>, dim3(WG), dim3(512), args, 0, s, nullptr, nullptr, 0));
+                base += WG / 8;
+            }
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("chain of %d links (512 wgs x 512 thr, work %d): per-XCD counters (8 words), %s: %.2f us per link on the device, err %u\n", N, work,
+                   fence ? "release + acquire fences" : "NO fences (counter traffic alone; not a valid data hand-over)", ms * 1e3 / N, *err);
         }
     }
     return 0;
