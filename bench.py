@@ -196,9 +196,12 @@ def main():
             plan.prefill(toks[:args.n_prompt], 0, batch=batch)
 
     def timed(fn, steps, warmup):
+        import gc
         for _ in range(warmup):
             fn()
         samples = []
+        gc.collect()                            # the timed window measures the forward calls, not a generation-2 collection of the host model's objects
+        gc.disable()                            # (seen as one repetition of five 12 % slower whenever the host copy of the weights was alive)
         barrier()
         t_start = time.perf_counter()
         for _ in range(steps):
@@ -207,6 +210,7 @@ def main():
             samples.append(time.perf_counter() - t1)
         barrier()
         total = time.perf_counter() - t_start
+        gc.enable()
         if dist is not None:
             t = torch.tensor([total], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -431,7 +435,7 @@ def main():
                        "parallelism": ("tp%d (row split, %s all-gathers)" % (world, "peer-write xGMI" if transport != "rccl" else "RCCL")) if world > 1 else "single GPU",
                        "ranks": world, "transport": (transport if world > 1 else None), "fold_mode": (list(plan.tp_fold_mode()) if world > 1 else None),
                        "ctx": cfg.ctx, "tokens": "java.util.Random(42)"},
-            "tg_tok_s_mean": round(float(mean), 3), "tg_tok_s_stddev": round(sd, 3),
+            "tg_tok_s_mean": round(float(mean), 3), "tg_tok_s_stddev": round(sd, 3), "tg_samples_tok_s": [round(args.n_gen / s, 2) for s in tg_samples],
             "pp": pp, "pp_rows": pp_rows,
             **({"depth_rows": depth_rows} if depths else {}),
             "roofline": roofline, "roofline_pp": roofline_pp,
