@@ -47,6 +47,9 @@ struct gl3_prefill_state {
     float* AO = nullptr;                // [M][q_dim] attention output (rank-chunked)
     float* HB = nullptr;                // [M][hidden] (rank-chunked)
     float* ATT = nullptr;               // [M][n_heads][ctx] scores
+    float* TMX = nullptr;               // [M][n_heads][tmx_tiles] per-64-timestep-tile maxima of the score rows (pf_scores_tiled_kernel -> pf_softmax_rows_kernel)
+    float* SUMS = nullptr;              // [M][n_heads] softmax denominators (pf_softmax_rows_kernel -> pf_pv_tiled_kernel)
+    int tmx_tiles = 0;
     int32_t* seqpos = nullptr;          // [2][M]: sequence id, position of every token of the step
     float* LOGITS = nullptr;            // [rows][vocab], grown on demand (batched decode)
     int logits_rows = 0;
@@ -630,6 +633,21 @@ __device__ __forceinline__ void static_for(F&& f) {
         static_for<I + STEP, N, STEP>(f);
     }
 }
+// maximum over the 64 lanes, uniform result: four DPP steps inside the rows of 16 lanes, then one readlane per row (VALU only; wave_max's
+// six ds_bpermute round trips would sit on the score chains' critical path)
+#define GL3_DPP_MAX(V_, CTRL_) V_ = fmaxf(V_, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V_), CTRL_, 0xf, 0xf, false)))
+__device__ __forceinline__ float row8_max(float v) {        // every lane: maximum over its aligned group of 8 lanes
+    GL3_DPP_MAX(v, 0xB1); GL3_DPP_MAX(v, 0x4E); GL3_DPP_MAX(v, 0x141);      // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+    return v;
+}
+__device__ __forceinline__ float wave_max_uniform(float v) {
+    v = row8_max(v); GL3_DPP_MAX(v, 0x140);                                  // row_mirror: the row of 16
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
 // two score chains advance 16 elements: score = score + q[j] * k[j], j ascending (no FMA)
 __device__ __forceinline__ void score_step16(float& s0, float& s1, const v16f_t& qa, const v16f_t& qb, const float4* k) {
 #pragma unroll
@@ -644,7 +662,7 @@ constexpr int PA_TB = 16;
 template <int HS>
 __global__ __launch_bounds__(256) void pf_scores_tiled_kernel(const float* __restrict__ Q, int q_stride, const float* __restrict__ kc,
                                                               float* __restrict__ att, int n_heads, int kvmul, int kv_dim, int ctx,
-                                                              int pos0, int ntok, float att_mul) {
+                                                              int pos0, int ntok, float att_mul, float* __restrict__ tmx, int tmx_tiles) {
     extern __shared__ __attribute__((aligned(16))) float kt[];       // [64][PITCH]
     constexpr int PITCH = HS + 4, H4 = HS / 4;
     const int t = threadIdx.x, nthr = blockDim.x;
@@ -693,9 +711,16 @@ __global__ __launch_bounds__(256) void pf_scores_tiled_kernel(const float* __res
             score_step16(s0, s1, c0, c1, &kr[4]);
         }
         const int b = b0 + tb;
-        if (t0 + r < t1) {
-            if (t0 + r <= pos0 + b) att[((size_t)b * n_heads + head) * ctx + t0 + r] = att_mul != 0.f ? s0 * att_mul : s0 / sqrt_hs;
-            if (tb + 1 < nb && t0 + r <= pos0 + b + 1) att[((size_t)(b + 1) * n_heads + head) * ctx + t0 + r] = att_mul != 0.f ? s1 * att_mul : s1 / sqrt_hs;
+        const float v0 = att_mul != 0.f ? s0 * att_mul : s0 / sqrt_hs, v1 = att_mul != 0.f ? s1 * att_mul : s1 / sqrt_hs;
+        const bool ok0 = t0 + r <= pos0 + b, ok1 = tb + 1 < nb && t0 + r <= pos0 + b + 1;       // (tmax >= pos0 + b: both imply t0 + r < t1)
+        if (ok0) att[((size_t)b * n_heads + head) * ctx + t0 + r] = v0;
+        if (ok1) att[((size_t)(b + 1) * n_heads + head) * ctx + t0 + r] = v1;
+        if (tmx) {      // r6: the tile's maximum per (token, head) row for pf_softmax_rows_kernel (max is order-independent)
+            const float m0 = wave_max_uniform(ok0 ? v0 : -INFINITY), m1 = wave_max_uniform(ok1 ? v1 : -INFINITY);
+            if (r == 0) {
+                if (t0 <= pos0 + b) tmx[((size_t)b * n_heads + head) * tmx_tiles + blockIdx.x] = m0;
+                if (tb + 1 < nb && t0 <= pos0 + b + 1) tmx[((size_t)(b + 1) * n_heads + head) * tmx_tiles + blockIdx.x] = m1;
+            }
         }
     }
 }
@@ -720,11 +745,89 @@ __global__ __launch_bounds__(256) void pf_softmax_kernel(const PfAttnArgs a, int
     for (int i = lane; i < n; i += 64) sc[i] = e_s[i] / sum;
 }
 
+// r6 — softmax of the score rows at depth, R rows per workgroup: 8 worker wavefronts stream the rows' 64-timestep tiles (loads a tile ahead,
+// e_t = (float) exp((double) (s_t - max)) written back in place and into a double-buffered LDS tile), a ninth wavefront runs the strictly
+// sequential sums with lane = row — R chains side by side, LDS reads pinned ahead of the adds (seq_sum_lds_ring).  The row maxima come from
+// the per-tile maxima pf_scores_tiled_kernel leaves in tmx (max is order-independent); the denominators go to `sums` and the division
+// e_t / sum happens where the weights are staged (pf_pv_tiled_kernel) — same operands, same rounding as FloatTensor.softmaxInPlace
+// (J/tensor/standard/FloatTensor.java:196-219: max, exp, sum, divide).  pf_softmax_kernel keeps ONE row per wavefront in LDS: its row loads
+// are one HBM round trip per 64 scores, its sums one chain per wavefront and at most three rows per workgroup fit at 4608 positions:
+// 640 us per 8B layer at pp512 @ d4096 against ~150 us here.  Needs ctx % 4 == 0 (16-byte row starts).
+constexpr int SR_PITCH = 68;
+template <int R>
+__global__ __launch_bounds__(576) void pf_softmax_rows_kernel(const PfAttnArgs a, int nrows_total, const float* __restrict__ tmx, int tmx_tiles, float* __restrict__ sums) {
+    __shared__ __attribute__((aligned(16))) float E[2][R * SR_PITCH];
+    __shared__ float mx_s[R];
+    __shared__ int n_s[R];
+    __shared__ int nmax_s;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int row0 = blockIdx.x * R;
+    if (t == 0) nmax_s = 0;
+    if (t < R * 8) {                                  // 8 lanes fold a row's tile maxima
+        const int r = t >> 3, sub = t & 7, row = row0 + r;
+        const int n = row < nrows_total ? a.pos[row / a.n_heads] + 1 : 0;
+        const int nt = (n + 63) >> 6;
+        float m = -INFINITY;
+        for (int i = sub; i < nt; i += 8) m = fmaxf(m, tmx[(size_t)row * tmx_tiles + i]);
+        m = row8_max(m);
+        if (sub == 0) { mx_s[r] = m; n_s[r] = n; }
+    }
+    __syncthreads();
+    if (t < R) atomicMax(&nmax_s, n_s[t]);
+    __syncthreads();
+    const int ntile = (nmax_s + 63) >> 6;
+    if (wave == 8) {                                  // the chains: lane = row
+        const int r = min(lane, R - 1);
+        float s = 0.f;
+        for (int k = 0; k < ntile; ++k) {
+            __syncthreads();                          // tile k has landed in E[k & 1]; the workers refill it behind the NEXT barrier
+            s = seq_sum_lds_ring(&E[k & 1][r * SR_PITCH], 64, s);
+        }
+        if (lane < R && row0 + lane < nrows_total) sums[row0 + lane] = s;
+        return;
+    }
+    constexpr int NS = (R * 16 + 511) / 512;          // 16-byte slots per worker thread and tile
+    float* rowp[NS]; float mrow[NS]; int nrow[NS], ldsoff[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int q = min(t + 512 * u, R * 16 - 1), r = q >> 4, c4 = q & 15;
+        rowp[u] = a.att + (size_t)min(row0 + r, nrows_total - 1) * a.ctx + 4 * c4;
+        mrow[u] = mx_s[r];
+        nrow[u] = (t + 512 * u < R * 16) ? n_s[r] - 4 * c4 : 0;       // elements of the row at and behind this slot's first column of tile 0
+        ldsoff[u] = r * SR_PITCH + 4 * c4;
+    }
+    float4 cur[NS], nxt[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) cur[u] = *reinterpret_cast<const float4*>(rowp[u]);               // tile 0 (column 4 c4 < 64 <= ctx)
+    for (int k = 0; k < ntile; ++k) {
+        const int kn = min(k + 1, ntile - 1);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {                // unconditional loads: slots past the row's end re-read tile 0 (masked below)
+            const float* src = 64 * kn < nrow[u] ? rowp[u] + 64 * kn : rowp[u];
+            nxt[u] = *reinterpret_cast<const float4*>(src);
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int left = nrow[u] - 64 * k;        // valid elements of this slot: min(left, 4)
+            float4 e;
+            e.x = left > 0 ? (float)exp((double)(cur[u].x - mrow[u])) : 0.f;
+            e.y = left > 1 ? (float)exp((double)(cur[u].y - mrow[u])) : 0.f;
+            e.z = left > 2 ? (float)exp((double)(cur[u].z - mrow[u])) : 0.f;
+            e.w = left > 3 ? (float)exp((double)(cur[u].w - mrow[u])) : 0.f;
+            if (t + 512 * u < R * 16) *reinterpret_cast<float4*>(&E[k & 1][ldsoff[u]]) = e;
+            if (left > 0) *reinterpret_cast<float4*>(rowp[u] + 64 * k) = e;      // in place (columns past the row's end stay inside the row: ctx % 4 == 0)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NS; ++u) cur[u] = nxt[u];
+    }
+}
+
 // Weighted V sum: grid = (n_heads, token tiles), block 256.  V tiles of 64 timesteps are staged in LDS once per
 // workgroup; wavefront w carries tokens 4w..4w+3 of the tile, lane j the output columns j (+64): acc = a_t * v + acc,
 // t ascending.  The softmax weights are wavefront-uniform loads.
 template <int NCOL>
-__global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, int seq, int pos0, int ntok) {
+__global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, int seq, int pos0, int ntok, const float* __restrict__ sums) {
     extern __shared__ __attribute__((aligned(16))) float vt[];        // [64][hs]
     const int hs = a.hs, h4 = hs >> 2, kvmul = a.n_heads / a.n_kv_heads;
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -752,7 +855,9 @@ __global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, in
         }
         for (int i = t; i < PA_TB * 64; i += 256) {                   // entries past a token's position are never used
             const int tb = i >> 6, r = i & 63;
-            as[i] = (tb < nb && t0 + r <= pos0 + b0 + tb) ? a.att[((size_t)(b0 + tb) * a.n_heads + h) * a.ctx + t0 + r] : 0.f;
+            float wv = (tb < nb && t0 + r <= pos0 + b0 + tb) ? a.att[((size_t)(b0 + tb) * a.n_heads + h) * a.ctx + t0 + r] : 0.f;
+            if (sums) wv = wv / sums[(size_t)(b0 + min(tb, nb - 1)) * a.n_heads + h];      // r6: att holds the numerators (pf_softmax_rows_kernel)
+            as[i] = wv;
         }
         __syncthreads();
         const int ttw = min(tt, wmax + 1 - t0);                       // this wavefront's tokens stop at wmax
@@ -1155,6 +1260,9 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
         GL3_HIP(hipMalloc((void**)&p->HB2, M * ctx->hidden_l * 4));
         GL3_HIP(hipMalloc((void**)&p->QKV, M * (ctx->q_dim + 2 * ctx->kv_dim) * 4));
         GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
+        p->tmx_tiles = (d.ctx + 63) / 64;
+        GL3_HIP(hipMalloc((void**)&p->TMX, M * d.n_heads * (size_t)p->tmx_tiles * 4));
+        GL3_HIP(hipMalloc((void**)&p->SUMS, M * d.n_heads * 4));
         GL3_HIP(hipMalloc((void**)&p->seqpos, 2 * M * sizeof(int32_t)));
         GL3_HIP(hipMalloc((void**)&p->amax, M * sizeof(int32_t)));
         GL3_HIP(hipMalloc((void**)&p->amx_v, M * AMX_SPLIT * sizeof(float)));
@@ -1214,6 +1322,9 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_HIP(hipMemsetAsync(p->XS, 0, MQ * (p->maxk / 32) * 4, ctx->stream));
     GL3_HIP(hipMalloc((void**)&p->QKV, M * (ctx->q_dim + 2 * ctx->kv_dim) * 4));
     GL3_HIP(hipMalloc((void**)&p->ATT, M * d.n_heads * (size_t)d.ctx * 4));
+    p->tmx_tiles = (d.ctx + 63) / 64;
+    GL3_HIP(hipMalloc((void**)&p->TMX, M * d.n_heads * (size_t)p->tmx_tiles * 4));
+    GL3_HIP(hipMalloc((void**)&p->SUMS, M * d.n_heads * 4));
     GL3_HIP(hipMalloc((void**)&p->seqpos, 2 * M * sizeof(int32_t)));
     GL3_HIP(hipMalloc((void**)&p->amax, M * sizeof(int32_t)));
     GL3_HIP(hipMalloc((void**)&p->amx_v, M * AMX_SPLIT * sizeof(float)));
@@ -1244,7 +1355,7 @@ void gl3_prefill_free(gl3_ctx* ctx) {
     if (!p) return;
     for (auto ge : p->step_graphs) if (ge) hipGraphExecDestroy(ge);
     auto f = [](void* q) { if (q) hipFree(q); };
-    f(p->tokens); f(p->XQ); f(p->XS); f(p->XP); f(p->XQh); f(p->XPh); f(p->XQb); f(p->XSb); f(p->QKV); f(p->ATT); f(p->seqpos); f(p->amax); f(p->amx_v); f(p->amx_i); f(p->XN); f(p->HB2);
+    f(p->tokens); f(p->XQ); f(p->XS); f(p->XP); f(p->XQh); f(p->XPh); f(p->XQb); f(p->XSb); f(p->QKV); f(p->ATT); f(p->TMX); f(p->SUMS); f(p->seqpos); f(p->amax); f(p->amx_v); f(p->amx_i); f(p->XN); f(p->HB2);
     if (!p->in_arena) { f(p->X); f(p->AO); f(p->HB); f(p->LOGITS); }
     delete p;
     ctx->pf = nullptr;
@@ -1391,7 +1502,10 @@ static bool pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
         return fuse_q;
     }
     hipLaunchKernelGGL(pf_rope_kv_kernel, dim3(H + KVH, n), dim3(64), 0, s, ra);
-    const bool tiled = one_seq >= 0 && kvmul <= 4 && (hs == 32 || hs == 64 || hs == 128) && (size_t)(max_pos + 1) * 4 <= 60 * 1024;
+    // r6: pf_softmax_rows_kernel streams the score rows (no row-fits-LDS limit); GL3_PF_SOFTMAX_ROWS=0: the one-row-per-wavefront kernel
+    static const bool rows_off = getenv("GL3_PF_SOFTMAX_ROWS") && atoi(getenv("GL3_PF_SOFTMAX_ROWS")) == 0;
+    const bool rows_softmax = !rows_off && d.ctx % 4 == 0 && d.ctx >= 64 && p->TMX && p->SUMS;
+    const bool tiled = one_seq >= 0 && kvmul <= 4 && (hs == 32 || hs == 64 || hs == 128) && (rows_softmax || (size_t)(max_pos + 1) * 4 <= 60 * 1024);
     // r4: one launch for scores + softmax + weighted V sum when a tile's score rows fit LDS (GL3_PF_FUSED_ATTN=0: the three kernels)
     static const bool fused_off = getenv("GL3_PF_FUSED_ATTN") && atoi(getenv("GL3_PF_FUSED_ATTN")) == 0;
     const int fa_sstride = ((max_pos + 1 + 63) & ~63) + 4;
@@ -1418,17 +1532,28 @@ static bool pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
         const size_t sms = (size_t)64 * (hs + 4) * 4;
         const dim3 g1(nsplit, KVH, ntt), b1(64 * kvmul);
         const float* kc1 = aa.kcache + (size_t)one_seq * ctx->kv_seq_stride;
-#define GL3_SCORES(HS_) hipLaunchKernelGGL((pf_scores_tiled_kernel<HS_>), g1, b1, sms, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul)
+#define GL3_SCORES(HS_) hipLaunchKernelGGL((pf_scores_tiled_kernel<HS_>), g1, b1, sms, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul, \
+                                           rows_softmax ? p->TMX : nullptr, p->tmx_tiles)
         if (hs == 128) GL3_SCORES(128);
         else if (hs == 64) GL3_SCORES(64);
         else GL3_SCORES(32);
 #undef GL3_SCORES
-        const int npad = (max_pos + 1 + 63) & ~63;
-        int wpw = (int)((60 * 1024) / ((size_t)npad * 4));
-        wpw = wpw > 4 ? 4 : wpw;
-        hipLaunchKernelGGL(pf_softmax_kernel, dim3((n * H + wpw - 1) / wpw), dim3(256), (size_t)wpw * npad * 4, s, aa, n, wpw, npad);
-        if (hs > 64) hipLaunchKernelGGL((pf_pv_tiled_kernel<2>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
-        else hipLaunchKernelGGL((pf_pv_tiled_kernel<1>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n);
+        const float* sums = nullptr;
+        if (rows_softmax) {
+            // r6: R rows per workgroup, the sums as R chains of one wavefront; at least one workgroup per CU when the chunk has the rows
+            const int rows = n * H;
+            sums = p->SUMS;
+            if (rows >= 64 * 256) hipLaunchKernelGGL((pf_softmax_rows_kernel<64>), dim3((rows + 63) / 64), dim3(576), 0, s, aa, rows, p->TMX, p->tmx_tiles, p->SUMS);
+            else if (rows >= 32 * 256) hipLaunchKernelGGL((pf_softmax_rows_kernel<32>), dim3((rows + 31) / 32), dim3(576), 0, s, aa, rows, p->TMX, p->tmx_tiles, p->SUMS);
+            else hipLaunchKernelGGL((pf_softmax_rows_kernel<16>), dim3((rows + 15) / 16), dim3(576), 0, s, aa, rows, p->TMX, p->tmx_tiles, p->SUMS);
+        } else {
+            const int npad = (max_pos + 1 + 63) & ~63;
+            int wpw = (int)((60 * 1024) / ((size_t)npad * 4));
+            wpw = wpw > 4 ? 4 : wpw;
+            hipLaunchKernelGGL(pf_softmax_kernel, dim3((n * H + wpw - 1) / wpw), dim3(256), (size_t)wpw * npad * 4, s, aa, n, wpw, npad);
+        }
+        if (hs > 64) hipLaunchKernelGGL((pf_pv_tiled_kernel<2>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n, sums);
+        else hipLaunchKernelGGL((pf_pv_tiled_kernel<1>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n, sums);
     } else {
         const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
         hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, KVH, n), dim3(64 * kvmul), sm1, s, aa);

@@ -67,6 +67,32 @@ def test_llama3_8b_shaped_layer_prefill512_and_decode(pkg, orc, planmod):
     plan.freeTornadoExecutionPlan()
 
 
+def test_llama3_8b_shaped_layer_prefill_chunks_behind_1000_positions(pkg, orc, planmod):
+    """pp512 @ depth: chunks whose score rows no longer fit the one-launch prefill attention (from ~640 positions at kvMul 4, head size 128)
+    take pf_scores_tiled_kernel (tile maxima) -> pf_softmax_rows_kernel (64 / 32 / 16 rows per workgroup for 512- / 256- / 100-token
+    chunks, sums as lane-per-row chains) -> pf_pv_tiled_kernel (divides where it stages the weights): residual stream, KV rows and the
+    decode steps behind them against the C oracle."""
+    plan_mod, hip = planmod
+    m = _model(pkg, "8b-layer", 131, ctx=1500)
+    toks = pkg.javarand.bench_tokens(m.cfg.vocab, 1400)
+    plan = plan_mod.HipMasterPlan.initializeTornadoVMPlan(m, prefill_batch_size=512)
+    o = orc.COracle(m)
+    pos = 0
+    for c in (512, 512, 256, 100):
+        plan.tornadoVMForwardBatchPrefill(toks[pos:pos + c], pos)
+        o.prefill(toks[pos:pos + c], pos)
+        pos += c
+        assert np.array_equal(plan.x(), o.x()), pos
+    for p in (0, 511, 512, 1023, 1024, 1279, 1280, 1379):
+        k, v = plan.kv(0, p)
+        ko, vo = o.kv(0, p)
+        assert np.array_equal(k, ko) and np.array_equal(v, vo), p
+    for p in range(1380, 1383):
+        ref = o.forward(toks[p], p)
+        assert np.array_equal(plan.tornadoVMForwardDecode(toks[p], p), ref), p
+    plan.freeTornadoExecutionPlan()
+
+
 def test_llama32_1b_shaped_layer_tied_vocab_decode_and_prefill512(pkg, orc, planmod):
     """BASELINE configs[1] (Llama-3.2-1B Q8_0 tg128) at ITS OWN shape: dim 2048 / hidden 8192 / head_size 64 and the tied
     128256 x 2048 head (wcls = token_embd): decode from position 0 with full logits, per-layer x and device argmax, a 512-token

@@ -39,3 +39,17 @@ def test_k_split_small_batch_gemm_stays_bit_exact():
     tail = out.stdout[-1500:] + out.stderr[-500:]
     assert out.returncode == 0, tail
     assert " passed" in out.stdout and "failed" not in out.stdout, tail
+
+
+@pytest.mark.parametrize("env", [{"GL3_PF_FUSED_ATTN": "0"}, {"GL3_PF_FUSED_ATTN": "0", "GL3_PF_SOFTMAX_ROWS": "0"}], ids=["three-kernels", "three-kernels-row-per-wavefront"])
+def test_three_kernel_prefill_attention_at_every_depth(env):
+    """GL3_PF_FUSED_ATTN=0: scores / softmax / weighted V sum as three launches from position 0 (by default only chunks whose score rows do not
+    fit the one-launch kernel's LDS take them); GL3_PF_SOFTMAX_ROWS=0: the r1 softmax kernel (one row per wavefront, normalises in place)
+    instead of pf_softmax_rows_kernel.  Ragged chunks, chunks at non-zero positions, the 8B / 1B layers at 512 tokens."""
+    e = dict(os.environ, **env)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_decode.py"), os.path.join(ROOT, "tests", "test_gpu_fullsize.py"),
+                          "-m", "gpu", "-x", "-q", "-k", "chunks_above_64 or prefill512 or long_context_prefill or behind_1000 or batched_prefill_is_bit", "-p", "no:cacheprovider"],
+                         capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    tail = out.stdout[-1500:] + out.stderr[-500:]
+    assert out.returncode == 0, tail
+    assert " passed" in out.stdout and "failed" not in out.stdout, tail
