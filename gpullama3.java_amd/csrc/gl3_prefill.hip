@@ -912,6 +912,124 @@ __global__ __launch_bounds__(256) void pf_pv_tiled_kernel(const PfAttnArgs a, in
     }
 }
 
+// r6 — pf_pv_tiled_kernel with the two latencies taken off its critical path (same arithmetic: acc = a_t * v + acc, t ascending; token tiles of 32):
+//   * the NEXT tile's V rows and softmax numerators are requested into registers before the current tile is consumed and reach LDS behind it
+//     (pf_pv_tiled_kernel loads, waits and stores between two barriers, 72 times per workgroup at 4608 positions);
+//   * inside a tile the LDS reads of timestep group g + 1 (four weights per token, four V rows) are in flight under the 64 multiply-add pairs
+//     of group g, pinned there with sched_barrier (left alone the scheduler sinks every read next to its use).
+// Masking is by weight: timesteps behind a token's position get the weight 0 (0 * v + acc = acc exactly: acc is never -0 and every staged
+// V row is a written row <= the tile's last position), so the inner loop has no per-token conditions.  The division e_t / sum happens
+// where the weights are staged (sums from pf_softmax_rows_kernel).
+constexpr int PVR_NW = 8, PVR_TB = 4 * PVR_NW;     // 8 wavefronts of 4 tokens: a V tile serves 32 tokens, 512 workgroups for 512 tokens x 32 heads (two per CU)
+template <int HS>
+__global__ __launch_bounds__(64 * PVR_NW) void pf_pv_ring_kernel(const PfAttnArgs a, int seq, int pos0, int ntok, const float* __restrict__ sums) {
+    constexpr int NCOL = HS > 64 ? 2 : 1, H4 = HS / 4, NT = 64 * PVR_NW, VPT = 64 * H4 / NT;
+    static_assert(VPT >= 1, "a V tile is at least one 16-byte slot per thread");
+    extern __shared__ __attribute__((aligned(16))) float vt[];        // [64][HS] V rows, then [PVR_TB][64] weights
+    float* as = vt + 64 * HS;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int kvmul = a.n_heads / a.n_kv_heads, h = blockIdx.x, kvh = h / kvmul, b0 = blockIdx.y * PVR_TB;
+    const int nb = min(PVR_TB, ntok - b0);
+    const int tmax = pos0 + b0 + nb - 1, ntile = tmax / 64 + 1;
+    const int wmax = 4 * w < nb ? pos0 + b0 + min(4 * w + 3, nb - 1) : -1;     // last position any of this wavefront's four tokens attends to
+    const float* vc = a.vcache + (size_t)seq * a.seq_stride + kvh * HS;
+    // staging roles: thread = (token w + PVR_NW j, timestep lane) of the weights; 16-byte slots t + NT j of the V tile
+    const float* arow[4]; float rsum[4]; int apos[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int tb = w + PVR_NW * j;
+        apos[j] = tb < nb ? pos0 + b0 + tb : -1;
+        arow[j] = a.att + ((size_t)(b0 + min(tb, nb - 1)) * a.n_heads + h) * a.ctx;
+        rsum[j] = sums[(size_t)(b0 + min(tb, nb - 1)) * a.n_heads + h];
+    }
+    typedef float v4f_native __attribute__((ext_vector_type(4)));     // typed loads / stores (a float4 array that is only copied in and out stays a stack object)
+    v4f_native vreg[VPT]; float areg[4];
+#define PVR_GLOAD(K_) do { const int t0_ = 64 * (K_); \
+        static_for<0, VPT, 1>([&](auto jc) { constexpr int j = decltype(jc)::value; const int i = t + NT * j, r = i / H4, c = i % H4; \
+            vreg[j] = *reinterpret_cast<const v4f_native*>(vc + (size_t)min(t0_ + r, tmax) * a.kv_dim + 4 * c); }); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) areg[j] = arow[j][max(min(t0_ + lane, apos[j]), 0)]; } while (0)
+#define PVR_LSTORE(K_) do { const int t0_ = 64 * (K_); \
+        static_for<0, VPT, 1>([&](auto jc) { constexpr int j = decltype(jc)::value; const int i = t + NT * j, r = i / H4, c = i % H4; \
+            *reinterpret_cast<v4f_native*>(vt + r * HS + 4 * c) = vreg[j]; }); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) as[(w + PVR_NW * j) * 64 + lane] = t0_ + lane <= apos[j] ? areg[j] / rsum[j] : 0.f; } while (0)
+    float acc[4][NCOL];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) acc[u][c] = 0.f;
+    const float* vp = vt + (NCOL == 2 ? 2 * lane : min(lane, HS - 1));
+    const float* ap = as + 4 * w * 64;
+    PVR_GLOAD(0);
+    PVR_LSTORE(0);
+    __syncthreads();
+    for (int k = 0; k < ntile; ++k) {
+        PVR_GLOAD(min(k + 1, ntile - 1));                            // unconditional (a condition around the loads makes the compiler drain them)
+        const int ng = max(0, min(64, wmax + 1 - 64 * k) + 3) >> 2;   // groups of four timesteps this wavefront's tokens reach in the tile
+        float4 wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
+        float va[4][NCOL], vb[4][NCOL];
+#define PVR_LD(G_, W0_, W1_, W2_, W3_, V_) do { const int r_ = 4 * min((G_), 15); \
+            W0_ = *reinterpret_cast<const float4*>(ap + r_); W1_ = *reinterpret_cast<const float4*>(ap + 64 + r_); \
+            W2_ = *reinterpret_cast<const float4*>(ap + 128 + r_); W3_ = *reinterpret_cast<const float4*>(ap + 192 + r_); \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { \
+                if (NCOL == 2) { const float2 x_ = *reinterpret_cast<const float2*>(vp + (r_ + i_) * HS); V_[i_][0] = x_.x; V_[i_][NCOL - 1] = x_.y; } \
+                else V_[i_][0] = vp[(r_ + i_) * HS]; } } while (0)
+#define PVR_STEP(I_, WX_, V_) do { const float w_[4] = {W0X_.WX_, W1X_.WX_, W2X_.WX_, W3X_.WX_}; \
+            _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) _Pragma("unroll") for (int c_ = 0; c_ < NCOL; ++c_) acc[u_][c_] = w_[u_] * V_[I_][c_] + acc[u_][c_]; } while (0)
+        PVR_LD(0, wa0, wa1, wa2, wa3, va); PVR_LD(1, wb0, wb1, wb2, wb3, vb); __builtin_amdgcn_sched_barrier(0);
+        int g = 0;
+        for (; g + 2 <= ng; g += 2) {
+#define W0X_ wa0
+#define W1X_ wa1
+#define W2X_ wa2
+#define W3X_ wa3
+            PVR_STEP(0, x, va); PVR_STEP(1, y, va); PVR_STEP(2, z, va); PVR_STEP(3, w, va);
+#undef W0X_
+#undef W1X_
+#undef W2X_
+#undef W3X_
+            PVR_LD(g + 2, wa0, wa1, wa2, wa3, va); __builtin_amdgcn_sched_barrier(0);
+#define W0X_ wb0
+#define W1X_ wb1
+#define W2X_ wb2
+#define W3X_ wb3
+            PVR_STEP(0, x, vb); PVR_STEP(1, y, vb); PVR_STEP(2, z, vb); PVR_STEP(3, w, vb);
+#undef W0X_
+#undef W1X_
+#undef W2X_
+#undef W3X_
+            PVR_LD(g + 3, wb0, wb1, wb2, wb3, vb); __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g < ng) {
+#define W0X_ wa0
+#define W1X_ wa1
+#define W2X_ wa2
+#define W3X_ wa3
+            PVR_STEP(0, x, va); PVR_STEP(1, y, va); PVR_STEP(2, z, va); PVR_STEP(3, w, va);
+#undef W0X_
+#undef W1X_
+#undef W2X_
+#undef W3X_
+        }
+#undef PVR_LD
+#undef PVR_STEP
+        __syncthreads();
+        PVR_LSTORE(min(k + 1, ntile - 1));
+        __syncthreads();
+    }
+#undef PVR_GLOAD
+#undef PVR_LSTORE
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int tb = 4 * w + u;
+        if (tb >= nb) continue;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            const int j = NCOL == 2 ? 2 * lane + c : lane;
+            if (j < HS) a.out[(size_t)(b0 + tb) * a.out_stride + h * HS + j] = acc[u][c];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Round 4: scores + softmax + weighted V sum of ONE sequence's prefill chunk in one launch (the three kernels above stay for long
 // contexts and odd shapes).  Workgroup = (kv head, tile of FA_TB = 8 tokens), 2 * kvMul wavefronts; the score rows of the tile's
@@ -1552,8 +1670,15 @@ static bool pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
             wpw = wpw > 4 ? 4 : wpw;
             hipLaunchKernelGGL(pf_softmax_kernel, dim3((n * H + wpw - 1) / wpw), dim3(256), (size_t)wpw * npad * 4, s, aa, n, wpw, npad);
         }
-        if (hs > 64) hipLaunchKernelGGL((pf_pv_tiled_kernel<2>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n, sums);
-        else hipLaunchKernelGGL((pf_pv_tiled_kernel<1>), dim3(H, ntt), dim3(256), (size_t)64 * (hs + PA_TB) * 4, s, aa, one_seq, pos0, n, sums);
+        static const bool ring_off = getenv("GL3_PF_PV_RING") && atoi(getenv("GL3_PF_PV_RING")) == 0;
+        const size_t pv_sm = (size_t)64 * (hs + PA_TB) * 4, pvr_sm = (size_t)64 * (hs + PVR_TB) * 4;
+        const dim3 pvr_grid(H, (n + PVR_TB - 1) / PVR_TB), pvr_block(64 * PVR_NW);
+        if (sums && !ring_off) {
+            if (hs == 128) hipLaunchKernelGGL((pf_pv_ring_kernel<128>), pvr_grid, pvr_block, pvr_sm, s, aa, one_seq, pos0, n, sums);
+            else if (hs == 64) hipLaunchKernelGGL((pf_pv_ring_kernel<64>), pvr_grid, pvr_block, pvr_sm, s, aa, one_seq, pos0, n, sums);
+            else hipLaunchKernelGGL((pf_pv_ring_kernel<32>), pvr_grid, pvr_block, pvr_sm, s, aa, one_seq, pos0, n, sums);
+        } else if (hs > 64) hipLaunchKernelGGL((pf_pv_tiled_kernel<2>), dim3(H, ntt), dim3(256), pv_sm, s, aa, one_seq, pos0, n, sums);
+        else hipLaunchKernelGGL((pf_pv_tiled_kernel<1>), dim3(H, ntt), dim3(256), pv_sm, s, aa, one_seq, pos0, n, sums);
     } else {
         const size_t sm1 = ((size_t)kvmul * d.head_size + (size_t)ATT_TT * (d.head_size + 1)) * 4;
         hipLaunchKernelGGL(pf_attn_scores_kernel, dim3(nsplit, KVH, n), dim3(64 * kvmul), sm1, s, aa);

@@ -1,5 +1,6 @@
 #!/bin/bash
 # SQ / LDS / TCP counters of the batched-prefill GEMMs (separate --pmc passes, no tracing), variant = $2 ("VAR=val ...")
+#   CMD="python scripts/pp_only.py llama-3-8b 2 8" FILTER="pf_scores pf_pv" PASSES="1 2" bash scripts/gpu/gemm_pmc.sh out "PP_DEPTH=4096"   (any command / kernels)
 set -u
 O=$1; V=${2:-GL3_NOOP=1}; mkdir -p $O
 export TMPDIR=/tmp
@@ -12,8 +13,8 @@ i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   [ -n "${PASSES:-}" ] && case " $PASSES " in *" $((i+1)) "*) ;; *) i=$((i+1)); continue;; esac
   i=$((i+1))
-  ( cd /tmp && env $V timeout 300 rocprofv3 --pmc $P --output-format csv -d $R/$O/p$i -o p -- python $R/scripts/gemm_ab.py llama-3-8b 2 > $R/$O/p$i.log 2>&1; echo "pass $i rc=$?" )
-  python scripts/pmc_table.py $O/p$i gemm > $O/pmc_p$i.csv 2>> $O/p$i.log
+  ( cd /tmp && env $V timeout 300 rocprofv3 --pmc $P --output-format csv -d $R/$O/p$i -o p -- ${CMD:-python $R/scripts/gemm_ab.py llama-3-8b 2} > $R/$O/p$i.log 2>&1; echo "pass $i rc=$?" )
+  python scripts/pmc_table.py $O/p$i ${FILTER:-gemm} > $O/pmc_p$i.csv 2>> $O/p$i.log
   find $O/p$i -name "*.csv" -size +2M -delete
 done
 tail -2 $O/p1.log; cat $O/pmc_p*.csv
