@@ -725,6 +725,110 @@ __global__ __launch_bounds__(256) void pf_scores_tiled_kernel(const float* __res
     }
 }
 
+// r6 — pf_scores_tiled_kernel on packed f32: two tokens' chains advance in ONE register pair, {s_a, s_b} = {s_a, s_b} + {q_a[j], q_b[j]} * k[j]
+// (v_pk_mul_f32 + v_pk_add_f32: every product and every sum rounded as before, j ascending), two pairs side by side per wavefront.  The query
+// rows of the tile's 16 tokens reach LDS once per workgroup, interleaved by token pairs ([head][pair][j][2]), so a 16-byte broadcast read is
+// two steps of a pair; the reads of the next group of 8 steps are pinned under the current group's 32 packed instructions.  (The scalar-load
+// form feeds q through SGPRs: its lead is bounded by the SGPR file — one group of 16 steps — and the scalar cache misses to L2 at 32 KB of
+// query rows per workgroup.)  K rows in registers as before, lane = timestep.  Two wavefronts per SIMD (~210 VGPRs, 65 KB of LDS).
+typedef float v2f_native __attribute__((ext_vector_type(2)));
+typedef float v4f_native_s __attribute__((ext_vector_type(4)));
+template <int HS, int KVM>
+__global__ __launch_bounds__(64 * KVM) __attribute__((amdgpu_waves_per_eu(2, 2))) void pf_scores_pk_kernel(const float* __restrict__ Q, int q_stride, const float* __restrict__ kc,
+        float* __restrict__ att, int n_heads, int kvmul_, int kv_dim, int ctx, int pos0, int ntok, float att_mul, float* __restrict__ tmx, int tmx_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float kt[];       // [64][PITCH] K rows, then [KVM][8 pairs][HS][2] query rows
+    constexpr int PITCH = HS + 4, H4 = HS / 4, NGR = HS / 8, NT = 64 * KVM, KPT = 64 * H4 / NT, QPT = H4 / 8, kvmul = KVM;
+    static_assert(KPT >= 1 && QPT >= 1, "staging slots per thread");
+    float* qs = kt + 64 * PITCH;
+    const int t = threadIdx.x;
+    const int t0 = blockIdx.x * 64, kvh = blockIdx.y, b0 = blockIdx.z * PA_TB;
+    const int nb = min(PA_TB, ntok - b0);
+    const int tmax = pos0 + b0 + nb - 1;
+    if (tmax < t0) return;
+    const int t1 = min(tmax + 1, t0 + 64);
+    {   // staging: EVERY global load of the workgroup's K tile and query rows is in flight before the first LDS write (a loop with a run-time
+        // trip count keeps one load per thread in flight: 8 + 8 L2 round trips per workgroup against ~8 us of arithmetic)
+        v4f_native_s kreg[KPT], qra[QPT], qrb[QPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {                               // rows past the tile's last timestep repeat it (their scores are never stored)
+            const int i = t + NT * j, r = i / H4, c = i % H4;
+            kreg[j] = *reinterpret_cast<const v4f_native_s*>(kc + (size_t)(t0 + min(r, t1 - t0 - 1)) * kv_dim + kvh * HS + 4 * c);
+        }
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {                               // slot = (head, token pair, 4 columns): both tokens' float4
+            const int i = t + NT * j, c = i % H4, pair = (i / H4) % (PA_TB / 2), hq = i / (H4 * (PA_TB / 2));
+            const float* qp = Q + (size_t)(kvh * kvmul + hq) * HS + 4 * c;
+            qra[j] = *reinterpret_cast<const v4f_native_s*>(qp + (size_t)(b0 + min(2 * pair, nb - 1)) * q_stride);
+            qrb[j] = *reinterpret_cast<const v4f_native_s*>(qp + (size_t)(b0 + min(2 * pair + 1, nb - 1)) * q_stride);
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int i = t + NT * j, r = i / H4, c = i % H4;
+            *reinterpret_cast<v4f_native_s*>(kt + r * PITCH + 4 * c) = kreg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const int i = t + NT * j, c = i % H4, pair = (i / H4) % (PA_TB / 2), hq = i / (H4 * (PA_TB / 2));
+            float* d = qs + ((size_t)(hq * (PA_TB / 2) + pair) * HS + 4 * c) * 2;
+            *reinterpret_cast<v4f_native_s*>(d) = (v4f_native_s){qra[j].x, qrb[j].x, qra[j].y, qrb[j].y};
+            *reinterpret_cast<v4f_native_s*>(d + 4) = (v4f_native_s){qra[j].z, qrb[j].z, qra[j].w, qrb[j].w};
+        }
+    }
+    __syncthreads();
+    const int hq = __builtin_amdgcn_readfirstlane(t >> 6), r = t & 63;
+    v2f_native kr[HS / 2];                                             // this lane's K row as 64-bit operands {k[2 i], k[2 i + 1]}
+#pragma unroll
+    for (int c = 0; c < H4; ++c) {
+        const v4f_native_s x = *reinterpret_cast<const v4f_native_s*>(kt + r * PITCH + 4 * c);
+        kr[2 * c] = x.xy; kr[2 * c + 1] = x.zw;
+    }
+    const float sqrt_hs = (float)sqrt((double)HS);
+    const int head = kvh * kvmul + hq;
+    for (int pp = 0; 4 * pp < nb; ++pp) {
+        const float* q01 = qs + (size_t)(hq * (PA_TB / 2) + 2 * pp) * HS * 2;      // pairs (4 pp, 4 pp + 1) and (4 pp + 2, 4 pp + 3)
+        const float* q23 = q01 + HS * 2;
+        v2f_native c0 = {0.f, 0.f}, c1 = {0.f, 0.f};
+        v4f_native_s qa[8], qb[8];                                     // two groups of 8 steps: [0..3] pair 0, [4..7] pair 1
+#define SPK_LD(G_, R_) do { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { \
+            R_[i_] = *reinterpret_cast<const v4f_native_s*>(q01 + 16 * (G_) + 4 * i_); R_[4 + i_] = *reinterpret_cast<const v4f_native_s*>(q23 + 16 * (G_) + 4 * i_); } } while (0)
+        // two steps of both pairs in one block: the K value is broadcast out of its register pair by op_sel (the compiler materialises {k, k}
+        // pairs instead: twice the K registers), and every dependent instruction has an independent one in front of it (packed f32 needs a wait
+        // state between a result and its use)
+#define SPK_STEP2(QA_, QB_, K_) do { v2f_native p0_, p1_; \
+            asm("v_pk_mul_f32 %[p0], %[qa0], %[k] op_sel_hi:[1,0]\n\tv_pk_mul_f32 %[p1], %[qb0], %[k] op_sel_hi:[1,0]\n\t" \
+                "v_pk_add_f32 %[c0], %[c0], %[p0]\n\tv_pk_add_f32 %[c1], %[c1], %[p1]\n\t" \
+                "v_pk_mul_f32 %[p0], %[qa1], %[k] op_sel:[0,1]\n\tv_pk_mul_f32 %[p1], %[qb1], %[k] op_sel:[0,1]\n\t" \
+                "v_pk_add_f32 %[c0], %[c0], %[p0]\n\tv_pk_add_f32 %[c1], %[c1], %[p1]" \
+                : [c0] "+v"(c0), [c1] "+v"(c1), [p0] "=&v"(p0_), [p1] "=&v"(p1_) \
+                : [qa0] "v"(QA_.xy), [qa1] "v"(QA_.zw), [qb0] "v"(QB_.xy), [qb1] "v"(QB_.zw), [k] "v"(K_)); } while (0)
+#define SPK_ACC(G_, R_) do { SPK_STEP2(R_[0], R_[4], kr[4 * (G_)]); SPK_STEP2(R_[1], R_[5], kr[4 * (G_) + 1]); \
+            SPK_STEP2(R_[2], R_[6], kr[4 * (G_) + 2]); SPK_STEP2(R_[3], R_[7], kr[4 * (G_) + 3]); } while (0)
+        SPK_LD(0, qa); SPK_LD(1, qb); __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NGR, 2>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            SPK_ACC(g, qa);
+            SPK_LD((g + 2 < NGR ? g + 2 : NGR - 1), qa); __builtin_amdgcn_sched_barrier(0);
+            SPK_ACC(g + 1, qb);
+            SPK_LD((g + 3 < NGR ? g + 3 : NGR - 1), qb); __builtin_amdgcn_sched_barrier(0);
+        });
+#undef SPK_LD
+#undef SPK_STEP2
+#undef SPK_ACC
+        const float sv[4] = {c0.x, c0.y, c1.x, c1.y};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tb = 4 * pp + u, b = b0 + tb;
+            const float v = att_mul != 0.f ? sv[u] * att_mul : sv[u] / sqrt_hs;
+            const bool ok = tb < nb && t0 + r <= pos0 + b;
+            if (ok) att[((size_t)b * n_heads + head) * ctx + t0 + r] = v;
+            if (tmx) {
+                const float m = wave_max_uniform(ok ? v : -INFINITY);
+                if (r == 0 && tb < nb && t0 <= pos0 + b) tmx[((size_t)b * n_heads + head) * tmx_tiles + blockIdx.x] = m;
+            }
+        }
+    }
+}
+
 // Softmax of every (token, head) score row, in place: one wavefront per row, wpw rows per workgroup.
 // max -> exp in double -> sequential f32 sum -> divide (InferenceCore.java softmax via FloatTensor.softmaxInPlace).
 __global__ __launch_bounds__(256) void pf_softmax_kernel(const PfAttnArgs a, int ntok, int wpw, int npad) {
@@ -1403,6 +1507,15 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
         GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         return GL3_OK;
     }
     p->maxk = d.hidden > ctx->q_dim ? d.hidden : ctx->q_dim;
@@ -1465,6 +1578,15 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     return GL3_OK;
 }
 
@@ -1650,12 +1772,19 @@ static bool pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
         const size_t sms = (size_t)64 * (hs + 4) * 4;
         const dim3 g1(nsplit, KVH, ntt), b1(64 * kvmul);
         const float* kc1 = aa.kcache + (size_t)one_seq * ctx->kv_seq_stride;
-#define GL3_SCORES(HS_) hipLaunchKernelGGL((pf_scores_tiled_kernel<HS_>), g1, b1, sms, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul, \
+        static const bool pk_off = getenv("GL3_PF_SCORES_PK") && atoi(getenv("GL3_PF_SCORES_PK")) == 0;
+        const size_t sms_pk = sms + (size_t)kvmul * PA_TB * hs * 4;
+        const bool pk = !pk_off && sms_pk <= 150 * 1024 && (kvmul == 4 || kvmul == 2 || kvmul == 1);
+#define GL3_SCORES_PK(HS_, KVM_) hipLaunchKernelGGL((pf_scores_pk_kernel<HS_, KVM_>), g1, b1, sms_pk, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul, \
                                            rows_softmax ? p->TMX : nullptr, p->tmx_tiles)
+#define GL3_SCORES(HS_) do { if (pk) { if (kvmul == 4) GL3_SCORES_PK(HS_, 4); else if (kvmul == 2) GL3_SCORES_PK(HS_, 2); else GL3_SCORES_PK(HS_, 1); } \
+        else hipLaunchKernelGGL((pf_scores_tiled_kernel<HS_>), g1, b1, sms, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul, \
+                                           rows_softmax ? p->TMX : nullptr, p->tmx_tiles); } while (0)
         if (hs == 128) GL3_SCORES(128);
         else if (hs == 64) GL3_SCORES(64);
         else GL3_SCORES(32);
 #undef GL3_SCORES
+#undef GL3_SCORES_PK
         const float* sums = nullptr;
         if (rows_softmax) {
             // r6: R rows per workgroup, the sums as R chains of one wavefront; at least one workgroup per CU when the chunk has the rows
