@@ -811,9 +811,6 @@ __global__ __launch_bounds__(64 * KVM) __attribute__((amdgpu_waves_per_eu(2, 2))
             SPK_ACC(g + 1, qb);
             SPK_LD((g + 3 < NGR ? g + 3 : NGR - 1), qb); __builtin_amdgcn_sched_barrier(0);
         });
-#undef SPK_LD
-#undef SPK_STEP2
-#undef SPK_ACC
         const float sv[4] = {c0.x, c0.y, c1.x, c1.y};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1411,6 +1408,252 @@ __global__ __launch_bounds__(512) void pf_attn_fused_kernel(const float* __restr
     }
 }
 
+// r6 — pf_attn_fused_kernel with the inner loops of pf_scores_pk_kernel (phase 1: query rows interleaved in LDS, two tokens' chains per register pair
+// on packed f32, reads of the next 8 steps pinned under the current group) and pf_pv_ring_kernel (phase 3: masking by zero weights, the next
+// timestep group's LDS reads pinned under the current group's arithmetic).  Same arithmetic in the same order; 16 KB more LDS (query rows).
+template <int HS>
+__global__ __launch_bounds__(512) void pf_attn_fused2_kernel(const float* __restrict__ Q, int q_stride, const float* __restrict__ kc, const float* __restrict__ vc,
+                                                            float* __restrict__ out, int out_stride, int n_kv_heads, int kvmul, int kv_dim,
+                                                            int pos0, int ntok, float att_mul, int sstride,
+                                                            uint8_t* __restrict__ xq_out = nullptr, uint4* __restrict__ xp_out = nullptr, int xp_tok = 0) {
+    extern __shared__ __attribute__((aligned(16))) float fa_sm[];
+    constexpr int PITCH = HS + 4, H4 = HS / 4, NCOL = HS > 64 ? 2 : 1;
+    float* Ssc = fa_sm;                                             // [kvmul][FA_TB][sstride] score -> softmax rows
+    float* kt = fa_sm + (size_t)kvmul * FA_TB * sstride;            // [2][64][PITCH] K (phase 1) / V (phase 3) tiles
+    float* sums = kt + 2 * 64 * PITCH;                              // [kvmul * FA_TB] (+ padding to 64 floats)
+    float* qs = sums + 64;                                          // [kvmul][FA_TB / 2 pairs][HS][2] query rows, interleaved by token pairs
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nthr = blockDim.x, gthreads = 64 * kvmul;
+    const int grp = wave / kvmul, hq = wave % kvmul, gt = t - grp * gthreads;
+    const int ntile = (ntok + FA_TB - 1) / FA_TB;
+    const int kvh = blockIdx.x % n_kv_heads, tile = ntile - 1 - blockIdx.x / n_kv_heads;
+    const int b0 = tile * FA_TB, nb = min(FA_TB, ntok - b0), tmax = pos0 + b0 + nb - 1;
+    const int head = kvh * kvmul + hq;
+    const float sqrt_hs = (float)sqrt((double)HS);
+
+    // K / V tiles travel global -> registers -> LDS; the next tile's loads are in flight while the current one is consumed (clamped
+    // rows: every address is inside the cache, the surplus rows are never read).  8 float4 per thread cover a 64-row tile (host check).
+    // (written out at every site: a register array captured by a lambda, or filled in a macro loop, ends up in scratch with this compiler)
+    constexpr int NPK = 8;
+#ifdef FA_TIMING
+    unsigned long long fa_t0 = __builtin_readcyclecounter(), fa_t1, fa_t2, fa_t3;
+#endif
+    // ---- phase 1: scores
+    const int nkt = tmax / 64 + 1;
+    float4 pk0, pk1, pk2, pk3, pk4, pk5, pk6, pk7;           // named registers: an array here is not promoted out of scratch
+#define FA_REP8(X_) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7)
+    static_assert(NPK == 8, "FA_REP8");
+    {
+        const int ft0 = min(grp * 64, tmax), frows = max(1, min(64, tmax + 1 - grp * 64));
+#define FA_F(U_) { const int fi = min(gt + U_ * gthreads, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                        pk##U_ = *reinterpret_cast<const float4*>(kc + (size_t)(ft0 + fr) * kv_dim + kvh * HS + 4 * fc); }
+        FA_REP8(FA_F)
+#undef FA_F
+    }
+    // query rows of the tile's tokens -> LDS, interleaved by token pairs: {q_a[j], q_b[j], q_a[j + 1], q_b[j + 1]} is one 16-byte broadcast read
+    for (int i = t; i < kvmul * (FA_TB / 2) * H4; i += nthr) {
+        const int c = i % H4, pair = (i / H4) % (FA_TB / 2), qh = i / (H4 * (FA_TB / 2));
+        const float* qp = Q + (size_t)(kvh * kvmul + qh) * HS + 4 * c;
+        const v4f_native_s xa = *reinterpret_cast<const v4f_native_s*>(qp + (size_t)(b0 + min(2 * pair, nb - 1)) * q_stride);
+        const v4f_native_s xb = *reinterpret_cast<const v4f_native_s*>(qp + (size_t)(b0 + min(2 * pair + 1, nb - 1)) * q_stride);
+        float* d = qs + ((size_t)(qh * (FA_TB / 2) + pair) * HS + 4 * c) * 2;
+        *reinterpret_cast<v4f_native_s*>(d) = (v4f_native_s){xa.x, xb.x, xa.y, xb.y};
+        *reinterpret_cast<v4f_native_s*>(d + 4) = (v4f_native_s){xa.z, xb.z, xa.w, xb.w};
+    }
+    for (int trip = 0; 2 * trip < nkt; ++trip) {
+        const int t0 = (2 * trip + grp) * 64;
+        const bool live = t0 <= tmax;
+        const int t1 = min(tmax + 1, t0 + 64);
+        float* ktg = kt + grp * 64 * PITCH;
+        if (live) {
+#define FA_P(U_) { const int fi = gt + U_ * gthreads; if (fi < 64 * H4) *reinterpret_cast<float4*>(ktg + (fi / H4) * PITCH + 4 * (fi % H4)) = pk##U_; }
+            FA_REP8(FA_P)
+#undef FA_P
+        }
+        __syncthreads();
+        {
+            const int tn = t0 + 128;                                 // this group's next tile (clamped: fetched even if it is not used)
+            {
+                const int ft0 = min(tn, tmax), frows = max(1, min(64, tmax + 1 - tn));
+#define FA_F(U_) { const int fi = min(gt + U_ * gthreads, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                                pk##U_ = *reinterpret_cast<const float4*>(kc + (size_t)(ft0 + fr) * kv_dim + kvh * HS + 4 * fc); }
+                FA_REP8(FA_F)
+#undef FA_F
+            }
+        }
+        if (live) {
+            v2f_native kr[HS / 2];
+#pragma unroll
+            for (int c = 0; c < H4; ++c) {
+                const v4f_native_s x = *reinterpret_cast<const v4f_native_s*>(ktg + min(lane, t1 - t0 - 1) * PITCH + 4 * c);
+                kr[2 * c] = x.xy; kr[2 * c + 1] = x.zw;
+            }
+            for (int pp = 0; 4 * pp < nb; ++pp) {                    // four tokens = two packed chains per pass (pf_scores_pk_kernel's inner loop)
+                const float* q01 = qs + (size_t)(hq * (FA_TB / 2) + 2 * pp) * HS * 2;
+                const float* q23 = q01 + HS * 2;
+                v2f_native c0 = {0.f, 0.f}, c1 = {0.f, 0.f};
+                v4f_native_s qa[8], qb[8];
+                SPK_LD(0, qa); SPK_LD(1, qb); __builtin_amdgcn_sched_barrier(0);
+                static_for<0, HS / 8, 2>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    SPK_ACC(g, qa);
+                    SPK_LD((g + 2 < HS / 8 ? g + 2 : HS / 8 - 1), qa); __builtin_amdgcn_sched_barrier(0);
+                    SPK_ACC(g + 1, qb);
+                    SPK_LD((g + 3 < HS / 8 ? g + 3 : HS / 8 - 1), qb); __builtin_amdgcn_sched_barrier(0);
+                });
+                const float sv[4] = {c0.x, c0.y, c1.x, c1.y};
+                const int ts = t0 + lane;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tb = 4 * pp + u;
+                    if (tb < nb && ts <= pos0 + b0 + tb) Ssc[(size_t)(hq * FA_TB + tb) * sstride + ts] = att_mul != 0.f ? sv[u] * att_mul : sv[u] / sqrt_hs;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+#ifdef FA_TIMING
+    fa_t1 = __builtin_readcyclecounter();
+#endif
+    // the first V tile travels while the softmax runs
+    {
+        const int ft0 = 0, frows = min(64, tmax + 1);
+#define FA_F(U_) { const int fi = min(t + U_ * nthr, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                        pk##U_ = *reinterpret_cast<const float4*>(vc + (size_t)(ft0 + fr) * kv_dim + kvh * HS + 4 * fc); }
+        FA_REP8(FA_F)
+#undef FA_F
+    }
+    // ---- phase 2: softmax of the kvmul * nb rows
+    const int nrows = kvmul * nb, nwaves = nthr >> 6;
+    for (int row = wave; row < nrows; row += nwaves) {
+        const int tb = row % nb, n = pos0 + b0 + tb + 1;
+        float* e = Ssc + (size_t)((row / nb) * FA_TB + tb) * sstride;
+        float mx = -INFINITY;
+        for (int i = lane; i < n; i += 64) mx = fmaxf(mx, e[i]);
+        mx = wave_max(mx);
+        for (int i = lane; i < n; i += 64) e[i] = (float)exp((double)(e[i] - mx));      // lane-private slots
+    }
+    __syncthreads();
+    if (wave == 0 && lane < nrows) {                                 // lane = row: the strictly sequential sums, side by side
+        const int tb = lane % nb, n = pos0 + b0 + tb + 1;
+        const float* e = Ssc + (size_t)((lane / nb) * FA_TB + tb) * sstride;
+        sums[lane] = seq_sum_lds_ring(e, n);                         // reads pinned three groups ahead (gl3_decode_kernels.h)
+    }
+    __syncthreads();
+    for (int row = wave; row < nrows; row += nwaves) {
+        const int tb = row % nb, n = pos0 + b0 + tb + 1;
+        float* e = Ssc + (size_t)((row / nb) * FA_TB + tb) * sstride;
+        const float sum = sums[row];
+        // weight 0 behind the token's position (phase 3 masks by weight): up to where the wavefront that carries this token can read — its last
+        // token sits at most 3 positions further, rounded up to a group of four, inside the tile's last 64-timestep block
+        const int zend = min((n + 4 + 63) & ~63, (tmax + 1 + 63) & ~63);
+        for (int i = lane; i < zend; i += 64) e[i] = i < n ? e[i] / sum : 0.f;
+    }
+
+#ifdef FA_TIMING
+    fa_t2 = __builtin_readcyclecounter();
+#endif
+    // ---- phase 3: weighted V sum; wavefront = (query head hq, tokens 4 * grp .. + 3)
+    const int wmax = 4 * grp < nb ? pos0 + b0 + min(4 * grp + 3, nb - 1) : -1;
+    const float* as = Ssc + (size_t)(hq * FA_TB + 4 * grp) * sstride;                             // rows of this wavefront's four tokens
+    float acc[4][NCOL];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) acc[u][c] = 0.f;
+    int vb = 0;
+    for (int t0 = 0; t0 <= tmax; t0 += 64, vb ^= 1) {
+        const int tt = min(64, tmax + 1 - t0);
+        float* vt = kt + vb * 64 * PITCH;
+        {
+#define FA_P(U_) { const int fi = t + U_ * nthr; if (fi < 64 * H4) *reinterpret_cast<float4*>(vt + (fi / H4) * PITCH + 4 * (fi % H4)) = pk##U_; }
+            FA_REP8(FA_P)
+#undef FA_P
+        }
+        __syncthreads();                                             // (also orders phase 2's writes before the first reads of `as`)
+        {
+            const int ft0 = min(t0 + 64, tmax), frows = max(1, min(64, tmax + 1 - (t0 + 64)));
+#define FA_F(U_) { const int fi = min(t + U_ * nthr, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                            pk##U_ = *reinterpret_cast<const float4*>(vc + (size_t)(ft0 + fr) * kv_dim + kvh * HS + 4 * fc); }
+            FA_REP8(FA_F)
+#undef FA_F
+        }
+        // groups of four timesteps; the next group's weights and V rows are read from LDS under the current group's arithmetic (pinned).
+        // Timesteps behind a token's position carry the weight 0 (0 * v + acc = acc exactly; every staged V row is a written row).
+        const int ng = max(0, min(64, wmax + 1 - t0) + 3) >> 2;
+        const float* ap = as + t0;
+        const float* vp = vt + (NCOL == 2 ? 2 * lane : min(lane, HS - 1));
+        float4 wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
+        float va[4][NCOL], vb4[4][NCOL];
+#define FA2_LD(G_, W0_, W1_, W2_, W3_, V_) do { const int r_ = 4 * min((G_), 15); \
+            W0_ = *reinterpret_cast<const float4*>(ap + r_); W1_ = *reinterpret_cast<const float4*>(ap + (size_t)sstride + r_); \
+            W2_ = *reinterpret_cast<const float4*>(ap + 2 * (size_t)sstride + r_); W3_ = *reinterpret_cast<const float4*>(ap + 3 * (size_t)sstride + r_); \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { \
+                if (NCOL == 2) { const float2 x_ = *reinterpret_cast<const float2*>(vp + (r_ + i_) * PITCH); V_[i_][0] = x_.x; V_[i_][NCOL - 1] = x_.y; } \
+                else V_[i_][0] = vp[(r_ + i_) * PITCH]; } } while (0)
+#define FA2_STEP(I_, WX_, V_, W0_, W1_, W2_, W3_) do { const float w_[4] = {W0_.WX_, W1_.WX_, W2_.WX_, W3_.WX_}; \
+            _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) _Pragma("unroll") for (int c_ = 0; c_ < NCOL; ++c_) acc[u_][c_] = w_[u_] * V_[I_][c_] + acc[u_][c_]; } while (0)
+#define FA2_ACC(V_, W0_, W1_, W2_, W3_) do { FA2_STEP(0, x, V_, W0_, W1_, W2_, W3_); FA2_STEP(1, y, V_, W0_, W1_, W2_, W3_); \
+            FA2_STEP(2, z, V_, W0_, W1_, W2_, W3_); FA2_STEP(3, w, V_, W0_, W1_, W2_, W3_); } while (0)
+        FA2_LD(0, wa0, wa1, wa2, wa3, va); FA2_LD(1, wb0, wb1, wb2, wb3, vb4); __builtin_amdgcn_sched_barrier(0);
+        int g = 0;
+        for (; g + 2 <= ng; g += 2) {
+            FA2_ACC(va, wa0, wa1, wa2, wa3);
+            FA2_LD(g + 2, wa0, wa1, wa2, wa3, va); __builtin_amdgcn_sched_barrier(0);
+            FA2_ACC(vb4, wb0, wb1, wb2, wb3);
+            FA2_LD(g + 3, wb0, wb1, wb2, wb3, vb4); __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g < ng) FA2_ACC(va, wa0, wa1, wa2, wa3);
+#undef FA2_LD
+#undef FA2_STEP
+#undef FA2_ACC
+    }
+#ifdef FA_TIMING
+    fa_t3 = __builtin_readcyclecounter();
+    if (lane == 0 && kvh == 0 && (tile % 9) == 0) printf("fa tile %d wave %d: scores %llu softmax %llu pv %llu\n", tile, wave, fa_t1 - fa_t0, fa_t2 - fa_t1, fa_t3 - fa_t2);
+#endif
+    if (NCOL == 2 && xq_out) {
+        // r6: the attention output leaves the kernel as the wo projection's operand (int8 chunks XQ3[k / 16][token slot][16 B] + the scale-operand table
+        // of gl3_prefill_gemm3.h) instead of f32 + a quantise launch.  A 32-element block of a token's row = 32 consecutive columns = the 16 lanes of a
+        // DPP row, two columns each; Q8_0FloatTensor.java:96-118 arithmetic as quantize_quad_pack.
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tb = 4 * grp + u;
+            float amax = fmaxf(fabsf(acc[u][0]), fabsf(acc[u][NCOL - 1]));
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+            const float qs = amax / 127.0f;
+            const float ainv = qs != 0.f ? 1.0f / qs : 0.f;
+            const float s0 = acc[u][0] * ainv, s1 = acc[u][NCOL - 1] * ainv;
+            const uint32_t q0 = (uint32_t)((int)(s0 + copysignf(0.5f, s0)) & 0xFF), q1 = (uint32_t)((int)(s1 + copysignf(0.5f, s1)) & 0xFF);
+            if (tb >= nb) continue;
+            const int col = head * HS + 2 * lane, b = b0 + tb;
+            *reinterpret_cast<uint16_t*>(xq_out + ((size_t)(col >> 4) * xp_tok + b) * 16 + (col & 15)) = (uint16_t)(q0 | (q1 << 8));
+            if ((lane & 15) == 0) {
+                const float qf = (float)(_Float16)qs;
+                const float ahi = __uint_as_float(__float_as_uint(qf) & 0xFFFF0000u), alo = qf - ahi;
+                auto pk = [](float h, float l) { return (__float_as_uint(h) >> 16) | (__float_as_uint(l) & 0xFFFF0000u); };
+                const uint32_t pr = pk(ahi, alo), n0 = pk(ahi * -8388608.f, alo * -8388608.f), n1 = pk(ahi * -4194304.f, alo * -4194304.f);
+                const int blk = col >> 5;
+                xp_out[((size_t)blk * 2 + 0) * xp_tok + b] = make_uint4(pr, pr, n0, n0);
+                xp_out[((size_t)blk * 2 + 1) * xp_tok + b] = make_uint4(0u, 0u, n1, n1);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int tb = 4 * grp + u;
+        if (tb >= nb) continue;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            const int j = NCOL == 2 ? 2 * lane + c : lane;
+            if (j < HS) out[(size_t)(b0 + tb) * out_stride + head * HS + j] = acc[u][c];
+        }
+    }
+}
+
 #undef FA_REP8
 
 // Greedy id per sequence: first index of the maximum of each logits row (FloatTensor.argmax :138-151).
@@ -1457,6 +1700,18 @@ __global__ __launch_bounds__(64) void pf_argmax_fold_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// LDS attributes of the prefill attention kernels (both plan kinds)
+static int32_t pf_attention_attributes(gl3_ctx* ctx) {
+#define GL3_ATTR150(K_) GL3_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+    GL3_ATTR150(pf_attn_fused_kernel<128>); GL3_ATTR150(pf_attn_fused_kernel<64>); GL3_ATTR150(pf_attn_fused_kernel<32>);
+    GL3_ATTR150(pf_attn_fused2_kernel<128>); GL3_ATTR150(pf_attn_fused2_kernel<64>); GL3_ATTR150(pf_attn_fused2_kernel<32>);
+    GL3_ATTR150((pf_scores_pk_kernel<128, 4>)); GL3_ATTR150((pf_scores_pk_kernel<128, 2>)); GL3_ATTR150((pf_scores_pk_kernel<128, 1>));
+    GL3_ATTR150((pf_scores_pk_kernel<64, 4>)); GL3_ATTR150((pf_scores_pk_kernel<64, 2>)); GL3_ATTR150((pf_scores_pk_kernel<64, 1>));
+    GL3_ATTR150((pf_scores_pk_kernel<32, 4>)); GL3_ATTR150((pf_scores_pk_kernel<32, 2>)); GL3_ATTR150((pf_scores_pk_kernel<32, 1>));
+#undef GL3_ATTR150
+    return GL3_OK;
+}
+
 int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
     const gl3_model_desc& d = ctx->d;
     gl3_prefill_state* p = new gl3_prefill_state();
@@ -1504,18 +1759,7 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
 #undef GL3_VQM_ATTR
         GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    { const int32_t ar = pf_attention_attributes(ctx); if (ar != GL3_OK) return ar; }
         return GL3_OK;
     }
     p->maxk = d.hidden > ctx->q_dim ? d.hidden : ctx->q_dim;
@@ -1575,18 +1819,7 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
 #undef GL3_BDK_ATTR
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_fused_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GL3_HIP(hipFuncSetAttribute((const void*)pf_scores_pk_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    { const int32_t ar = pf_attention_attributes(ctx); if (ar != GL3_OK) return ar; }
     return GL3_OK;
 }
 
@@ -1759,8 +1992,14 @@ static bool pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
         const bool qao = !qao_off && hs == 128 && n > 64 && d.tp_size == 1 && pf_use_gemm3() && p->XP && (getenv("GL3_NO_FUSED_QUANT") == nullptr || atoi(getenv("GL3_NO_FUSED_QUANT")) == 0);
         uint8_t* xqo = qao ? p->XQ : nullptr;
         uint4* xpo = qao ? reinterpret_cast<uint4*>(p->XP) : nullptr;
-#define GL3_FA(HS_) hipLaunchKernelGGL((pf_attn_fused_kernel<HS_>), dim3(KVH * ntile), dim3(128 * kvmul), sms, s, aa.Q, aa.q_stride, kc1, vc1, aa.out, aa.out_stride, \
-                                       KVH, kvmul, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride, xqo, xpo, p->xp_tok)
+        // r6: packed-f32 scores + pinned weighted V sum (pf_attn_fused2_kernel) when its 16 KB of query rows still fit; GL3_PF_FUSED_V1=1: the r4 kernel
+        static const bool v1_only = getenv("GL3_PF_FUSED_V1") && atoi(getenv("GL3_PF_FUSED_V1")) != 0;
+        const size_t sms2 = sms + (size_t)kvmul * FA_TB * hs * 4;
+        const bool v2 = !v1_only && sms2 <= 150 * 1024;
+#define GL3_FA(HS_) do { if (v2) hipLaunchKernelGGL((pf_attn_fused2_kernel<HS_>), dim3(KVH * ntile), dim3(128 * kvmul), sms2, s, aa.Q, aa.q_stride, kc1, vc1, aa.out, aa.out_stride, \
+                                       KVH, kvmul, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride, xqo, xpo, p->xp_tok); \
+        else hipLaunchKernelGGL((pf_attn_fused_kernel<HS_>), dim3(KVH * ntile), dim3(128 * kvmul), sms, s, aa.Q, aa.q_stride, kc1, vc1, aa.out, aa.out_stride, \
+                                       KVH, kvmul, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride, xqo, xpo, p->xp_tok); } while (0)
         if (hs == 128) GL3_FA(128);
         else if (hs == 64) GL3_FA(64);
         else GL3_FA(32);
