@@ -1,1 +1,2 @@
-cd $GRAFT_REPO_ROOT/scripts/probes && hipcc --offload-arch=gfx950 -O3 -o /tmp/lds_bcast lds_bcast_probe.hip 2>/dev/null && timeout 120 /tmp/lds_bcast
+cd $GRAFT_REPO_ROOT
+bash scripts/gpu/round6_final.sh gpurun_out/r6b tests bench depth 2>&1 | tail -40
