@@ -1700,11 +1700,255 @@ __global__ __launch_bounds__(64) void pf_argmax_fold_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// r6 — the one-launch prefill attention with the PRODUCTS of phases 1 and 3 on the matrix pipe (kvMul 4: 32 (head, token) rows per workgroup).
+// pf_attn_fused_kernel / fused2 feed one operand of every multiply from a wavefront-uniform place (SGPRs: lead bounded by the SGPR file; LDS:
+// a uniform-address ds_read_b128 costs 9.2 cycles of the CU's LDS pipe against 4.9 for 64 distinct addresses, scripts/probes/lds_bcast_probe.hip)
+// and both phases end up bound by that delivery.  A K = 1 f32 MFMA with C = 0 is an outer product of two LANE-DISTINCT vectors whose every
+// element is rounded once (D = fma(a, b, 0) = fl(a * b): the property gemm_vlq_mfma_kernel uses): v_mfma_f32_16x16x1_4b_f32 = four independent
+// 16 x 16 blocks per instruction, 1024 rounded products in 32 cycles, no broadcast anywhere; the VALU keeps the ordered adds (packed).
+//   phase 1  wavefront = 16 timesteps of the K tile x all 32 rows.  Block q = (row group q & 1, step parity q >> 1): A = k[t][2 m + parity]
+//            (the lane's K row, every second element, in registers), B = q[row][2 m + parity] (one ds_read_b32 of 64 distinct addresses).
+//            Per MFMA the chains advance two steps: s = (s + P_even) + P_odd, j ascending.  64 MFMAs + 512 packed adds per tile and wavefront.
+//   phase 3  wavefront = 16 rows x 32 columns.  Block q = (column group q & 1, timestep parity q >> 1): A = w[row][t + parity] (softmax weight,
+//            0 behind the row's position), B = v[t + parity][column]; acc = (acc + P_t) + P_t+1, t ascending.  8 accumulator registers.
+// Same arithmetic, same order, same roundings as InferenceCore.java:98-137; phase 2 is pf_attn_fused_kernel's.
+__host__ __device__ constexpr size_t fa3_smem_bytes(int hs, int sstride) {
+    return ((size_t)4 * FA_TB * sstride + 2 * 64 * (hs + 4) + 64 + (size_t)4 * FA_TB * (hs + 2)) * 4;
+}
+typedef float v8f_native __attribute__((ext_vector_type(8)));
+template <int HS>
+__global__ __launch_bounds__(512) void pf_attn_fused3_kernel(const float* __restrict__ Q, int q_stride, const float* __restrict__ kc, const float* __restrict__ vc,
+                                                             float* __restrict__ out, int out_stride, int n_kv_heads, int kv_dim,
+                                                             int pos0, int ntok, float att_mul, int sstride,
+                                                             uint8_t* __restrict__ xq_out, uint4* __restrict__ xp_out, int xp_tok) {
+    extern __shared__ __attribute__((aligned(16))) float fa_sm[];
+    constexpr int KVM = 4, ROWS = KVM * FA_TB, PITCH = HS + 4, H4 = HS / 4, QP = HS + 2, NM = HS / 2, kvmul = KVM;
+    static_assert(ROWS == 32 && NM % 16 == 0, "two row groups of 16; operand ring of 8 MFMAs");
+    float* Ssc = fa_sm;                                             // [ROWS][sstride] score -> softmax rows, row = head * FA_TB + token
+    float* kt = fa_sm + (size_t)ROWS * sstride;                     // [2][64][PITCH] K (phase 1) / V (phase 3) tiles
+    float* sums = kt + 2 * 64 * PITCH;                              // [ROWS] (+ padding to 64 floats)
+    float* qs = sums + 64;                                          // [ROWS][QP] query rows
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int nthr = 512, gthreads = 256;
+    const int grp = wave >> 2, wg = wave & 3, gt = t - grp * gthreads;
+    const int lq = lane >> 4, li = lane & 15, par = lq >> 1;        // MFMA block of this lane's operands, index inside it, step parity of the block
+    const int ntile = (ntok + FA_TB - 1) / FA_TB;
+    const int kvh = blockIdx.x % n_kv_heads, tile = ntile - 1 - blockIdx.x / n_kv_heads;
+    const int b0 = tile * FA_TB, nb = min(FA_TB, ntok - b0), tmax = pos0 + b0 + nb - 1;
+    const float sqrt_hs = (float)sqrt((double)HS);
+    const v16f_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int NPK = 8;
+    const int nkt = tmax / 64 + 1;
+    float4 pk0, pk1, pk2, pk3, pk4, pk5, pk6, pk7;           // named registers: an array here is not promoted out of scratch
+#define FA_REP8(X_) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7)
+    static_assert(NPK == 8, "FA_REP8");
+    {
+        const int ft0 = min(grp * 64, tmax), frows = max(1, min(64, tmax + 1 - grp * 64));
+#define FA_F(U_) { const int fi = min(gt + U_ * gthreads, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                        pk##U_ = *reinterpret_cast<const float4*>(kc + (size_t)(ft0 + fr) * kv_dim + kvh * HS + 4 * fc); }
+        FA_REP8(FA_F)
+#undef FA_F
+    }
+    for (int i = t; i < ROWS * H4; i += nthr) {                      // query rows (tokens past the chunk's end repeat its last token: never stored)
+        const int row = i / H4, c = i % H4;
+        const float4 x = *reinterpret_cast<const float4*>(Q + (size_t)(b0 + min(row & (FA_TB - 1), nb - 1)) * q_stride + (size_t)(kvh * kvmul + (row >> 3)) * HS + 4 * c);
+        float* d = qs + row * QP + 4 * c;
+        *reinterpret_cast<float2*>(d) = make_float2(x.x, x.y);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(x.z, x.w);
+    }
+    // ---- phase 1: scores
+    for (int trip = 0; 2 * trip < nkt; ++trip) {
+        const int t0 = (2 * trip + grp) * 64;
+        const bool live = t0 <= tmax;
+        const int t1 = min(tmax + 1, t0 + 64);
+        float* ktg = kt + grp * 64 * PITCH;
+        if (live) {
+#define FA_P(U_) { const int fi = gt + U_ * gthreads; if (fi < 64 * H4) *reinterpret_cast<float4*>(ktg + (fi / H4) * PITCH + 4 * (fi % H4)) = pk##U_; }
+            FA_REP8(FA_P)
+#undef FA_P
+        }
+        __syncthreads();
+        {
+            const int tn = t0 + 128;                                 // this group's next tile (clamped: fetched even if it is not used)
+            const int ft0 = min(tn, tmax), frows = max(1, min(64, tmax + 1 - tn));
+#define FA_F(U_) { const int fi = min(gt + U_ * gthreads, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                            pk##U_ = *reinterpret_cast<const float4*>(kc + (size_t)(ft0 + fr) * kv_dim + kvh * HS + 4 * fc); }
+            FA_REP8(FA_F)
+#undef FA_F
+        }
+        if (live && t0 + 16 * wg <= tmax) {                          // this wavefront's 16 timesteps hold at least one attended position
+            const float* krow = ktg + min(16 * wg + li, t1 - t0 - 1) * PITCH;
+            float kreg[NM];                                          // k[t][2 m + parity], m ascending
+#pragma unroll
+            for (int c = 0; c < H4; ++c) {
+                const v4f_native_s x = *reinterpret_cast<const v4f_native_s*>(krow + 4 * c);
+                kreg[2 * c] = par ? x.y : x.x; kreg[2 * c + 1] = par ? x.w : x.z;
+            }
+            const float* qrow = qs + (16 * (lq & 1) + li) * QP + par;
+            v8f_native sc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // [0..3] row li, [4..7] row 16 + li; the four timesteps 16 wg + 4 lq + r
+            float qa[8], qb[8];
+#define F3_LDQ(G_, R_) do { _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) R_[u_] = qrow[2 * (8 * (G_) + u_)]; } while (0)
+            // blocks 0 / 1 = row groups 0 / 1 at the even step, blocks 2 / 3 at the odd step: two dependent adds per chain and MFMA
+#define F3_ADD(P_, S_) do { S_ = S_ + __builtin_shufflevector(P_, P_, 0, 1, 2, 3, 4, 5, 6, 7); S_ = S_ + __builtin_shufflevector(P_, P_, 8, 9, 10, 11, 12, 13, 14, 15); } while (0)
+            // one MFMA ahead of the adds that consume the previous one (two product registers, order pinned: left alone the scheduler issues a whole
+            // group's MFMAs first and spills their 8 x 16 result registers)
+#define F3_MF8(G_, R_, RN_) do { _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) { \
+                const int mn_ = 8 * (G_) + u_ + 1;      /* a constant after unrolling */ \
+                v16f_t Pn_ = Pc; \
+                if (mn_ < NM) Pn_ = __builtin_amdgcn_mfma_f32_16x16x1f32(kreg[mn_ < NM ? mn_ : 0], u_ < 7 ? R_[u_ < 7 ? u_ + 1 : 0] : RN_[0], zero16, 0, 0, 0); \
+                F3_ADD(Pc, sc); \
+                __builtin_amdgcn_sched_barrier(0); \
+                Pc = Pn_; } } while (0)
+            F3_LDQ(0, qa); F3_LDQ(1, qb); __builtin_amdgcn_sched_barrier(0);
+            v16f_t Pc = __builtin_amdgcn_mfma_f32_16x16x1f32(kreg[0], qa[0], zero16, 0, 0, 0);
+            static_for<0, NM / 8, 2>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                F3_MF8(g, qa, qb);
+                F3_LDQ((g + 2 < NM / 8 ? g + 2 : NM / 8 - 1), qa); __builtin_amdgcn_sched_barrier(0);
+                F3_MF8(g + 1, qb, qa);
+                F3_LDQ((g + 3 < NM / 8 ? g + 3 : NM / 8 - 1), qb); __builtin_amdgcn_sched_barrier(0);
+            });
+#undef F3_LDQ
+#undef F3_MF8
+            // lane (lq, li) holds rows li and 16 + li at the timesteps 16 wg + 4 lq + r
+            const float sv[2][4] = {{sc[0], sc[1], sc[2], sc[3]}, {sc[4], sc[5], sc[6], sc[7]}};
+#pragma unroll
+            for (int rgp = 0; rgp < 2; ++rgp) {
+                const int row = 16 * rgp + li, tb = row & (FA_TB - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ts = t0 + 16 * wg + 4 * lq + r;
+                    if (tb < nb && ts <= pos0 + b0 + tb) Ssc[(size_t)row * sstride + ts] = att_mul != 0.f ? sv[rgp][r] * att_mul : sv[rgp][r] / sqrt_hs;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the first V tile travels while the softmax runs
+    {
+        const int frows = min(64, tmax + 1);
+#define FA_F(U_) { const int fi = min(t + U_ * nthr, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                        pk##U_ = *reinterpret_cast<const float4*>(vc + (size_t)fr * kv_dim + kvh * HS + 4 * fc); }
+        FA_REP8(FA_F)
+#undef FA_F
+    }
+    // ---- phase 2: softmax of the kvmul * nb rows (pf_attn_fused_kernel's; weights behind a row's position are written as 0: phase 3 masks by weight)
+    const int nrows = kvmul * nb, nwaves = nthr >> 6;
+    for (int row = wave; row < nrows; row += nwaves) {
+        const int tb = row % nb, n = pos0 + b0 + tb + 1;
+        float* e = Ssc + (size_t)((row / nb) * FA_TB + tb) * sstride;
+        float mx = -INFINITY;
+        for (int i = lane; i < n; i += 64) mx = fmaxf(mx, e[i]);
+        mx = wave_max(mx);
+        for (int i = lane; i < n; i += 64) e[i] = (float)exp((double)(e[i] - mx));      // lane-private slots
+    }
+    __syncthreads();
+    if (wave == 0 && lane < nrows) {                                 // lane = row: the strictly sequential sums, side by side
+        const int tb = lane % nb, n = pos0 + b0 + tb + 1;
+        const float* e = Ssc + (size_t)((lane / nb) * FA_TB + tb) * sstride;
+        sums[lane] = seq_sum_lds_ring(e, n);
+    }
+    __syncthreads();
+    const int tend = (tmax + 1 + 63) & ~63;
+    for (int row = wave; row < ROWS; row += nwaves) {                // every row of the tile: rows of tokens past the chunk's end become all-zero weights
+        const int tb = row & (FA_TB - 1), hqr = row >> 3;
+        float* e = Ssc + (size_t)row * sstride;
+        const int n = tb < nb ? pos0 + b0 + tb + 1 : 0;
+        const float sum = tb < nb ? sums[hqr * nb + tb] : 1.f;
+        for (int i = lane; i < tend; i += 64) e[i] = i < n ? e[i] / sum : 0.f;
+    }
+    // ---- phase 3: weighted V sum; wavefront = (row group rg, 32 columns cq)
+    const int rg = wave & 1, cq = wave >> 1, cg = lq & 1;
+    const bool pv_live = cq < HS / 32;
+    v8f_native ac = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // [0..3] column 32 cq + li, [4..7] column 32 cq + 16 + li; rows 16 rg + 4 lq + r
+    const float* wrow = Ssc + (size_t)(16 * rg + li) * sstride + par;
+    int vb = 0;
+    for (int t0 = 0; t0 <= tmax; t0 += 64, vb ^= 1) {
+        float* vt = kt + vb * 64 * PITCH;
+        {
+#define FA_P(U_) { const int fi = t + U_ * nthr; if (fi < 64 * H4) *reinterpret_cast<float4*>(vt + (fi / H4) * PITCH + 4 * (fi % H4)) = pk##U_; }
+            FA_REP8(FA_P)
+#undef FA_P
+        }
+        __syncthreads();                                             // (also orders phase 2's writes before the first reads of the weights)
+        {
+            const int ft0 = min(t0 + 64, tmax), frows = max(1, min(64, tmax + 1 - (t0 + 64)));
+#define FA_F(U_) { const int fi = min(t + U_ * nthr, 64 * H4 - 1), fr = min(fi / H4, frows - 1), fc = fi % H4; \
+                            pk##U_ = *reinterpret_cast<const float4*>(vc + (size_t)(ft0 + fr) * kv_dim + kvh * HS + 4 * fc); }
+            FA_REP8(FA_F)
+#undef FA_F
+        }
+        if (pv_live) {
+            const int npair = (min(64, tmax + 1 - t0) + 1) >> 1;     // timestep pairs of the tile that hold an attended position (weights behind: 0)
+            const float* wp = wrow + t0;
+            const float* vp = vt + par * PITCH + 32 * cq + 16 * cg + li;
+            float wa[8], va[8], wb[8], vb8[8];
+#define F3_LDV(G_, W_, V_) do { _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) { const int m_ = min(8 * (G_) + u_, 31); W_[u_] = wp[2 * m_]; V_[u_] = vp[2 * m_ * PITCH]; } } while (0)
+#define F3_PV8(W_, V_) do { v16f_t Pc_ = __builtin_amdgcn_mfma_f32_16x16x1f32(W_[0], V_[0], zero16, 0, 0, 0); \
+                _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) { \
+                    v16f_t Pn_ = Pc_; \
+                    if (u_ < 7) Pn_ = __builtin_amdgcn_mfma_f32_16x16x1f32(W_[u_ < 7 ? u_ + 1 : 0], V_[u_ < 7 ? u_ + 1 : 0], zero16, 0, 0, 0); \
+                    F3_ADD(Pc_, ac); \
+                    __builtin_amdgcn_sched_barrier(0); \
+                    Pc_ = Pn_; } } while (0)
+            // groups of 8 MFMAs = 16 timesteps; a group past the tile's last attended pair multiplies zero weights (exact: acc + 0), so the trip
+            // count is rounded up to whole groups only where needed
+            const int ngr = (npair + 7) >> 3;
+            F3_LDV(0, wa, va); F3_LDV(1, wb, vb8); __builtin_amdgcn_sched_barrier(0);
+            int g = 0;
+            for (; g + 2 <= ngr; g += 2) {
+                F3_PV8(wa, va);
+                F3_LDV(g + 2, wa, va); __builtin_amdgcn_sched_barrier(0);
+                F3_PV8(wb, vb8);
+                F3_LDV(g + 3, wb, vb8); __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g < ngr) F3_PV8(wa, va);
+#undef F3_LDV
+#undef F3_PV8
+        }
+    }
+#undef F3_ADD
+#undef FA_REP8
+    if (!pv_live) return;
+    const float av[2][4] = {{ac[0], ac[1], ac[2], ac[3]}, {ac[4], ac[5], ac[6], ac[7]}};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rg + 4 * lq + r, tb = row & (FA_TB - 1), head = kvh * kvmul + (row >> 3), b = b0 + tb;
+        const int col = head * HS + 32 * cq + li;                    // av[0][r]; av[1][r] sits 16 columns further
+        if (xq_out) {
+            // the wo projection's operand (int8 chunks XQ3[k / 16][token slot][16 B] + the scale-operand table of gl3_prefill_gemm3.h): this wavefront's
+            // 32 columns of a row are one Q8_0 block = the 16 lanes of a DPP row x 2 registers (Q8_0FloatTensor.java:96-118 arithmetic)
+            float amax = fmaxf(fabsf(av[0][r]), fabsf(av[1][r]));
+            amax = row8_max(amax); GL3_DPP_MAX(amax, 0x140);
+            const float qsc = amax / 127.0f;
+            const float ainv = qsc != 0.f ? 1.0f / qsc : 0.f;
+            const float s0 = av[0][r] * ainv, s1 = av[1][r] * ainv;
+            const uint8_t q0 = (uint8_t)((int)(s0 + copysignf(0.5f, s0)) & 0xFF), q1 = (uint8_t)((int)(s1 + copysignf(0.5f, s1)) & 0xFF);
+            if (tb >= nb) continue;
+            xq_out[((size_t)(col >> 4) * xp_tok + b) * 16 + li] = q0;
+            xq_out[((size_t)((col >> 4) + 1) * xp_tok + b) * 16 + li] = q1;
+            if (li == 0) {
+                const float qf = (float)(_Float16)qsc;
+                const float ahi = __uint_as_float(__float_as_uint(qf) & 0xFFFF0000u), alo = qf - ahi;
+                auto pk = [](float h, float l) { return (__float_as_uint(h) >> 16) | (__float_as_uint(l) & 0xFFFF0000u); };
+                const uint32_t pr = pk(ahi, alo), n0 = pk(ahi * -8388608.f, alo * -8388608.f), n1 = pk(ahi * -4194304.f, alo * -4194304.f);
+                const int blk = col >> 5;
+                xp_out[((size_t)blk * 2 + 0) * xp_tok + b] = make_uint4(pr, pr, n0, n0);
+                xp_out[((size_t)blk * 2 + 1) * xp_tok + b] = make_uint4(0u, 0u, n1, n1);
+            }
+        } else if (tb < nb) {
+            out[(size_t)b * out_stride + col] = av[0][r];
+            out[(size_t)b * out_stride + col + 16] = av[1][r];
+        }
+    }
+}
+
 // LDS attributes of the prefill attention kernels (both plan kinds)
 static int32_t pf_attention_attributes(gl3_ctx* ctx) {
 #define GL3_ATTR150(K_) GL3_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
     GL3_ATTR150(pf_attn_fused_kernel<128>); GL3_ATTR150(pf_attn_fused_kernel<64>); GL3_ATTR150(pf_attn_fused_kernel<32>);
     GL3_ATTR150(pf_attn_fused2_kernel<128>); GL3_ATTR150(pf_attn_fused2_kernel<64>); GL3_ATTR150(pf_attn_fused2_kernel<32>);
+    GL3_ATTR150(pf_attn_fused3_kernel<128>); GL3_ATTR150(pf_attn_fused3_kernel<64>);
     GL3_ATTR150((pf_scores_pk_kernel<128, 4>)); GL3_ATTR150((pf_scores_pk_kernel<128, 2>)); GL3_ATTR150((pf_scores_pk_kernel<128, 1>));
     GL3_ATTR150((pf_scores_pk_kernel<64, 4>)); GL3_ATTR150((pf_scores_pk_kernel<64, 2>)); GL3_ATTR150((pf_scores_pk_kernel<64, 1>));
     GL3_ATTR150((pf_scores_pk_kernel<32, 4>)); GL3_ATTR150((pf_scores_pk_kernel<32, 2>)); GL3_ATTR150((pf_scores_pk_kernel<32, 1>));
@@ -2000,7 +2244,16 @@ static bool pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
                                        KVH, kvmul, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride, xqo, xpo, p->xp_tok); \
         else hipLaunchKernelGGL((pf_attn_fused_kernel<HS_>), dim3(KVH * ntile), dim3(128 * kvmul), sms, s, aa.Q, aa.q_stride, kc1, vc1, aa.out, aa.out_stride, \
                                        KVH, kvmul, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride, xqo, xpo, p->xp_tok); } while (0)
-        if (hs == 128) GL3_FA(128);
+        // r6: products of both phases on the matrix pipe (pf_attn_fused3_kernel: kvMul 4, head size 128 / 64); GL3_PF_FUSED_MFMA=0: the VALU kernels
+        static const bool mfma_off = getenv("GL3_PF_FUSED_MFMA") && atoi(getenv("GL3_PF_FUSED_MFMA")) == 0;
+        const size_t sms3 = fa3_smem_bytes(hs, fa_sstride);
+        if (!mfma_off && !v1_only && kvmul == 4 && (hs == 128 || hs == 64) && sms3 <= 150 * 1024) {
+            if (hs == 128) hipLaunchKernelGGL((pf_attn_fused3_kernel<128>), dim3(KVH * ntile), dim3(512), sms3, s, aa.Q, aa.q_stride, kc1, vc1, aa.out, aa.out_stride,
+                                              KVH, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride, xqo, xpo, p->xp_tok);
+            else hipLaunchKernelGGL((pf_attn_fused3_kernel<64>), dim3(KVH * ntile), dim3(512), sms3, s, aa.Q, aa.q_stride, kc1, vc1, aa.out, aa.out_stride,
+                                    KVH, aa.kv_dim, pos0, n, aa.att_mul, fa_sstride, xqo, xpo, p->xp_tok);
+        }
+        else if (hs == 128) GL3_FA(128);
         else if (hs == 64) GL3_FA(64);
         else GL3_FA(32);
 #undef GL3_FA

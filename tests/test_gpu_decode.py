@@ -357,7 +357,10 @@ def test_batched_prefill_is_bit_identical_to_the_cpu_path(pkg, orc, planmod, cfg
 
 
 @pytest.mark.parametrize("cfg,batch,chunks", [("mid-llama", 128, [100, 57]), ("mid-qwen2", 160, [129, 20]), ("mid-phi3", 128, [65, 70]), ("phi3-hs96", 160, [150]),
-                                             ("mid-granite", 96, [96, 50]), ("mid-qwen3", 36, [36]), ("ragged-llama", 192, [131, 66]), ("ragged-llama", 70, [70, 65, 64])])
+                                             ("mid-granite", 96, [96, 50]), ("mid-qwen3", 36, [36]), ("ragged-llama", 192, [131, 66]), ("ragged-llama", 70, [70, 65, 64]),
+                                             # kvMul 4 with head sizes 128 / 64: the one-launch attention with its products on the matrix pipe (pf_attn_fused3_kernel),
+                                             # chunks that end inside an 8-token tile and start at a non-zero position
+                                             ("mid-devstral", 128, [101, 58]), ("tiny-devstral", 64, [37, 26])])
 def test_batched_prefill_chunks_above_64_tokens(pkg, orc, planmod, cfg, batch, chunks):
     """Chunks of more than 64 tokens take the LDS-tiled GEMM (r6: pf_gemm3_kernel — 128 x 128, 96 x 128 and 64 x 128 workgroup tiles picked by
     the matrix's row count): ragged token counts (the last 128-token tile partly empty), row counts that are no multiple of a tile, K = 9 / 27
