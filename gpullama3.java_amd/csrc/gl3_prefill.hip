@@ -1756,6 +1756,9 @@ __global__ __launch_bounds__(512) void pf_attn_fused3_kernel(const float* __rest
         *reinterpret_cast<float2*>(d) = make_float2(x.x, x.y);
         *reinterpret_cast<float2*>(d + 2) = make_float2(x.z, x.w);
     }
+#ifdef FA_TIMING
+    unsigned long long fa_t0 = __builtin_readcyclecounter(), fa_t1, fa_t2, fa_t3;
+#endif
     // ---- phase 1: scores
     for (int trip = 0; 2 * trip < nkt; ++trip) {
         const int t0 = (2 * trip + grp) * 64;
@@ -1824,6 +1827,9 @@ __global__ __launch_bounds__(512) void pf_attn_fused3_kernel(const float* __rest
         }
         __syncthreads();
     }
+#ifdef FA_TIMING
+    fa_t1 = __builtin_readcyclecounter();
+#endif
     // the first V tile travels while the softmax runs
     {
         const int frows = min(64, tmax + 1);
@@ -1857,6 +1863,9 @@ __global__ __launch_bounds__(512) void pf_attn_fused3_kernel(const float* __rest
         const float sum = tb < nb ? sums[hqr * nb + tb] : 1.f;
         for (int i = lane; i < tend; i += 64) e[i] = i < n ? e[i] / sum : 0.f;
     }
+#ifdef FA_TIMING
+    fa_t2 = __builtin_readcyclecounter();
+#endif
     // ---- phase 3: weighted V sum; wavefront = (row group rg, 32 columns cq)
     const int rg = wave & 1, cq = wave >> 1, cg = lq & 1;
     const bool pv_live = cq < HS / 32;
@@ -1909,6 +1918,10 @@ __global__ __launch_bounds__(512) void pf_attn_fused3_kernel(const float* __rest
     }
 #undef F3_ADD
 #undef FA_REP8
+#ifdef FA_TIMING
+    fa_t3 = __builtin_readcyclecounter();
+    if (lane == 0 && kvh == 0 && (tile % 9) == 0) printf("fa tile %d wave %d: scores %llu softmax %llu pv %llu\n", tile, wave, fa_t1 - fa_t0, fa_t2 - fa_t1, fa_t3 - fa_t2);
+#endif
     if (!pv_live) return;
     const float av[2][4] = {{ac[0], ac[1], ac[2], ac[3]}, {ac[4], ac[5], ac[6], ac[7]}};
 #pragma unroll
