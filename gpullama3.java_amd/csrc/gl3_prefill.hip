@@ -1799,7 +1799,7 @@ __global__ __launch_bounds__(512) void pf_attn_fused3_kernel(const float* __rest
                 const int mn_ = 8 * (G_) + u_ + 1;      /* a constant after unrolling */ \
                 v16f_t Pn_ = Pc; \
                 if (mn_ < NM) Pn_ = __builtin_amdgcn_mfma_f32_16x16x1f32(kreg[mn_ < NM ? mn_ : 0], u_ < 7 ? R_[u_ < 7 ? u_ + 1 : 0] : RN_[0], zero16, 0, 0, 0); \
-                F3_ADD(Pc, sc); \
+                F3_ADD(Pc, sc); asm volatile("" : "+v"(sc)); \
                 __builtin_amdgcn_sched_barrier(0); \
                 Pc = Pn_; } } while (0)
             F3_LDQ(0, qa); F3_LDQ(1, qb); __builtin_amdgcn_sched_barrier(0);
@@ -1897,7 +1897,7 @@ __global__ __launch_bounds__(512) void pf_attn_fused3_kernel(const float* __rest
                 _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) { \
                     v16f_t Pn_ = Pc_; \
                     if (u_ < 7) Pn_ = __builtin_amdgcn_mfma_f32_16x16x1f32(W_[u_ < 7 ? u_ + 1 : 0], V_[u_ < 7 ? u_ + 1 : 0], zero16, 0, 0, 0); \
-                    F3_ADD(Pc_, ac); \
+                    F3_ADD(Pc_, ac); asm volatile("" : "+v"(ac)); \
                     __builtin_amdgcn_sched_barrier(0); \
                     Pc_ = Pn_; } } while (0)
             // groups of 8 MFMAs = 16 timesteps; a group past the tile's last attended pair multiplies zero weights (exact: acc + 0), so the trip
@@ -1956,12 +1956,217 @@ __global__ __launch_bounds__(512) void pf_attn_fused3_kernel(const float* __rest
     }
 }
 
+// r6 — the weighted V sum behind a long context with its products on the matrix pipe (phase 3 of pf_attn_fused3_kernel as a kernel of its own; kvMul 4).
+// Workgroup = (kv head, 16 tokens) = four row groups (one per query head) x HS / 32 column slices = 16 wavefronts; a wavefront advances its
+// 16 rows x 32 columns two timesteps per MFMA: A = w[row][t + parity] (numerator / sum, 0 behind the row's position: staged that way), B = v[t + parity]
+// [column], acc = (acc + P_t) + P_t+1.  Operands are lane-distinct 4-byte LDS reads (pf_pv_ring_kernel's uniform-address weight reads kept the
+// LDS pipe 68 % busy and bound it).  Staging as pf_pv_ring_kernel: the next tile's V rows and numerators travel in registers under the current
+// tile's arithmetic.
+constexpr int PVM_TB = 16, PVM_WP = 68;
+template <int HS>
+__global__ __launch_bounds__(1024) void pf_pv_mfma_kernel(const PfAttnArgs a, int seq, int pos0, int ntok, const float* __restrict__ sums) {
+    constexpr int PITCH = HS + 4, H4 = HS / 4, NT = 1024, VPT = 64 * H4 / NT, KVM = 4;
+    static_assert(VPT >= 1, "a V tile is at least one 16-byte slot per thread");
+    extern __shared__ __attribute__((aligned(16))) float vt[];        // [64][PITCH] V rows, then [4 heads x 16 tokens][PVM_WP] weights
+    float* ws = vt + 64 * PITCH;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int rg = wave & 3, cq = wave >> 2;                          // query head of the kv group, 32-column slice
+    const int lq = lane >> 4, li = lane & 15, par = lq >> 1, cg = lq & 1;
+    const int kvh = blockIdx.x, b0 = blockIdx.y * PVM_TB;
+    const int nb = min(PVM_TB, ntok - b0);
+    const int tmax = pos0 + b0 + nb - 1, ntile = tmax / 64 + 1;
+    const float* vc = a.vcache + (size_t)seq * a.seq_stride + kvh * HS;
+    const v16f_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // staging roles: thread = (row wave + 16 j, timestep lane) of the weights; 16-byte slots t + NT j of the V tile
+    const float* arow[4]; float rsum[4]; int apos[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave + 16 * j, hq = row >> 4, tb = row & 15, b = b0 + min(tb, nb - 1);
+        apos[j] = tb < nb ? pos0 + b0 + tb : -1;
+        arow[j] = a.att + ((size_t)b * a.n_heads + kvh * KVM + hq) * a.ctx;
+        rsum[j] = sums[(size_t)b * a.n_heads + kvh * KVM + hq];
+    }
+    typedef float v4f_native __attribute__((ext_vector_type(4)));
+    v4f_native vreg[VPT]; float areg[4];
+#define PVM_GLOAD(K_) do { const int t0_ = 64 * (K_); \
+        static_for<0, VPT, 1>([&](auto jc) { constexpr int j = decltype(jc)::value; const int i = t + NT * j, r = i / H4, c = i % H4; \
+            vreg[j] = *reinterpret_cast<const v4f_native*>(vc + (size_t)min(t0_ + r, tmax) * a.kv_dim + 4 * c); }); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) areg[j] = arow[j][max(min(t0_ + lane, apos[j]), 0)]; } while (0)
+#define PVM_LSTORE(K_) do { const int t0_ = 64 * (K_); \
+        static_for<0, VPT, 1>([&](auto jc) { constexpr int j = decltype(jc)::value; const int i = t + NT * j, r = i / H4, c = i % H4; \
+            *reinterpret_cast<v4f_native*>(vt + r * PITCH + 4 * c) = vreg[j]; }); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) ws[(wave + 16 * j) * PVM_WP + lane] = t0_ + lane <= apos[j] ? areg[j] / rsum[j] : 0.f; } while (0)
+    v8f_native ac = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // [0..3] column 32 cq + li, [4..7] column 32 cq + 16 + li; tokens 4 lq + r of head rg
+    const bool live = cq < HS / 32;
+    const float* wp = ws + (16 * rg + li) * PVM_WP + par;
+    const float* vp = vt + par * PITCH + 32 * cq + 16 * cg + li;
+    PVM_GLOAD(0);
+    PVM_LSTORE(0);
+    __syncthreads();
+    for (int k = 0; k < ntile; ++k) {
+        PVM_GLOAD(min(k + 1, ntile - 1));                            // unconditional (a condition around the loads makes the compiler drain them)
+        if (live) {
+            const int npair = (min(64, tmax + 1 - 64 * k) + 1) >> 1, ngr = (npair + 7) >> 3;
+            float wa[8], va[8], wb[8], vb8[8];
+#define PVM_ADD(P_, S_) do { S_ = S_ + __builtin_shufflevector(P_, P_, 0, 1, 2, 3, 4, 5, 6, 7); S_ = S_ + __builtin_shufflevector(P_, P_, 8, 9, 10, 11, 12, 13, 14, 15); } while (0)
+#define PVM_LDV(G_, W_, V_) do { _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) { const int m_ = min(8 * (G_) + u_, 31); W_[u_] = wp[2 * m_]; V_[u_] = vp[2 * m_ * PITCH]; } } while (0)
+#define PVM_PV8(W_, V_) do { v16f_t Pc_ = __builtin_amdgcn_mfma_f32_16x16x1f32(W_[0], V_[0], zero16, 0, 0, 0); \
+                _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) { \
+                    v16f_t Pn_ = Pc_; \
+                    if (u_ < 7) Pn_ = __builtin_amdgcn_mfma_f32_16x16x1f32(W_[u_ < 7 ? u_ + 1 : 0], V_[u_ < 7 ? u_ + 1 : 0], zero16, 0, 0, 0); \
+                    PVM_ADD(Pc_, ac); asm volatile("" : "+v"(ac)); \
+                    __builtin_amdgcn_sched_barrier(0); \
+                    Pc_ = Pn_; } } while (0)
+            PVM_LDV(0, wa, va); PVM_LDV(1, wb, vb8); __builtin_amdgcn_sched_barrier(0);
+            int g = 0;
+            for (; g + 2 <= ngr; g += 2) {
+                PVM_PV8(wa, va);
+                PVM_LDV(g + 2, wa, va); __builtin_amdgcn_sched_barrier(0);
+                PVM_PV8(wb, vb8);
+                PVM_LDV(g + 3, wb, vb8); __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g < ngr) PVM_PV8(wa, va);
+#undef PVM_ADD
+#undef PVM_LDV
+#undef PVM_PV8
+        }
+        __syncthreads();
+        PVM_LSTORE(min(k + 1, ntile - 1));
+        __syncthreads();
+    }
+#undef PVM_GLOAD
+#undef PVM_LSTORE
+    if (!live) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int tb = 4 * lq + r;
+        if (tb >= nb) continue;
+        float* o = a.out + (size_t)(b0 + tb) * a.out_stride + (size_t)(kvh * KVM + rg) * HS + 32 * cq + li;
+        o[0] = ac[r]; o[16] = ac[4 + r];
+    }
+}
+
+// r6 — the scores behind a long context with their products on the matrix pipe (phase 1 of pf_attn_fused3_kernel as a kernel of its own; kvMul 4).
+// Workgroup = (kv head, 16 tokens, every S-th K tile): 64 (head, token) rows whose query rows stay in LDS for the workgroup's whole life; 8 wavefronts
+// = 4 quarters of a 64-timestep K tile x 2 pairs of row groups.  Block q of an MFMA = (row group of the pair q & 1, step parity q >> 1): A = k[t][2 m +
+// parity] (the lane's K row, every second element, in registers), B = q[row][2 m + parity] (64 distinct LDS addresses); the chains advance two steps
+// per MFMA, s = (s + P_even) + P_odd, j ascending.  The next K tile travels in registers under the current tile's arithmetic.  Per-tile row maxima
+// for pf_softmax_rows_kernel: registers -> two cross-row exchanges -> one LDS slot per (quarter, row) -> 64 threads fold the quarters.
+constexpr int SCM_TB = 16, SCM_SPLIT = 4;
+template <int HS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void pf_scores_mfma_kernel(const float* __restrict__ Q, int q_stride, const float* __restrict__ kc, float* __restrict__ att,
+                                                             int n_heads, int kv_dim, int ctx, int pos0, int ntok, float att_mul, float* __restrict__ tmx, int tmx_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float kt[];       // [64][PITCH] K rows, then [64 rows][QP] query rows, then [4][64] quarter maxima
+    constexpr int KVM = 4, ROWS = KVM * SCM_TB, PITCH = HS + 4, H4 = HS / 4, QP = HS + 2, NM = HS / 2, NT = 512, KPT = 64 * H4 / NT;
+    static_assert(KPT >= 1 && NM % 16 == 0, "staging slots per thread; operand ring of 8 MFMAs");
+    float* qs = kt + 64 * PITCH;
+    float* mxs = qs + ROWS * QP;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tq = wave & 3, rp = wave >> 2;
+    const int lq = lane >> 4, li = lane & 15, par = lq >> 1, rsel = lq & 1;
+    const int split = blockIdx.x, nsplit = gridDim.x, kvh = blockIdx.y, b0 = blockIdx.z * SCM_TB;
+    const int nb = min(SCM_TB, ntok - b0);
+    const int tmax = pos0 + b0 + nb - 1, ntile = tmax / 64 + 1;
+    if (split >= ntile) return;
+    const float sqrt_hs = (float)sqrt((double)HS);
+    const v16f_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    typedef float v4f_native __attribute__((ext_vector_type(4)));
+    v4f_native kp[KPT];
+#define SCM_KLOAD(TILE_) do { const int t0_ = 64 * (TILE_), rows_ = max(1, min(64, tmax + 1 - t0_)); \
+        static_for<0, KPT, 1>([&](auto jc) { constexpr int j = decltype(jc)::value; const int i = t + NT * j, r = i / H4, c = i % H4; \
+            kp[j] = *reinterpret_cast<const v4f_native*>(kc + (size_t)(min(t0_, tmax) + min(r, rows_ - 1)) * kv_dim + kvh * HS + 4 * c); }); } while (0)
+    SCM_KLOAD(split);
+    for (int i = t; i < ROWS * H4; i += NT) {                        // query rows (tokens past the chunk's end repeat its last token: never stored)
+        const int row = i / H4, c = i % H4;
+        const float4 x = *reinterpret_cast<const float4*>(Q + (size_t)(b0 + min(row & (SCM_TB - 1), nb - 1)) * q_stride + (size_t)(kvh * KVM + (row >> 4)) * HS + 4 * c);
+        float* d = qs + row * QP + 4 * c;
+        *reinterpret_cast<float2*>(d) = make_float2(x.x, x.y);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(x.z, x.w);
+    }
+    const float* qrow = qs + (16 * (2 * rp + rsel) + li) * QP + par;
+    for (int tile = split; tile < ntile; tile += nsplit) {
+        const int t0 = 64 * tile, t1 = min(tmax + 1, t0 + 64);
+        static_for<0, KPT, 1>([&](auto jc) { constexpr int j = decltype(jc)::value; const int i = t + NT * j, r = i / H4, c = i % H4;
+            *reinterpret_cast<v4f_native*>(kt + r * PITCH + 4 * c) = kp[j]; });
+        __syncthreads();
+        SCM_KLOAD(min(tile + nsplit, ntile - 1));                    // unconditional; the last trip re-reads a tile it does not use
+        float mrow[2] = {-INFINITY, -INFINITY};
+        if (t0 + 16 * tq <= tmax) {                                  // this wavefront's 16 timesteps hold at least one attended position
+            const float* krow = kt + min(16 * tq + li, t1 - t0 - 1) * PITCH;
+            float kreg[NM];
+#pragma unroll
+            for (int c = 0; c < H4; ++c) {
+                const v4f_native_s x = *reinterpret_cast<const v4f_native_s*>(krow + 4 * c);
+                kreg[2 * c] = par ? x.y : x.x; kreg[2 * c + 1] = par ? x.w : x.z;
+            }
+            v8f_native sc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // [0..3] row group 2 rp, [4..7] row group 2 rp + 1 (row li of each); timesteps 16 tq + 4 lq + r
+            float qa[8], qb[8];
+#define SCM_LDQ(G_, R_) do { _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) R_[u_] = qrow[2 * (8 * (G_) + u_)]; } while (0)
+#define SCM_ADD(P_, S_) do { S_ = S_ + __builtin_shufflevector(P_, P_, 0, 1, 2, 3, 4, 5, 6, 7); S_ = S_ + __builtin_shufflevector(P_, P_, 8, 9, 10, 11, 12, 13, 14, 15); } while (0)
+#define SCM_MF8(G_, R_, RN_) do { _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) { \
+                const int mn_ = 8 * (G_) + u_ + 1;      /* a constant after unrolling */ \
+                v16f_t Pn_ = Pc; \
+                if (mn_ < NM) Pn_ = __builtin_amdgcn_mfma_f32_16x16x1f32(kreg[mn_ < NM ? mn_ : 0], u_ < 7 ? R_[u_ < 7 ? u_ + 1 : 0] : RN_[0], zero16, 0, 0, 0); \
+                SCM_ADD(Pc, sc); asm volatile("" : "+v"(sc));      /* every element's adds stay with their MFMA (left alone the chains are scalarised, re-vectorised pair by pair and the products spilled) */ \
+                __builtin_amdgcn_sched_barrier(0); \
+                Pc = Pn_; } } while (0)
+            SCM_LDQ(0, qa); SCM_LDQ(1, qb); __builtin_amdgcn_sched_barrier(0);
+            v16f_t Pc = __builtin_amdgcn_mfma_f32_16x16x1f32(kreg[0], qa[0], zero16, 0, 0, 0);
+            static_for<0, NM / 8, 2>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                SCM_MF8(g, qa, qb);
+                SCM_LDQ((g + 2 < NM / 8 ? g + 2 : NM / 8 - 1), qa); __builtin_amdgcn_sched_barrier(0);
+                SCM_MF8(g + 1, qb, qa);
+                SCM_LDQ((g + 3 < NM / 8 ? g + 3 : NM / 8 - 1), qb); __builtin_amdgcn_sched_barrier(0);
+            });
+#undef SCM_LDQ
+#undef SCM_ADD
+#undef SCM_MF8
+#pragma unroll
+            for (int rgp = 0; rgp < 2; ++rgp) {
+                const int tb = li, head = kvh * KVM + 2 * rp + rgp, b = b0 + tb;
+                const int ts0 = t0 + 16 * tq + 4 * lq, lim = tb < nb ? pos0 + b : -1;       // attended: ts <= lim
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = att_mul != 0.f ? sc[4 * rgp + r] * att_mul : sc[4 * rgp + r] / sqrt_hs;
+                    if (ts0 + r <= lim) mrow[rgp] = fmaxf(mrow[rgp], v[r]);
+                }
+                float* o = att + ((size_t)b * n_heads + head) * ctx + ts0;
+                if (ts0 + 3 <= lim) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (ts0 + r <= lim) o[r] = v[r];
+                }
+            }
+        }
+        if (tmx) {                                                   // the quarter's maximum per row: fold the four 16-lane rows, one slot per (quarter, row)
+#pragma unroll
+            for (int rgp = 0; rgp < 2; ++rgp) {
+                float m = mrow[rgp];
+                m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+                if (lq == 0) mxs[tq * ROWS + 16 * (2 * rp + rgp) + li] = m;
+            }
+        }
+        __syncthreads();
+        if (tmx && t < ROWS) {
+            const int tb = t & (SCM_TB - 1), b = b0 + tb;
+            if (tb < nb && t0 <= pos0 + b) {
+                const float m = fmaxf(fmaxf(mxs[t], mxs[ROWS + t]), fmaxf(mxs[2 * ROWS + t], mxs[3 * ROWS + t]));
+                tmx[((size_t)b * n_heads + kvh * KVM + (t >> 4)) * tmx_tiles + tile] = m;
+            }
+        }
+    }
+#undef SCM_KLOAD
+}
+
 // LDS attributes of the prefill attention kernels (both plan kinds)
 static int32_t pf_attention_attributes(gl3_ctx* ctx) {
 #define GL3_ATTR150(K_) GL3_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
     GL3_ATTR150(pf_attn_fused_kernel<128>); GL3_ATTR150(pf_attn_fused_kernel<64>); GL3_ATTR150(pf_attn_fused_kernel<32>);
     GL3_ATTR150(pf_attn_fused2_kernel<128>); GL3_ATTR150(pf_attn_fused2_kernel<64>); GL3_ATTR150(pf_attn_fused2_kernel<32>);
     GL3_ATTR150(pf_attn_fused3_kernel<128>); GL3_ATTR150(pf_attn_fused3_kernel<64>);
+    GL3_ATTR150(pf_scores_mfma_kernel<128>); GL3_ATTR150(pf_scores_mfma_kernel<64>); GL3_ATTR150(pf_pv_mfma_kernel<128>); GL3_ATTR150(pf_pv_mfma_kernel<64>);
     GL3_ATTR150((pf_scores_pk_kernel<128, 4>)); GL3_ATTR150((pf_scores_pk_kernel<128, 2>)); GL3_ATTR150((pf_scores_pk_kernel<128, 1>));
     GL3_ATTR150((pf_scores_pk_kernel<64, 4>)); GL3_ATTR150((pf_scores_pk_kernel<64, 2>)); GL3_ATTR150((pf_scores_pk_kernel<64, 1>));
     GL3_ATTR150((pf_scores_pk_kernel<32, 4>)); GL3_ATTR150((pf_scores_pk_kernel<32, 2>)); GL3_ATTR150((pf_scores_pk_kernel<32, 1>));
@@ -2285,7 +2490,14 @@ static bool pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
 #define GL3_SCORES(HS_) do { if (pk) { if (kvmul == 4) GL3_SCORES_PK(HS_, 4); else if (kvmul == 2) GL3_SCORES_PK(HS_, 2); else GL3_SCORES_PK(HS_, 1); } \
         else hipLaunchKernelGGL((pf_scores_tiled_kernel<HS_>), g1, b1, sms, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, kvmul, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul, \
                                            rows_softmax ? p->TMX : nullptr, p->tmx_tiles); } while (0)
-        if (hs == 128) GL3_SCORES(128);
+        static const bool scm_off = getenv("GL3_PF_SCORES_MFMA") && atoi(getenv("GL3_PF_SCORES_MFMA")) == 0;
+        if (rows_softmax && !scm_off && kvmul == 4 && (hs == 128 || hs == 64)) {      // r6: products on the matrix pipe, query rows resident, K tiles prefetched
+            const dim3 g(nsplit < SCM_SPLIT ? nsplit : SCM_SPLIT, KVH, (n + SCM_TB - 1) / SCM_TB);
+            const size_t sm = ((size_t)64 * (hs + 4) + 4 * SCM_TB * (hs + 2) + 4 * 4 * SCM_TB) * 4;
+            if (hs == 128) hipLaunchKernelGGL((pf_scores_mfma_kernel<128>), g, dim3(512), sm, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul, p->TMX, p->tmx_tiles);
+            else hipLaunchKernelGGL((pf_scores_mfma_kernel<64>), g, dim3(512), sm, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul, p->TMX, p->tmx_tiles);
+        }
+        else if (hs == 128) GL3_SCORES(128);
         else if (hs == 64) GL3_SCORES(64);
         else GL3_SCORES(32);
 #undef GL3_SCORES
@@ -2307,7 +2519,13 @@ static bool pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
         static const bool ring_off = getenv("GL3_PF_PV_RING") && atoi(getenv("GL3_PF_PV_RING")) == 0;
         const size_t pv_sm = (size_t)64 * (hs + PA_TB) * 4, pvr_sm = (size_t)64 * (hs + PVR_TB) * 4;
         const dim3 pvr_grid(H, (n + PVR_TB - 1) / PVR_TB), pvr_block(64 * PVR_NW);
-        if (sums && !ring_off) {
+        static const bool pvm_off = getenv("GL3_PF_PV_MFMA") && atoi(getenv("GL3_PF_PV_MFMA")) == 0;
+        if (sums && !pvm_off && kvmul == 4 && (hs == 128 || hs == 64)) {      // r6: products on the matrix pipe (no uniform-address LDS reads)
+            const dim3 g(KVH, (n + PVM_TB - 1) / PVM_TB);
+            const size_t sm = ((size_t)64 * (hs + 4) + 4 * PVM_TB * PVM_WP) * 4;
+            if (hs == 128) hipLaunchKernelGGL((pf_pv_mfma_kernel<128>), g, dim3(1024), sm, s, aa, one_seq, pos0, n, sums);
+            else hipLaunchKernelGGL((pf_pv_mfma_kernel<64>), g, dim3(1024), sm, s, aa, one_seq, pos0, n, sums);
+        } else if (sums && !ring_off) {
             if (hs == 128) hipLaunchKernelGGL((pf_pv_ring_kernel<128>), pvr_grid, pvr_block, pvr_sm, s, aa, one_seq, pos0, n, sums);
             else if (hs == 64) hipLaunchKernelGGL((pf_pv_ring_kernel<64>), pvr_grid, pvr_block, pvr_sm, s, aa, one_seq, pos0, n, sums);
             else hipLaunchKernelGGL((pf_pv_ring_kernel<32>), pvr_grid, pvr_block, pvr_sm, s, aa, one_seq, pos0, n, sums);
