@@ -1799,6 +1799,7 @@ __global__ __launch_bounds__(512) void pf_attn_fused3_kernel(const float* __rest
                 const int mn_ = 8 * (G_) + u_ + 1;      /* a constant after unrolling */ \
                 v16f_t Pn_ = Pc; \
                 if (mn_ < NM) Pn_ = __builtin_amdgcn_mfma_f32_16x16x1f32(kreg[mn_ < NM ? mn_ : 0], u_ < 7 ? R_[u_ < 7 ? u_ + 1 : 0] : RN_[0], zero16, 0, 0, 0); \
+ __builtin_amdgcn_sched_barrier(0); \
                 F3_ADD(Pc, sc); asm volatile("" : "+v"(sc)); \
                 __builtin_amdgcn_sched_barrier(0); \
                 Pc = Pn_; } } while (0)
@@ -1897,6 +1898,7 @@ __global__ __launch_bounds__(512) void pf_attn_fused3_kernel(const float* __rest
                 _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) { \
                     v16f_t Pn_ = Pc_; \
                     if (u_ < 7) Pn_ = __builtin_amdgcn_mfma_f32_16x16x1f32(W_[u_ < 7 ? u_ + 1 : 0], V_[u_ < 7 ? u_ + 1 : 0], zero16, 0, 0, 0); \
+ __builtin_amdgcn_sched_barrier(0); \
                     F3_ADD(Pc_, ac); asm volatile("" : "+v"(ac)); \
                     __builtin_amdgcn_sched_barrier(0); \
                     Pc_ = Pn_; } } while (0)
@@ -2014,6 +2016,7 @@ __global__ __launch_bounds__(1024) void pf_pv_mfma_kernel(const PfAttnArgs a, in
                 _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) { \
                     v16f_t Pn_ = Pc_; \
                     if (u_ < 7) Pn_ = __builtin_amdgcn_mfma_f32_16x16x1f32(W_[u_ < 7 ? u_ + 1 : 0], V_[u_ < 7 ? u_ + 1 : 0], zero16, 0, 0, 0); \
+ __builtin_amdgcn_sched_barrier(0); \
                     PVM_ADD(Pc_, ac); asm volatile("" : "+v"(ac)); \
                     __builtin_amdgcn_sched_barrier(0); \
                     Pc_ = Pn_; } } while (0)
@@ -2492,7 +2495,8 @@ static bool pf_attention(gl3_ctx* ctx, int l, int n, int max_pos, int one_seq, f
                                            rows_softmax ? p->TMX : nullptr, p->tmx_tiles); } while (0)
         static const bool scm_off = getenv("GL3_PF_SCORES_MFMA") && atoi(getenv("GL3_PF_SCORES_MFMA")) == 0;
         if (rows_softmax && !scm_off && kvmul == 4 && (hs == 128 || hs == 64)) {      // r6: products on the matrix pipe, query rows resident, K tiles prefetched
-            const dim3 g(nsplit < SCM_SPLIT ? nsplit : SCM_SPLIT, KVH, (n + SCM_TB - 1) / SCM_TB);
+            static const int scm_split = getenv("GL3_SCM_SPLIT") ? atoi(getenv("GL3_SCM_SPLIT")) : SCM_SPLIT;      // workgroups that share a (kv head, token tile)'s K tiles
+            const dim3 g(nsplit < scm_split ? nsplit : scm_split, KVH, (n + SCM_TB - 1) / SCM_TB);
             const size_t sm = ((size_t)64 * (hs + 4) + 4 * SCM_TB * (hs + 2) + 4 * 4 * SCM_TB) * 4;
             if (hs == 128) hipLaunchKernelGGL((pf_scores_mfma_kernel<128>), g, dim3(512), sm, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul, p->TMX, p->tmx_tiles);
             else hipLaunchKernelGGL((pf_scores_mfma_kernel<64>), g, dim3(512), sm, s, aa.Q, aa.q_stride, kc1, aa.att, aa.n_heads, aa.kv_dim, aa.ctx, pos0, n, aa.att_mul, p->TMX, p->tmx_tiles);
