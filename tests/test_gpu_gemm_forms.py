@@ -41,14 +41,26 @@ def test_k_split_small_batch_gemm_stays_bit_exact():
     assert " passed" in out.stdout and "failed" not in out.stdout, tail
 
 
-@pytest.mark.parametrize("env", [{"GL3_PF_FUSED_ATTN": "0"}, {"GL3_PF_FUSED_ATTN": "0", "GL3_PF_SOFTMAX_ROWS": "0"}], ids=["three-kernels", "three-kernels-row-per-wavefront"])
-def test_three_kernel_prefill_attention_at_every_depth(env):
-    """GL3_PF_FUSED_ATTN=0: scores / softmax / weighted V sum as three launches from position 0 (by default only chunks whose score rows do not
-    fit the one-launch kernel's LDS take them); GL3_PF_SOFTMAX_ROWS=0: the r1 softmax kernel (one row per wavefront, normalises in place)
-    instead of pf_softmax_rows_kernel.  Ragged chunks, chunks at non-zero positions, the 8B / 1B layers at 512 tokens."""
+@pytest.mark.parametrize("env,select", [
+    ({"GL3_PF_FUSED_ATTN": "0"}, "chunks_above_64 or prefill512 or long_context_prefill or behind_1000 or batched_prefill_is_bit"),
+    ({"GL3_PF_FUSED_ATTN": "0", "GL3_PF_SOFTMAX_ROWS": "0"}, "chunks_above_64 or prefill512 or long_context_prefill or behind_1000 or batched_prefill_is_bit"),
+    ({"GL3_PF_FUSED_ATTN": "0", "GL3_PF_SCORES_MFMA": "0", "GL3_PF_PV_MFMA": "0"}, "chunks_above_64 or long_context_prefill or behind_1000"),
+    ({"GL3_PF_FUSED_ATTN": "0", "GL3_PF_SCORES_MFMA": "0", "GL3_PF_SCORES_PK": "0", "GL3_PF_PV_MFMA": "0", "GL3_PF_PV_RING": "0"}, "chunks_above_64 or long_context_prefill or behind_1000"),
+    ({"GL3_PF_FUSED_MFMA": "0"}, "chunks_above_64 or prefill512"),
+    ({"GL3_PF_FUSED_V1": "1"}, "chunks_above_64 or prefill512")],
+    ids=["three-kernels", "three-kernels-row-per-wavefront", "three-kernels-valu-packed", "three-kernels-valu-scalar", "one-launch-valu-packed", "one-launch-r4"])
+def test_prefill_attention_forms(env, select):
+    """The forms of the prefill attention stay bit-exact, each in its own process (switches are read once):
+       default                      one launch with MFMA products (pf_attn_fused3_kernel) while a tile's score rows fit LDS, else pf_scores_mfma_kernel ->
+                                    pf_softmax_rows_kernel -> pf_pv_mfma_kernel (kvMul 4, head size 128 / 64; other shapes: the VALU kernels)
+       GL3_PF_FUSED_ATTN=0          the three kernels from position 0
+       GL3_PF_SOFTMAX_ROWS=0        the r1 softmax kernel (one row per wavefront, normalises in place) and the r1 V-sum kernel
+       GL3_PF_SCORES_MFMA=0 / GL3_PF_PV_MFMA=0     packed-f32 VALU products (pf_scores_pk_kernel, pf_pv_ring_kernel); + _PK=0 / _RING=0: the scalar r1 kernels
+       GL3_PF_FUSED_MFMA=0 / GL3_PF_FUSED_V1=1     the one-launch kernel with packed-f32 VALU products (fused2) / the r4 kernel
+    Ragged chunks, chunks at non-zero positions, the 8B / 1B layers at 512 tokens and behind 1000 positions."""
     e = dict(os.environ, **env)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_decode.py"), os.path.join(ROOT, "tests", "test_gpu_fullsize.py"),
-                          "-m", "gpu", "-x", "-q", "-k", "chunks_above_64 or prefill512 or long_context_prefill or behind_1000 or batched_prefill_is_bit", "-p", "no:cacheprovider"],
+                          "-m", "gpu", "-x", "-q", "-k", select, "-p", "no:cacheprovider"],
                          capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
     tail = out.stdout[-1500:] + out.stderr[-500:]
     assert out.returncode == 0, tail
