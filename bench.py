@@ -197,11 +197,11 @@ def main():
 
     def timed(fn, steps, warmup):
         import gc
-        for _ in range(warmup):
-            fn()
-        samples = []
         gc.collect()                            # the timed window measures the forward calls, not a generation-2 collection of the host model's objects
         gc.disable()                            # (seen as one repetition of five 12 % slower whenever the host copy of the weights was alive)
+        for _ in range(warmup):                 # warm-up directly in front of the timed window: the collection above idles the device for a few hundred
+            fn()                                # milliseconds, and the first 15 ms prefill repetition behind such a pause ran 10 % below the others
+        samples = []
         barrier()
         t_start = time.perf_counter()
         for _ in range(steps):
