@@ -427,7 +427,8 @@ static void launch_attention(gl3_ctx* ctx, int l, int which /* 0 both, 1 scores,
     }
     else if (which != 2) hipLaunchKernelGGL(attn_scores_kernel, dim3(ctx->n_tsplit, ctx->kv_heads_l), dim3(64 * kvmul), sm1, ctx->stream, aa);
     if (which != 1 && amode == ATT_LONG) {
-        hipLaunchKernelGGL(attn_exp_kernel, dim3((d.ctx + EXP_ROW - 1) / EXP_ROW, ctx->heads_l), dim3(256), 0, ctx->stream, aa, ctx->n_tsplit);
+        const int exp_rows = (d.ctx + EXP_ROW - 1) / EXP_ROW;
+        hipLaunchKernelGGL(attn_exp_kernel, dim3(exp_rows < EXP_GRID_MAX ? exp_rows : EXP_GRID_MAX, ctx->heads_l), dim3(256), 0, ctx->stream, aa, ctx->n_tsplit);
         hipLaunchKernelGGL(attn_sum_kernel, dim3(ctx->heads_l), dim3(256), attn_sum_smem(), ctx->stream, aa);
         hipLaunchKernelGGL(attn_pv_kernel, dim3(ctx->kv_heads_l * attn_pv_hq(kvmul) * (d.head_size / PV_COLS16)), dim3(64 * PV_WAVES), attn_pv_smem(), ctx->stream, aa);
     } else if (which != 1)

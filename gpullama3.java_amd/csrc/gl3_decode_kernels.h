@@ -1453,16 +1453,17 @@ constexpr int SMX_CHUNK = 4096;
 __host__ __device__ constexpr size_t attn_sum_smem() { return (size_t)(SMX_CHUNK + 32) * 4 + ss_scratch_bytes(SMX_CHUNK); }
 constexpr int EXP_ROW = 1024;              // scores per attn_exp_kernel workgroup
 
-// e_t = (float)exp((double)(s_t - max)) for EXP_ROW scores of one head: grid = (ceil(ctx / EXP_ROW), heads), 256 threads.  The double-precision
-// exp is ~250 instructions; one workgroup per head (the first form of this path) needed 7 us per 4096 scores for it alone — the VALU of one
-// CU — so it is spread over the chip.  max = fold of the per-tile maxima attn_scores_kernel left in tmax.  The numerators go to att_t in
-// attn_pv_kernel's operand order [kv head][head quad][t][PV_G] (the PV_G heads of a timestep are one 16-byte load there).
+// e_t = (float)exp((double)(s_t - max)) for rows of EXP_ROW scores of one head: grid = (min(ceil(ctx / EXP_ROW), EXP_GRID_MAX), heads), 256 threads,
+// workgroup x takes the rows x, x + gridDim.x, ... (r6: a grid of ceil(ctx / EXP_ROW) left 128 x heads workgroups per layer at a 128 k context of
+// which all but ceil((pos + 1) / EXP_ROW) rows exit at once).  One workgroup per head (the first form of this path) needed 7 us per 4096 scores
+// for the exp alone — the VALU of one CU — so it is spread over the chip.  max = fold of the per-tile maxima attn_scores_kernel left in tmax.  The
+// numerators go to att_t in attn_pv_kernel's operand order [kv head][head quad][t][PV_G] (the PV_G heads of a timestep are one 16-byte load there).
+constexpr int EXP_GRID_MAX = 16;      // 16 k positions in one pass; the 21 k-position test takes the second trip
 static __global__ __launch_bounds__(256) void attn_exp_kernel(const AttnArgs a, int n_tiles_max) {
     __shared__ float red_s[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int h = blockIdx.y, n = a.dyn[1] + 1;
-    const int i0 = blockIdx.x * EXP_ROW;
-    if (i0 >= n) return;
+    if (blockIdx.x * EXP_ROW >= n) return;
     const int ntile = (n + ATT_TT - 1) / ATT_TT;
     float mx = -INFINITY;
     for (int i = t; i < ntile; i += 256) mx = fmaxf(mx, a.tmax[(size_t)h * n_tiles_max + i]);
@@ -1473,10 +1474,12 @@ static __global__ __launch_bounds__(256) void attn_exp_kernel(const AttnArgs a, 
     const int kvmul = a.n_heads / a.n_kv_heads, kvh = h / kvmul, gq = h % kvmul;
     const float* sc = a.att + (size_t)h * a.att_stride;
     float* at = a.att_t + (size_t)(kvh * attn_pv_hq(kvmul) + gq / PV_G) * a.att_stride * PV_G + (gq % PV_G);
+    for (int i0 = blockIdx.x * EXP_ROW; i0 < n; i0 += gridDim.x * EXP_ROW) {
 #pragma unroll
-    for (int u = 0; u < EXP_ROW / 256; ++u) {
-        const int i = i0 + t + 256 * u;
-        if (i < n) at[(size_t)i * PV_G] = (float)exp((double)(sc[i] - mx));
+        for (int u = 0; u < EXP_ROW / 256; ++u) {
+            const int i = i0 + t + 256 * u;
+            if (i < n) at[(size_t)i * PV_G] = (float)exp((double)(sc[i] - mx));
+        }
     }
 }
 
