@@ -43,11 +43,11 @@ def test_k_split_small_batch_gemm_stays_bit_exact():
 
 @pytest.mark.parametrize("env,select", [
     ({"GL3_PF_FUSED_ATTN": "0"}, "chunks_above_64 or prefill512 or long_context_prefill or behind_1000 or batched_prefill_is_bit"),
-    ({"GL3_PF_FUSED_ATTN": "0", "GL3_PF_SOFTMAX_ROWS": "0"}, "chunks_above_64 or prefill512 or long_context_prefill or behind_1000 or batched_prefill_is_bit"),
+    ({"GL3_PF_FUSED_ATTN": "0", "GL3_PF_SOFTMAX_ROWS": "0"}, "chunks_above_64 or long_context_prefill or behind_1000 or batched_prefill_is_bit"),
     ({"GL3_PF_FUSED_ATTN": "0", "GL3_PF_SCORES_MFMA": "0", "GL3_PF_PV_MFMA": "0"}, "chunks_above_64 or long_context_prefill or behind_1000"),
-    ({"GL3_PF_FUSED_ATTN": "0", "GL3_PF_SCORES_MFMA": "0", "GL3_PF_SCORES_PK": "0", "GL3_PF_PV_MFMA": "0", "GL3_PF_PV_RING": "0"}, "chunks_above_64 or long_context_prefill or behind_1000"),
-    ({"GL3_PF_FUSED_MFMA": "0"}, "chunks_above_64 or prefill512"),
-    ({"GL3_PF_FUSED_V1": "1"}, "chunks_above_64 or prefill512")],
+    ({"GL3_PF_FUSED_ATTN": "0", "GL3_PF_SCORES_MFMA": "0", "GL3_PF_SCORES_PK": "0", "GL3_PF_PV_MFMA": "0", "GL3_PF_PV_RING": "0"}, "chunks_above_64 or long_context_prefill"),
+    ({"GL3_PF_FUSED_MFMA": "0"}, "chunks_above_64 or llama3_8b_shaped_layer_prefill512"),
+    ({"GL3_PF_FUSED_V1": "1"}, "chunks_above_64 or long_context_prefill")],
     ids=["three-kernels", "three-kernels-row-per-wavefront", "three-kernels-valu-packed", "three-kernels-valu-scalar", "one-launch-valu-packed", "one-launch-r4"])
 def test_prefill_attention_forms(env, select):
     """The forms of the prefill attention stay bit-exact, each in its own process (switches are read once):
