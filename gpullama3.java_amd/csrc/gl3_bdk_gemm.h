@@ -10,8 +10,10 @@
 //     array; the chain wavefront adds the P tiles of the previous round in block order — a ds_read_b128 and four adds per block — and owns the epilogue.
 //   * one raw `s_waitcnt lgkmcnt(0); s_barrier` per round (P tiles): a __syncthreads() would carry vmcnt(0) and drain the producers' load rings
 //     (profiles/r05_tg_depth.md, the lesson of attn_pv_kernel).  r2's k-slice experiments were measured with __syncthreads().
-//   * loads are unconditional (past the end of a strip the last tile is re-read: a uniform clamp of the tile index); tiles / blocks past the end are
-//     skipped by the chain.
+//   * loads are unconditional and unclamped (uniform bases + running 32-bit lane offsets; the reads past the end of a strip land in the next strip or
+//     in GL3_TAIL_PAD); tiles / blocks past the end are skipped by the chain, whose full rounds add without per-block conditions.
+//   * two workgroups per CU in the launch bounds: a register budget of 256 makes the compiler pick the VGPR form of the MFMAs (with 512 it
+//     parked the results in AGPRs: 16 v_accvgpr_read per tile on a wavefront that is bound by its own issue rate).
 #pragma once
 #include "gl3_bd_gemm.h"
 
@@ -22,7 +24,7 @@ template <int EPI, int P, bool QOUT>
 __host__ __device__ constexpr int bdk_lds_bytes() { return (QOUT ? 2 : 1) * bdk_group_floats<(EPI == EPI_SWIGLU ? 2 : 1), P>() * 4; }
 
 template <int EPI, int P, int DA, bool QOUT = false, int TS = BD_TS>
-__global__ __launch_bounds__(64 * (QOUT ? 2 : 1) * (P + 1)) void bdk_gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(64 * (QOUT ? 2 : 1) * (P + 1), 2) void bdk_gemm_kernel(const GemmArgs a) {
     static_assert(!QOUT || EPI == EPI_SWIGLU, "the quantising epilogue is the SwiGLU one");
     static_assert(DA % 2 == 0 && DA % BDK_T == 0, "ring slots are static under the unroll; a round is a whole number of ring slots");
     constexpr int T = BDK_T;
@@ -58,32 +60,32 @@ __global__ __launch_bounds__(64 * (QOUT ? 2 : 1) * (P + 1)) void bdk_gemm_kernel
 
     if (role < P) {
         // ------------------------------------------------------------------------------------------------ producer
+        // addresses: uniform bases (SGPRs) + running 32-bit lane offsets, advanced by compile-time steps — a producer's tiles are role * T + j of
+        // every round of P * T tiles — and nothing is clamped: the rings read up to 2 * DA * P tiles past the end of a strip / of the
+        // activations (GL3_TAIL_PAD covers it for P <= 3; those products are never added)
         const size_t strip_bytes = (size_t)a.ng * TILE_BYTES;
         const uint8_t* pa[NM];
 #pragma unroll
         for (int m = 0; m < NM; ++m) pa[m] = (m == 0 ? a.w : a.w2) + (size_t)strip * strip_bytes;
         const uint8_t* pb = a.XQ;
-        const float* px = a.XS;
-        const uint32_t la = ((g & 1) ? 1152 : 128) + 16 * (t + 16 * (g >> 1));
-        const uint32_t lh = 4 * (lane & 31);
-        const uint32_t lb = (16 * h + t) * 64 + 16 * g;
-        const uint32_t lx = ((16 * h + t) * 4 + g) * 4;
+        const uint8_t* px = reinterpret_cast<const uint8_t*>(a.XS);
+        uint32_t oa = (uint32_t)(role * T) * TILE_BYTES + ((g & 1) ? 1152 : 128) + 16 * (t + 16 * (g >> 1));
+        uint32_t oh = (uint32_t)(role * T) * TILE_BYTES + 4 * (lane & 31);
+        uint32_t ob = (uint32_t)(role * T) * (2 * TS * 64) + (16 * h + t) * 64 + 16 * g;
+        uint32_t ox = (uint32_t)(role * T) * (TS * 16) + ((16 * h + t) * 4 + g) * 4;
         v4i_t Ar[NM][DA][2]; uint32_t Hr[NM][DA]; v2l_t Br[DA][2]; float Xr[DA];
-        int fk = 0;                                      // local index of the tile the next fetch reads: round fk / T, tile role * T + fk % T of it
-        auto fetch = [&](int u) {                        // this producer's next tile -> ring slot u.  Unconditional: past the end of the strip the LAST
-            const int tf = min((fk / T) * (P * T) + role * T + fk % T, ntiles - 1);      // tile is re-read (a uniform clamp; the chain never adds those products)
+        auto fetch = [&](int u) {                        // this producer's next tile -> ring slot u (u % T = its index in the round's share)
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                const uint8_t* pt = pa[m] + (size_t)tf * TILE_BYTES;
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) Ar[m][u][jj] = *reinterpret_cast<const v4i_t*>(pt + la + 512 * jj);
-                Hr[m][u] = *reinterpret_cast<const uint32_t*>(pt + lh);
+                for (int jj = 0; jj < 2; ++jj) Ar[m][u][jj] = *reinterpret_cast<const v4i_t*>(pa[m] + oa + 512 * jj);
+                Hr[m][u] = *reinterpret_cast<const uint32_t*>(pa[m] + oh);
             }
-            const uint8_t* pbt = pb + (size_t)tf * (2 * TS * 64);
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) Br[u][jj] = *reinterpret_cast<const v2l_t*>(pbt + lb + jj * (TS * 64));
-            Xr[u] = *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(px + (size_t)tf * (TS * 4)) + lx);
-            ++fk;
+            for (int jj = 0; jj < 2; ++jj) Br[u][jj] = *reinterpret_cast<const v2l_t*>(pb + ob + jj * (TS * 64));
+            Xr[u] = *reinterpret_cast<const float*>(px + ox);
+            const uint32_t step = (u % T == T - 1) ? (uint32_t)(P * T - T + 1) : 1u;      // tiles to this producer's next one
+            oa += step * TILE_BYTES; oh += step * TILE_BYTES; ob += step * (2 * TS * 64); ox += step * (TS * 16);
         };
         auto park = [&](int u, int k) {                  // scales of the tile in ring slot u (local tile k) -> LDS slot k & 3
 #pragma unroll
@@ -172,23 +174,28 @@ __global__ __launch_bounds__(64 * (QOUT ? 2 : 1) * (P + 1)) void bdk_gemm_kernel
                     for (int e = 0; e < 4 * NM; ++e) pv[set][e] = *reinterpret_cast<const float4*>(src + (w * 4 * NM + e) * 256);
                 };
                 rd(0, 0);
+                auto adds = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-                for (int w = 0; w < P * T; ++w) {                             // producer w / T, its tile w % T: ascending tile order
-                    if (w + 1 < P * T) rd(w + 1, (w + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int nv = a.nb - 4 * ((k - 1) * P * T + w);         // real blocks of this tile (<= 0: past the end)
+                    for (int w = 0; w < P * T; ++w) {                         // producer w / T, its tile w % T: ascending tile order
+                        if (w + 1 < P * T) rd(w + 1, (w + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int nv = FULL ? 4 : a.nb - 4 * ((k - 1) * P * T + w);      // real blocks of this tile (<= 0: past the end)
 #pragma unroll
-                    for (int bi = 0; bi < 4; ++bi) {
-                        if (bi >= nv) continue;
+                        for (int bi = 0; bi < 4; ++bi) {
+                            if (!FULL && bi >= nv) continue;
 #pragma unroll
-                        for (int m = 0; m < NM; ++m) {
-                            const float4 p = pv[w & 1][bi * NM + m];
-                            acc[m][0] = acc[m][0] + v2f_t{p.x, p.y};         // result +=, blocks ascending
-                            acc[m][1] = acc[m][1] + v2f_t{p.z, p.w};
+                            for (int m = 0; m < NM; ++m) {
+                                const float4 p = pv[w & 1][bi * NM + m];
+                                acc[m][0] = acc[m][0] + v2f_t{p.x, p.y};     // result +=, blocks ascending
+                                acc[m][1] = acc[m][1] + v2f_t{p.z, p.w};
+                            }
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                };
+                if (4 * k * P * T <= a.nb) adds(std::true_type{});            // every block of the round is a real one: no per-block conditions
+                else adds(std::false_type{});
             }
             BDK_BARRIER();
         }

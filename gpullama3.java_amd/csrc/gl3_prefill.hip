@@ -2281,6 +2281,10 @@ int32_t gl3_prefill_alloc(gl3_ctx* ctx) {
 #define GL3_BDK_ATTRS(P_, TS_) GL3_BDK_ATTR(EPI_STORE, P_, 4, false, TS_); GL3_BDK_ATTR(EPI_RESID, P_, 4, false, TS_); GL3_BDK_ATTR(EPI_SWIGLU, P_, 4, false, TS_); GL3_BDK_ATTR(EPI_SWIGLU, (P_ > 2 ? 2 : P_), 4, true, TS_)
     GL3_BDK_ATTRS(2, BD_TS); GL3_BDK_ATTRS(3, BD_TS); GL3_BDK_ATTRS(4, BD_TS); GL3_BDK_ATTRS(2, BD_TS_MAX); GL3_BDK_ATTRS(3, BD_TS_MAX); GL3_BDK_ATTRS(4, BD_TS_MAX);
 #undef GL3_BDK_ATTRS
+    // ring of 8 tiles per producer (GL3_BDK_DA=8): single-matrix classes only
+#define GL3_BDK_ATTRS8(P_, TS_) GL3_BDK_ATTR(EPI_STORE, P_, 8, false, TS_); GL3_BDK_ATTR(EPI_RESID, P_, 8, false, TS_)
+    GL3_BDK_ATTRS8(2, BD_TS); GL3_BDK_ATTRS8(3, BD_TS); GL3_BDK_ATTRS8(2, BD_TS_MAX); GL3_BDK_ATTRS8(3, BD_TS_MAX);
+#undef GL3_BDK_ATTRS8
 #undef GL3_BDK_ATTR
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GL3_HIP(hipFuncSetAttribute((const void*)pf_attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -2343,6 +2347,16 @@ static void launch_gemm(gl3_ctx* ctx, const Q8Mat& w, const Q8Mat* w2, int ntok,
         } while (0)
 #define GL3_BDK(TS_) do { if (bdk_p == 2) GL3_BDK_L(2, TS_); else if (bdk_p == 4) GL3_BDK_L(4, TS_); else GL3_BDK_L(3, TS_); } while (0)
         static const int bdk_gu = getenv("GL3_BDK_GU") ? atoi(getenv("GL3_BDK_GU")) : 1;      // 0: the gate + up launch stays on bdw_gemm_kernel
+        static const int bdk_da = getenv("GL3_BDK_DA") ? atoi(getenv("GL3_BDK_DA")) : 4;      // tiles in flight per producer (8: single-matrix classes, P = 2 / 3)
+        if constexpr (EPI != EPI_SWIGLU) {
+            if (bdk && bdk_da == 8 && bdk_p <= 3) {
+#define GL3_BDK8(P_, TS_) hipLaunchKernelGGL((bdk_gemm_kernel<EPI, P_, 8, false, TS_>), grid, dim3(64 * (P_ + 1)), (bdk_lds_bytes<EPI, P_, false>()), ctx->stream, a)
+                if (ts == BD_TS) { if (bdk_p == 2) GL3_BDK8(2, BD_TS); else GL3_BDK8(3, BD_TS); }
+                else { if (bdk_p == 2) GL3_BDK8(2, BD_TS_MAX); else GL3_BDK8(3, BD_TS_MAX); }
+#undef GL3_BDK8
+                return;
+            }
+        }
         if (bdk && (EPI != EPI_SWIGLU || bdk_gu)) { if (ts == BD_TS) GL3_BDK(BD_TS); else GL3_BDK(BD_TS_MAX); return; }
 #undef GL3_BDK
 #undef GL3_BDK_L
