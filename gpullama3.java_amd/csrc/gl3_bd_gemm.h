@@ -83,6 +83,9 @@ __global__ __launch_bounds__(QOUT ? 128 : 64, WPE) void bdw_gemm_kernel(const Ge
     __shared__ float amax_s[NWV][64];
     const int lane = threadIdx.x & 63, t = lane & 15, g = lane >> 4;
     const int wv = QOUT ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+#ifdef BDW_TIMING
+    const unsigned long long bdw_t0 = __builtin_readcyclecounter(), bdw_w0 = wall_clock64();
+#endif
     float* wsl = wsl_all[wv];
     float* xsl = xsl_all[wv];
     const int NTG = (a.ntok + 15) >> 4;                                         // token tiles of this launch
@@ -220,6 +223,14 @@ __global__ __launch_bounds__(QOUT ? 128 : 64, WPE) void bdw_gemm_kernel(const Ge
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#ifdef BDW_TIMING
+    // per-wavefront record: where it ran (XCC, SE, CU, SIMD of HW_ID), when it started (100 MHz wall clock) and how many cycles its K walk took
+    if (lane == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
+        printf("bdw EPI %d rows %d nb %d wg %d xcc %u se %u cu %u simd %u start %llu cycles %llu\n", EPI, a.rows, a.nb, (int)blockIdx.x, xcc & 15, (hw >> 13) & 7, (hw >> 8) & 15,
+               (hw >> 4) & 3, bdw_w0, __builtin_readcyclecounter() - bdw_t0);
+    }
+#endif
     // epilogue.  C layout: token = 16 h + (lane & 15), weight rows 4g .. 4g + 3 of the strip
     const int b = 16 * h + t;
     if constexpr (QOUT) {
