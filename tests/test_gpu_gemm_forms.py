@@ -29,12 +29,16 @@ def test_prefill_parity_of_a_gemm_form(env):
     assert " passed" in out.stdout and "failed" not in out.stdout, tail
 
 
-def test_k_split_small_batch_gemm_stays_bit_exact():
+@pytest.mark.parametrize("env,select", [({"GL3_BDK_P": "3"}, "static_batched or batched_prefill_is_bit or b32"),
+                                        ({"GL3_BDK_P": "2", "GL3_BDK_DA": "8", "GL3_BDK_GU": "0"}, "static_batched or b32")],
+                         ids=["three-producers", "two-producers-ring-of-8"])
+def test_k_split_small_batch_gemm_stays_bit_exact(env, select):
     """GL3_BDK=1: the static-batched decode / small-chunk GEMM with K split over producer wavefronts and an ordered chain wavefront (gl3_bdk_gemm.h,
-    off by default: measured slower) against the same parity tests as the default one-wavefront-per-tile kernel."""
-    e = dict(os.environ, GL3_BDK="1", GL3_BDK_P="3")
+    off by default: measured slower) against the same parity tests as the default one-wavefront-per-tile kernel; the second form runs the ring of
+    8 tiles per producer (single-matrix classes) beside the default gate + up kernel."""
+    e = dict(os.environ, GL3_BDK="1", **env)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_decode.py"), os.path.join(ROOT, "tests", "test_gpu_fullsize.py"),
-                          "-m", "gpu", "-x", "-q", "-k", "static_batched or batched_prefill_is_bit or b32", "-p", "no:cacheprovider"],
+                          "-m", "gpu", "-x", "-q", "-k", select, "-p", "no:cacheprovider"],
                          capture_output=True, text=True, timeout=800, env=e, cwd=ROOT)
     tail = out.stdout[-1500:] + out.stderr[-500:]
     assert out.returncode == 0, tail
